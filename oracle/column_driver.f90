@@ -1,0 +1,128 @@
+! TEST INFRASTRUCTURE (fixture capture only; built by oracle/build_ref.sh `model`, never shipped, never timed).
+!
+! A stripped time loop that sequences the reference's own, unmodified, compiled routines for ONE configuration
+! class: 1-D column, microphysics on, chemistry on, no nucleation, water surface, fresh start.  It exists because
+! the reference's main program (src/str.f90:72-560) calls write_grid (src/str.f90:216) unconditionally, and that
+! routine lives in src/out_netCDF.f which needs netcdf.inc/libnetcdf — absent from this image.  Instead of faking
+! that library, this harness simply never calls any output routine (netCDF, binary plots, restart files): those
+! do not feed back into the model state.  Everything that does (dynamics, microphysics, radiation, photolysis,
+! chemistry stem) is called in the order the reference's loop uses (src/str.f90:198-300 start-up, 324-516 loop).
+!
+! Purpose: reach realistic cloudy-layer chemistry states so that oracle/capture_wrap.c can record real
+! INTEGRATE_g/a/t inputs and outputs (/GDATA_x/) for tests/golden/.
+program mistra_column_capture
+  use config, only: read_config, box, chamber, chem, mic, nuc, rst, isurf, lstmax, z_box, lpJoyce14bc, lpBuys13_0D
+  use global_params, only: n, nf, nm, nphrxn, nrlay, mbs
+  use precision, only: dp
+  implicit none
+
+  interface
+     subroutine equil(ncase, kk)
+       integer, intent(in) :: ncase
+       integer, optional, intent(in) :: kk
+     end subroutine equil
+  end interface
+
+  real(dp), parameter :: dt_slow = 60._dp, dt_fast = 10._dp
+  character(len=1), parameter :: tag = 'a'
+  integer :: minutes, sub, k, nbl
+  real(dp) :: xra, u0_floor
+  logical :: daylight
+
+  ! the handful of reference COMMON members this loop has to advance itself
+  real(dp) :: u0, albedo, thk
+  common /cb16/ u0, albedo(mbs), thk(nrlay)
+  real(dp) :: time
+  integer :: lday, lst, lmin, it, lcl, lct
+  common /cb40/ time, lday, lst, lmin, it, lcl, lct
+  real(dp) :: sk, sl, dtrad, dtcon
+  common /cb48/ sk, sl, dtrad(n), dtcon(n)
+  real(dp) :: theta, thetl, t, talt, p, rho
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  real(dp) :: photol_j
+  common /band_rat/ photol_j(nphrxn, n)
+
+  call read_config
+  if (box .or. chamber .or. nuc .or. rst .or. (.not. chem) .or. (.not. mic) .or. isurf /= 0) then
+     write (0, *) 'mistra_column_capture: only 1-D, mic=T, chem=T, nuc=F, rst=F, isurf=0 namelists are supported'
+     stop 2
+  end if
+  nbl = nf
+  xra = 0._dp
+
+  ! ---- start-up
+  call grid
+  call openm(tag)
+  call openc(tag)
+  call mk_interface
+  call initm(tag, rst)
+  call initc(nbl)
+  call atk0
+  call equil(0)
+  call radiation(.true.)
+  call oneD_dist_jjb
+  call constm
+  call constc
+  call profm(dt_slow)
+  call profc(dt_slow, mic)
+  call photol_initialize
+  call photol
+  call out_mass
+  time = 0._dp
+  u0_floor = merge(1.75e-2_dp, 3.48e-2_dp, lpBuys13_0D)
+
+  ! ---- minutes
+  do minutes = 1, 60 * lstmax
+     it = minutes
+     if (lct > nf) stop 'cloud top above nf'
+     lmin = lmin + 1
+     if (lmin == 60) then
+        lmin = 0
+        lst = lst + 1
+        if (lst == 24) then
+           lst = 0
+           lday = lday + 1
+        end if
+     end if
+     call partdep(xra)
+     do sub = 1, 6
+        time = time + dt_fast
+        call difm(dt_fast)
+        call difc(dt_fast)
+        call difp(dt_fast)
+        call kon(dt_fast, chem)
+        call sedp(dt_fast)
+        call equil(2)
+        do k = 2, nm
+           t(k) = t(k) + dtrad(k) * dt_fast
+        end do
+        call surf0(dt_fast)
+        call sedc(dt_fast)
+        call sedl(dt_fast)
+        call stem_kpp(dt_fast, xra, z_box, nbl, box, chamber, nuc)
+     end do
+     call radiation(.false.)
+     ! photolysis refresh rule of the reference loop
+     if (lpJoyce14bc) then
+        daylight = u0 > 1.0e-2_dp
+        if (daylight) then
+           call photol
+        else
+           photol_j(:, :) = 0._dp
+        end if
+     else if (u0 > u0_floor) then
+        if (mod(lmin, 2) == 0) call photol
+     else
+        photol_j(:, :) = 0._dp
+     end if
+     if (mod(lmin, 15) == 0) then
+        call oneD_dist_jjb
+        call out_mass
+     end if
+     if (mod(lmin, 60) == 0) then
+        call profm(dt_slow)
+        call profc(dt_slow, mic)
+     end if
+     if (mod(minutes, 10) == 0) write (0, '(a,i5,a,i3,a,i3)') ' [column] minute ', minutes, '  lcl ', lcl, '  lct ', lct
+  end do
+end program mistra_column_capture
