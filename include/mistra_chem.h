@@ -1,0 +1,73 @@
+/* mistra_chem.h — C ABI of the MI355X-native chemistry integrator (libmistra_chem.so).
+ *
+ * This is the drop-in boundary for ONE path of the reference model (Mistra-UEA/Mistra): the per-grid-cell KPP
+ * Rosenbrock (Ros3) integrator of the gas / aer / tot mechanisms.  Each entry point below names the reference
+ * interface it replaces (file:line under the reference's src/).  Plain pointers and sizes only.
+ *
+ * Semantics shared by the integrate calls (what the reference does for one cell, gas.f:710-773):
+ *   input   VAR(NVAR), FIX(NFIX), RCONST(NREACT)   = COMMON /GDATA_x/  C(1:NVAR), C(NVAR+1:NSPEC), RCONST
+ *                                                    (gas_Global.h:29-41 | aer_Global.h | tot_Global.h)
+ *   options fixed as INTEGRATE_x fixes them: Ros3, RTOL 1e-3, ATOL 1e-25 (scalar), Hstart 1e-3 s, Hmin 0,
+ *           Hmax |TOUT-TIN|, FacMin 0.2, FacMax 6, FacRej 0.1, FacSafe 0.9, at most 100000 steps (gas.f:739-746, 950-1043)
+ *   output  VAR after integrating from TIN to TOUT; ierr = 1 on success or the negative code of
+ *           ros_ErrorMsg_x (gas.f:1474-1509: -6 too many steps, -7 step too small, -8 matrix repeatedly singular);
+ *           like the reference, VAR then holds whatever state was reached ("print and continue", gas.f:764-767);
+ *           stats = COMMON /Statistics/ for that call: Nfun,Njac,Nstp,Nacc,Nrej,Ndec,Nsol,Nsng (gas.f:913-915).
+ * Arrays are cell-major: cell c occupies [c*N, (c+1)*N).  Cells are independent (kpp.f90:4310-4470 loops over k).
+ * All functions return 0 on success, non-zero on error (mistra_chem_last_error() gives the text).  There is no CPU
+ * fallback: without a usable HIP device every compute entry point fails.
+ */
+#ifndef MISTRA_CHEM_H
+#define MISTRA_CHEM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISTRA_MECH_GAS 0 /* gas.f  : NVAR 102, NFIX 3, NREACT 331, LU_NONZERO 1110  */
+#define MISTRA_MECH_AER 1 /* aer.f  : NVAR 257, NFIX 5, NREACT 979, LU_NONZERO 6579  */
+#define MISTRA_MECH_TOT 2 /* tot.f  : NVAR 417, NFIX 7, NREACT 1627, LU_NONZERO 13503 */
+
+/* Select the HIP device, load the three mechanism tables (directory: env MISTRA_MECH_DIR, else ../mech next to the
+ * library) and upload their kernel schedules.  Replaces nothing in the reference (its tables are compiled in:
+ * BLOCK DATA JACOBIAN_SPARSE_DATA_x, gas.f:6718 | aer.f:23480 | tot.f:44435); call once before anything else. */
+int mistra_chem_init(int device);
+
+/* Release device memory.  Safe to call more than once. */
+void mistra_chem_finalize(void);
+
+/* Sizes of a mechanism (gas_Parameters.h:28-49 and siblings).  Any pointer may be NULL.  Works before init. */
+int mistra_chem_dims(int mech, int* nvar, int* nfix, int* nreact, int* lu_nonzero);
+
+/* INTEGRATE_x(TIN,TOUT) for ncell cells, host buffers (gas.f:710 | aer.f:1408 | tot.f:2812; called by x_drive at
+ * gas.f:173 | aer.f:217 | tot.f:604).  Copies inputs to the device, integrates, copies results back, synchronous.
+ * var_out may alias var_in.  ierr (ncell) and stats (ncell*8) may be NULL. */
+int mistra_chem_integrate(int mech, int ncell, const double* var_in, const double* fix, const double* rconst,
+                          double tin, double tout, double* var_out, int32_t* ierr, int32_t* stats);
+
+/* Same call on device-resident buffers (hipMalloc'ed or torch tensors on the selected device), asynchronous on
+ * `hip_stream` (a hipStream_t; NULL = default stream).  d_ierr (ncell) and d_stats (ncell*8) are required;
+ * d_texit_hexit (ncell*2: what INTEGRATE_x leaves in TIN and STEPMIN, gas.f:769-770) may be NULL. */
+int mistra_chem_integrate_device(int mech, int ncell, const double* d_var_in, const double* d_fix,
+                                 const double* d_rconst, double tin, double tout, double* d_var_out,
+                                 int32_t* d_ierr, int32_t* d_stats, double* d_texit_hexit, void* hip_stream);
+
+/* Fortran-callable per-cell entry points with the reference's own signature, `SUBROUTINE INTEGRATE_x(TIN,TOUT)`
+ * (REAL*8 by reference; data through COMMON /GDATA_x/).  `gdata` is the address of that COMMON block, laid out
+ * C(NSPEC), RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX (gas_Global.h:29-58).  On return VAR
+ * is updated in place, *tin = exit time, STEPMIN = last step size, ATOL/RTOL are set as INTEGRATE_x sets them, and an
+ * unsuccessful integration prints the reference's message.  The ISO_C_BINDING shim in shim/ passes the COMMON block. */
+int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tout);
+
+/* Text of the last error on this thread ("" if none). */
+const char* mistra_chem_last_error(void);
+
+/* One line describing the schedule built for a mechanism (rounds, slots); for logs. */
+const char* mistra_chem_describe(int mech);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISTRA_CHEM_H */

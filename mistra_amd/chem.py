@@ -1,0 +1,144 @@
+"""Host-side mirror of the reference's integrator interface over the C ABI (include/mistra_chem.h).
+
+The reference exposes, per mechanism x in {g, a, t}, `SUBROUTINE INTEGRATE_x(TIN, TOUT)` working on
+`COMMON /GDATA_x/ C(NSPEC), RCONST(NREACT), ...` (gas.f:710, gas_Global.h:29-58 | aer.f:1408 | tot.f:2812).
+Here the same call takes the arrays explicitly and handles any number of cells:
+
+    integrate("tot", var, fix, rconst, tin=0.0, tout=10.0) -> IntegrateResult(var, ierr, stats)
+
+`var`, `fix`, `rconst` are cell-major arrays [ncell, NVAR|NFIX|NREACT]: numpy arrays go through the host-buffer
+entry point, torch CUDA tensors stay on the device (`mistra_chem_integrate_device`, asynchronous on the current
+torch stream).  There is no CPU implementation in this package: without the HIP library and a GPU the calls raise.
+"""
+import ctypes as C
+import os
+from collections import namedtuple
+
+import numpy as np
+
+from .mechtab import MECH_IDS, MECH_NAMES
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmistra_chem.so")
+
+DIMS = {"gas": (102, 3, 331, 1110), "aer": (257, 5, 979, 6579), "tot": (417, 7, 1627, 13503)}
+STAT_NAMES = ("Nfun", "Njac", "Nstp", "Nacc", "Nrej", "Ndec", "Nsol", "Nsng")   # COMMON /Statistics/, gas.f:913
+IERR_TEXT = {1: "success", -6: "too many steps", -7: "step size too small", -8: "matrix repeatedly singular"}
+
+IntegrateResult = namedtuple("IntegrateResult", "var ierr stats")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lib = None
+_inited_device = None
+
+
+class MistraChemError(RuntimeError):
+    pass
+
+
+def lib():
+    """The C-ABI library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MistraChemError("HIP library %s is missing: run `python -m mistra_amd.build` (or __graft_entry__.build())"
+                                  % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.mistra_chem_init.argtypes = [C.c_int]
+        L.mistra_chem_finalize.restype = None
+        L.mistra_chem_dims.argtypes = [C.c_int, _ip, _ip, _ip, _ip]
+        L.mistra_chem_integrate.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip]
+        L.mistra_chem_integrate_device.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                                   C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mistra_chem_integrate_common.argtypes = [C.c_int, C.c_void_p, _dp, _dp]
+        L.mistra_chem_last_error.restype = C.c_char_p
+        L.mistra_chem_describe.restype = C.c_char_p
+        L.mistra_chem_describe.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MistraChemError(lib().mistra_chem_last_error().decode())
+
+
+def init(device=0):
+    """Select the GPU, load mechanism tables and upload the kernel schedules (idempotent per device)."""
+    global _inited_device
+    if _inited_device != device:
+        _check(lib().mistra_chem_init(int(device)))
+        _inited_device = device
+
+
+def finalize():
+    global _inited_device
+    if _lib is not None:
+        _lib.mistra_chem_finalize()
+    _inited_device = None
+
+
+def describe(mech):
+    return lib().mistra_chem_describe(MECH_IDS[mech]).decode()
+
+
+def _mech_id(mech):
+    if isinstance(mech, str):
+        return MECH_IDS[mech], mech
+    return int(mech), MECH_NAMES[int(mech)]
+
+
+def integrate(mech, var, fix, rconst, tin=0.0, tout=10.0, device=None):
+    """INTEGRATE_x over a batch of cells.  numpy in -> numpy out (synchronous); torch CUDA tensors in -> torch
+    tensors out on the same device, enqueued on the current torch stream."""
+    mid, name = _mech_id(mech)
+    nvar, nfix, nreact, _ = DIMS[name]
+    try:
+        import torch
+        is_torch = isinstance(var, torch.Tensor)
+    except ImportError:      # pragma: no cover
+        is_torch = False
+    if is_torch:
+        return _integrate_torch(mid, name, var, fix, rconst, tin, tout)
+    init(0 if device is None else device)
+    v = np.ascontiguousarray(var, np.float64).reshape(-1, nvar)
+    ncell = v.shape[0]
+    f = np.ascontiguousarray(fix, np.float64).reshape(ncell, nfix)
+    r = np.ascontiguousarray(rconst, np.float64).reshape(ncell, nreact)
+    out = np.empty_like(v)
+    ierr = np.zeros(ncell, np.int32)
+    stats = np.zeros((ncell, 8), np.int32)
+    _check(lib().mistra_chem_integrate(mid, ncell, v.ctypes.data_as(_dp), f.ctypes.data_as(_dp), r.ctypes.data_as(_dp),
+                                      float(tin), float(tout), out.ctypes.data_as(_dp), ierr.ctypes.data_as(_ip),
+                                      stats.ctypes.data_as(_ip)))
+    return IntegrateResult(out, ierr, stats)
+
+
+def _integrate_torch(mid, name, var, fix, rconst, tin, tout, out=None, ierr=None, stats=None):
+    import torch
+    nvar, nfix, nreact, _ = DIMS[name]
+    if not var.is_cuda:
+        raise MistraChemError("torch tensors must live on the GPU (there is no CPU path); pass numpy arrays for host data")
+    dev = var.device.index or 0
+    init(dev)
+    for x, n in ((var, nvar), (fix, nfix), (rconst, nreact)):
+        if x.dtype != torch.float64 or not x.is_contiguous() or x.shape[-1] != n or x.device != var.device:
+            raise MistraChemError("expected contiguous float64 [ncell,%d] tensors on one device" % n)
+    ncell = var.numel() // nvar
+    if fix.numel() != ncell * nfix or rconst.numel() != ncell * nreact:
+        raise MistraChemError("cell counts of var / fix / rconst differ")
+    out = torch.empty_like(var) if out is None else out
+    ierr = torch.empty(ncell, dtype=torch.int32, device=var.device) if ierr is None else ierr
+    stats = torch.empty((ncell, 8), dtype=torch.int32, device=var.device) if stats is None else stats
+    stream = torch.cuda.current_stream(var.device).cuda_stream
+    _check(lib().mistra_chem_integrate_device(mid, ncell, var.data_ptr(), fix.data_ptr(), rconst.data_ptr(), float(tin),
+                                             float(tout), out.data_ptr(), ierr.data_ptr(), stats.data_ptr(), None,
+                                             C.c_void_p(stream)))
+    return IntegrateResult(out, ierr, stats)
+
+
+def integrate_into(mech, var, fix, rconst, out, ierr, stats, tin=0.0, tout=10.0):
+    """Device path with caller-owned output tensors (no allocation inside the timed region of bench.py)."""
+    mid, name = _mech_id(mech)
+    return _integrate_torch(mid, name, var, fix, rconst, tin, tout, out, ierr, stats)

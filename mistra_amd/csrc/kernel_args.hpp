@@ -1,0 +1,43 @@
+// Plain-old-data argument blocks shared by the host API (capi.cpp) and the device code (ros3_kernel.hip).
+#pragma once
+#include <cstdint>
+
+namespace mistra {
+
+struct VmDev {                 // LDS VM program in device memory (see schedule.hpp)
+  const uint32_t* blk_base;
+  const uint16_t* blk_n;
+  const uint32_t* words;
+  int nrounds;
+};
+
+struct GsDev {                 // gather-sum program in device memory
+  const uint32_t* blk_base;
+  const uint16_t* blk_n;
+  const uint32_t* idx;
+  const float* coef;
+};
+
+struct KernelArgs {
+  // per-cell data, cell-major (one cell's VAR / FIX / RCONST contiguous, as COMMON /GDATA_x/ holds them)
+  const double* var_in;        // [ncell][NVAR]
+  const double* fix;           // [ncell][NFIX]
+  const double* rconst;        // [ncell][NREACT]
+  double* var_out;             // [ncell][NVAR]   may alias var_in
+  int32_t* ierr;               // [ncell]         1 = success, <0 = ros_ErrorMsg code (gas.f:1474)
+  int32_t* stats;              // [ncell][8]      Nfun,Njac,Nstp,Nacc,Nrej,Ndec,Nsol,Nsng  (COMMON /Statistics/)
+  double* texit_hexit;         // [ncell][2] or null: what INTEGRATE_x leaves in TIN and STEPMIN
+  double tin, tout;
+  int32_t ncell;
+  // mechanism schedule
+  const double* consts;        // [NCONST]
+  const uint64_t* fun_fac;
+  const uint64_t* jac_fac;
+  const uint16_t* jvs_pos;
+  const uint16_t* zero_pos;
+  const uint16_t* diag_pos;
+  GsDev vdot, jvs;
+  VmDev lu, solve;
+};
+
+}  // namespace mistra

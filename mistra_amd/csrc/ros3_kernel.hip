@@ -1,0 +1,389 @@
+// One workgroup integrates one grid cell: the whole Ros3 Rosenbrock step loop of the reference
+// (INTEGRATE_x -> Rosenbrock_x -> RosenbrockIntegrator_x, gas.f:710-1337 | aer.f:1408-2035 | tot.f:2812-3439)
+// runs inside the kernel with the cell's state on chip:
+//
+//   LDS        M  = [ Ghimj (LU_NONZERO) | XS (NVAR) ]   matrix being factorised / solve vector   (LDS VM memory)
+//              X  = [ V (NVAR) | F (NFIX) | consts ]     extended species vector read by Fun/Jac products
+//              AB = A(NREACT) or B(NB)                   rate products, then Jacobian products
+//   registers  one species per lane-slot: Y, Ynew, Fcn0, Fcn, K1..K3 (thread t owns species q*NT+t);
+//              RCONST of the reactions the thread owns; the structurally non-zero entries of Jac0
+//   HBM        read VAR, FIX, RCONST once (coalesced, cell-major), write VAR once; schedule words stream from L2
+//
+// gfx950 only.  Built with -ffp-contract=off: every multiply and add/subtract rounds once, as in the reference
+// built without FMA contraction.  No MFMA: there is no dense contraction in this path.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernel_args.hpp"
+#include "ros3_kernel.hpp"
+
+namespace mistra {
+
+namespace {
+
+constexpr uint32_t kVmIdxBits = 14, kVmIdxMask = (1u << 14) - 1;
+constexpr uint32_t kVmHdr = 1u << 28, kVmEnd = 1u << 29, kVmDiv = 1u << 30, kVmNop = 1u << 31;
+constexpr uint32_t kGsFirst = 1u << 16, kGsNop = 1u << 17;
+constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
+
+// Ros3_x (gas.f:1596-1626)
+constexpr double kRosA1 = 1.0;
+constexpr double kRosC1 = -0.10156171083877702091975600115545e+01;
+constexpr double kRosC2 = 0.40759956452537699824805835358067e+01;
+constexpr double kRosC3 = 0.92076794298330791242156818474003e+01;
+constexpr double kRosM1 = 0.1e+01;
+constexpr double kRosM2 = 0.61697947043828245592553615689730e+01;
+constexpr double kRosM3 = -0.42772256543218573326238373806514e+00;
+constexpr double kRosE1 = 0.5e+00;
+constexpr double kRosE2 = -0.29079558716805469821718236208017e+01;
+constexpr double kRosE3 = 0.22354069897811569627360909276199e+00;
+constexpr double kRosGamma1 = 0.43586652150845899941601945119356e+00;
+constexpr double kRosGamma2 = 0.24291996454816804366592249683314e+00;
+constexpr double kRosGamma3 = 0.21851380027664058511513169485832e+01;
+constexpr double kRosElo = 3.0;
+
+__device__ __forceinline__ double fmin_f(double a, double b) { return (a < b || b != b) ? a : b; }   // Fortran MIN
+__device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || b != b) ? a : b; }   // Fortran MAX
+
+// ---- the LDS VM (schedule.hpp): one program = rounds separated by workgroup barriers
+template <int NT>
+__device__ __forceinline__ void vm_run(const VmDev& P, double* __restrict__ M, int wave, int lane) {
+  constexpr int NW = NT / 64;
+  for (int r = 0; r < P.nrounds; r++) {
+    const int n = P.blk_n[r * NW + wave];
+    const uint32_t* __restrict__ wp = P.words + (size_t)P.blk_base[r * NW + wave] * 64 + lane;
+    double acc = 0.0, dv = 1.0;
+    uint32_t tg = 0;
+    for (int i = 0; i < n; i++) {
+      const uint32_t wd = wp[(size_t)i * 64];
+      const uint32_t i1 = wd & kVmIdxMask, i2 = (wd >> kVmIdxBits) & kVmIdxMask;
+      const double x = M[i1], y = M[i2];
+      if (wd & kVmHdr) {
+        acc = x;
+        dv = y;
+        tg = i1;
+      } else if (!(wd & kVmNop)) {
+        const double p = x * y;
+        acc = acc - p;
+      }
+      if (wd & kVmEnd) M[tg] = (wd & kVmDiv) ? acc / dv : acc;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- the gather-sum machine: out[q] = c0*src[i0] + c1*src[i1] + ...  (left to right)
+template <int NT, int NQ>
+__device__ __forceinline__ void gsum_run(const GsDev& P, const double* __restrict__ src, double (&out)[NQ], int wave, int lane) {
+  constexpr int NW = NT / 64;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const int n = P.blk_n[q * NW + wave];
+    const size_t off = (size_t)P.blk_base[q * NW + wave] * 64 + lane;
+    double acc = 0.0;
+    for (int i = 0; i < n; i++) {
+      const uint32_t wd = P.idx[off + (size_t)i * 64];
+      const float cf = P.coef[off + (size_t)i * 64];
+      const double term = (double)cf * src[wd & 0xFFFFu];
+      if (!(wd & kGsNop)) acc = (wd & kGsFirst) ? term : acc + term;
+    }
+    out[q] = acc;
+  }
+}
+
+}  // namespace
+
+template <class MT, int NT>
+__global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) {
+  constexpr int NVAR = MT::NVAR, NFIX = MT::NFIX, NREACT = MT::NREACT, NNZ = MT::NNZ, NB = MT::NB, NCONST = MT::NCONST;
+  constexpr int NW = NT / 64;
+  constexpr int SPT = (NVAR + NT - 1) / NT, RPT = (NREACT + NT - 1) / NT;
+  constexpr int JPT = (MT::NJNZ + NT - 1) / NT, ZPT = (NNZ - MT::NJNZ + NT - 1) / NT;
+  using L = LdsLayout<MT, NT>;
+
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* const M = lds + L::M;
+  double* const XS = M + NNZ;
+  double* const X = lds + L::X;
+  double* const AB = lds + L::AB;
+  double* const red = lds + L::RED;
+  int* const flags = reinterpret_cast<int*>(lds + L::FLAGS);
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int cell = blockIdx.x;
+  if (cell >= a.ncell) return;
+
+  // ---- per-cell inputs: coalesced cell-major reads, once
+  double y[SPT], rct[RPT];
+#pragma unroll
+  for (int q = 0; q < SPT; q++) {
+    const int s = q * NT + t;
+    y[q] = s < NVAR ? a.var_in[(size_t)cell * NVAR + s] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; q++) {
+    const int r = q * NT + t;
+    rct[q] = r < NREACT ? a.rconst[(size_t)cell * NREACT + r] : 0.0;
+  }
+  if (t < NFIX) X[NVAR + t] = a.fix[(size_t)cell * NFIX + t];
+  if (t < NCONST) X[NVAR + NFIX + t] = a.consts[t];
+
+  // ---- Fun_x (gas.f:2043): X <- v; A(r) = RCT(r)*X*X*X; Vdot = signed sums of A
+  auto fun = [&](const double (&v)[SPT], double (&out)[SPT]) {
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {
+      const int s = q * NT + t;
+      if (s < NVAR) X[s] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RPT; q++) {
+      const uint64_t w = a.fun_fac[q * NT + t];
+      double p = rct[q] * X[w & 0xFFFFu];
+      p = p * X[(w >> 16) & 0xFFFFu];
+      p = p * X[(w >> 32) & 0xFFFFu];
+      if ((w >> 48) & 1u) AB[q * NT + t] = p;
+    }
+    __syncthreads();
+    gsum_run<NT, SPT>(a.vdot, AB, out, wave, lane);
+  };
+
+  // ---- Jac_SP_x (gas.f:2656) on the V already in X: B products under their reaction, JVS sums into registers
+  double jac0[JPT];
+  auto jac = [&]() {
+    __syncthreads();   // every lane is done reading AB as A
+#pragma unroll
+    for (int q = 0; q < RPT; q++) {
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const uint64_t w = a.jac_fac[(q * 3 + b) * NT + t];
+        double p = rct[q] * X[w & 0xFFFFu];
+        p = p * X[(w >> 16) & 0xFFFFu];
+        p = p * X[(w >> 32) & 0xFFFFu];
+        const uint32_t o = (uint32_t)(w >> 48);
+        if (o != 0xFFFFu) AB[o] = p;
+      }
+    }
+    __syncthreads();
+    gsum_run<NT, JPT>(a.jvs, AB, jac0, wave, lane);
+  };
+
+  // ---- ros_PrepareMatrix_x (gas.f:1404), first half: Ghimj = -Jac0, diagonal += 1/(H*gamma).
+  //      Returns (workgroup-uniform) whether a diagonal is exactly zero, the condition KppDecomp_x tests (gas.f:6157).
+  auto prepare = [&](double ghinv) -> bool {
+    if (t == 0) flags[0] = 0;
+    __syncthreads();   // also: all readers of M from the previous attempt are done
+    bool zero_diag = false;
+#pragma unroll
+    for (int q = 0; q < JPT; q++) {
+      const uint16_t p = a.jvs_pos[q * NT + t];
+      if (p != kPosNone) {
+        double v = -jac0[q];
+        if (p & kPosDiag) {
+          v = v + ghinv;
+          zero_diag |= (v == 0.0);
+        }
+        M[p & 0x7FFFu] = v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < ZPT; q++) {
+      const uint16_t p = a.zero_pos[q * NT + t];
+      if (p != kPosNone) {
+        double v = -0.0;
+        if (p & kPosDiag) {
+          v = v + ghinv;
+          zero_diag |= (v == 0.0);
+        }
+        M[p & 0x7FFFu] = v;
+      }
+    }
+    if (zero_diag) flags[0] = 1;
+    __syncthreads();
+    return flags[0] != 0;
+  };
+
+  // ---- KppSolve_x (gas.f:6206) on a register vector
+  auto solve = [&](double (&k)[SPT]) {
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {
+      const int s = q * NT + t;
+      if (s < NVAR) XS[s] = k[q];
+    }
+    __syncthreads();
+    vm_run<NT>(a.solve, M, wave, lane);
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {
+      const int s = q * NT + t;
+      if (s < NVAR) k[q] = XS[s];
+    }
+  };
+
+  // ---- ros_ErrorNorm_x (gas.f:1341): wave shuffle reduction, then the NW partial sums in a fixed order
+  auto error_norm = [&](const double (&y0)[SPT], const double (&y1)[SPT], const double (&ye)[SPT]) -> double {
+    double part = 0.0;
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {
+      const int s = q * NT + t;
+      if (s < NVAR) {
+        const double ymax = fmax_f(fabs(y0[q]), fabs(y1[q]));
+        const double scale = 1.0e-25 + 1.0e-3 * ymax;
+        const double e = ye[q] / scale;
+        part = part + e * e;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    __syncthreads();   // red[] may still be read from the previous step
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) sum += red[w];
+    return sqrt(sum / (double)NVAR);
+  };
+
+  // ---- RosenbrockIntegrator_x (gas.f:1180-1336); option values are the ones INTEGRATE_x/Rosenbrock_x fix
+  const double Tstart = a.tin, Tend = a.tout;
+  const double Roundoff = 2.220446049250313e-16, Hmin = 0.0, Hmax = fabs(Tend - Tstart);
+  const double FacMin = 0.2, FacMax = 6.0, FacRej = 0.1, FacSafe = 0.9;
+  const double Direction = (Tend >= Tstart) ? 1.0 : -1.0;
+  double T = Tstart, Hexit = 0.0;
+  double H = fmin_f(fmin_f(1.0e-3, fabs(Tend - Tstart)), Hmax);
+  if (fabs(H) <= 10.0 * Roundoff) H = 1.0e-5;
+  bool RejectLastH = false, RejectMoreH = false;
+  int nfun = 0, njac = 0, nstp = 0, nacc = 0, nrej = 0, ndec = 0, nsol = 0, nsng = 0;
+  int ierr = 1;
+
+  double ynew[SPT], fcn0[SPT], fcn[SPT], k1[SPT], k2[SPT], k3[SPT], yerr[SPT];
+
+  while (fabs(Tend - T) >= Roundoff) {
+    if (nstp > 100000) { ierr = -6; break; }
+    if (((T + 0.1 * H) == T) || (H <= Roundoff)) { ierr = -7; break; }
+    Hexit = H;
+    H = fmin_f(H, fabs(Tend - T));
+
+    fun(y, fcn0);
+    // ros_FunTimeDerivative_x (gas.f:1375): Fun_x does not depend on T and RCONST is frozen, so
+    // dFdT = (1/Delta)*(Fun - Fcn0) is an exact +0.0; the evaluation is skipped, its count and its "+ HG*0.0" are kept.
+    nfun += 2;
+    jac();
+    njac += 1;
+
+    bool accepted = false;
+    while (!accepted) {
+      {
+        int nconsecutive = 0;
+        bool singular = true;
+        while (singular) {
+          const double ghinv = 1.0 / (Direction * H * kRosGamma1);
+          singular = prepare(ghinv);
+          ndec += 1;
+          if (singular) {
+            __syncthreads();   // everyone has read flags[0] before the retry clears it
+            nsng += 1;
+            nconsecutive += 1;
+            if (nconsecutive <= 5) H = H * 0.5;
+            else { ierr = -8; break; }
+          } else {
+            vm_run<NT>(a.lu, M, wave, lane);
+          }
+        }
+        if (ierr == -8) break;
+      }
+      const double dh = Direction * H;
+      // stage 1
+#pragma unroll
+      for (int q = 0; q < SPT; q++) k1[q] = fcn0[q] + (dh * kRosGamma1) * 0.0;
+      solve(k1);
+      // stage 2: new function value at Y + A21*K1
+#pragma unroll
+      for (int q = 0; q < SPT; q++) ynew[q] = y[q] + kRosA1 * k1[q];
+      fun(ynew, fcn);
+      nfun += 1;
+      {
+        const double hc = kRosC1 / dh;
+#pragma unroll
+        for (int q = 0; q < SPT; q++) k2[q] = (fcn[q] + hc * k1[q]) + (dh * kRosGamma2) * 0.0;
+      }
+      solve(k2);
+      // stage 3 reuses the stage-2 function value
+      {
+        const double hc1 = kRosC2 / dh, hc2 = kRosC3 / dh;
+#pragma unroll
+        for (int q = 0; q < SPT; q++) k3[q] = ((fcn[q] + hc1 * k1[q]) + hc2 * k2[q]) + (dh * kRosGamma3) * 0.0;
+      }
+      solve(k3);
+      nsol += 3;
+#pragma unroll
+      for (int q = 0; q < SPT; q++) {
+        ynew[q] = ((y[q] + kRosM1 * k1[q]) + kRosM2 * k2[q]) + kRosM3 * k3[q];
+        yerr[q] = ((0.0 + kRosE1 * k1[q]) + kRosE2 * k2[q]) + kRosE3 * k3[q];
+      }
+      const double Err = error_norm(y, ynew, yerr);
+      const double Fac = fmin_f(FacMax, fmax_f(FacMin, FacSafe / pow(Err, 1.0 / kRosElo)));
+      double Hnew = H * Fac;
+      nstp += 1;
+      if ((Err <= 1.0) || (H <= Hmin)) {
+        nacc += 1;
+#pragma unroll
+        for (int q = 0; q < SPT; q++) y[q] = ynew[q];
+        T = T + dh;
+        Hnew = fmax_f(Hmin, fmin_f(Hnew, Hmax));
+        if (RejectLastH) Hnew = fmin_f(Hnew, H);
+        RejectLastH = false;
+        RejectMoreH = false;
+        H = Hnew;
+        accepted = true;
+      } else {
+        if (RejectMoreH) Hnew = H * FacRej;
+        RejectMoreH = RejectLastH;
+        RejectLastH = true;
+        H = Hnew;
+        if (nacc >= 1) nrej += 1;
+      }
+    }
+    if (ierr < 0) break;
+  }
+
+  // ---- results
+#pragma unroll
+  for (int q = 0; q < SPT; q++) {
+    const int s = q * NT + t;
+    if (s < NVAR) a.var_out[(size_t)cell * NVAR + s] = y[q];
+  }
+  if (t == 0) {
+    a.ierr[cell] = ierr;
+    int32_t* st = a.stats + (size_t)cell * 8;
+    st[0] = nfun; st[1] = njac; st[2] = nstp; st[3] = nacc; st[4] = nrej; st[5] = ndec; st[6] = nsol; st[7] = nsng;
+    if (a.texit_hexit) {
+      a.texit_hexit[(size_t)cell * 2] = T;
+      a.texit_hexit[(size_t)cell * 2 + 1] = Hexit;
+    }
+  }
+}
+
+// ---- launchers (one explicit instantiation per supported <mechanism, workgroup size>)
+template <class MT, int NT>
+hipError_t launch_ros3(const KernelArgs& a, hipStream_t stream) {
+  constexpr size_t lds_bytes = LdsLayout<MT, NT>::TOTAL * sizeof(double);
+  static bool configured = false;
+  auto kern = ros3_integrate_kernel<MT, NT>;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  if (a.ncell <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.ncell), dim3(NT), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+template hipError_t launch_ros3<GasTraits, 128>(const KernelArgs&, hipStream_t);
+template hipError_t launch_ros3<AerTraits, 512>(const KernelArgs&, hipStream_t);
+template hipError_t launch_ros3<TotTraits, 512>(const KernelArgs&, hipStream_t);
+template hipError_t launch_ros3<TotTraits, 1024>(const KernelArgs&, hipStream_t);
+
+}  // namespace mistra

@@ -1,0 +1,35 @@
+// Compile-time mechanism sizes and the LDS carve-up shared by the kernel and its launcher.
+// Sizes: gas_Parameters.h:28-49 | aer_Parameters.h:28-49 | tot_Parameters.h:28-49 (NVAR NFIX NREACT LU_NONZERO);
+// NB / NJNZ are counted from Jac_SP_x (number of B products / of JVS slots that are not `= 0`), NCONST from the
+// factor literals (1.0 padding + the 2 of squared reactants).  The host checks the loaded table against these.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernel_args.hpp"
+
+namespace mistra {
+
+struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945; };
+struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831; };
+struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709; };
+
+constexpr int round_up2(int x) { return (x + 1) & ~1; }
+constexpr int max_i(int a, int b) { return a > b ? a : b; }
+
+// offsets in doubles into the dynamic LDS block
+template <class MT, int NT>
+struct LdsLayout {
+  static constexpr int M = 0;                                                          // Ghimj | XS
+  static constexpr int X = M + round_up2(MT::NNZ + MT::NVAR);                          // V | F | consts
+  static constexpr int AB = X + round_up2(MT::NVAR + MT::NFIX + MT::NCONST);           // A or B products
+  static constexpr int RED = AB + round_up2(max_i(MT::NREACT, MT::NB));                // per-wave partial sums
+  static constexpr int FLAGS = RED + 32;
+  static constexpr int TOTAL = FLAGS + 2;
+  static_assert(TOTAL * 8 <= 160 * 1024, "cell state does not fit the 160 KiB LDS of a gfx950 CU");
+  static_assert(NT % 64 == 0 && NT <= 1024 && NT / 64 <= 32, "workgroup size");
+};
+
+template <class MT, int NT>
+hipError_t launch_ros3(const KernelArgs& a, hipStream_t stream);
+
+}  // namespace mistra

@@ -1,0 +1,341 @@
+#include "schedule.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <cstdio>
+#include <map>
+#include <numeric>
+#include <stdexcept>
+
+namespace mistra {
+
+namespace {
+
+struct Item {            // one chunk of one entry inside one round
+  int entry;
+  int first, count;      // range of entry.upd
+  bool div;              // divide by M[dv] before the store
+  int cost() const { return 1 + count; }
+};
+
+uint32_t vm_word(int i1, int i2, uint32_t flags) {
+  if (i1 < 0 || i2 < 0 || (uint32_t)i1 > VM_IDX_MASK || (uint32_t)i2 > VM_IDX_MASK)
+    throw std::logic_error("VM index out of range");
+  return (uint32_t)i1 | ((uint32_t)i2 << VM_IDX_BITS) | flags;
+}
+
+// Snake-deal n work items (already sorted by decreasing cost) over lanes; small sets are packed into few waves.
+std::vector<int> deal(int n, int nt) {
+  std::vector<int> lane((size_t)n);
+  int waves_used = std::max(1, std::min(nt / 64, (n + 63) / 64));
+  int lanes = waves_used * 64;
+  for (int i = 0; i < n; i++) {
+    int pass = i / lanes, pos = i % lanes;
+    lane[i] = (pass & 1) ? (lanes - 1 - pos) : pos;
+  }
+  return lane;
+}
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int nt) {
+  if (nt % 64 != 0 || nt <= 0) throw std::invalid_argument("nt must be a positive multiple of 64");
+  if ((uint32_t)msize > VM_IDX_MASK + 1) throw std::invalid_argument("VM memory exceeds the 14-bit index space");
+  VmProgram P;
+  P.nt = nt;
+  P.nw = nt / 64;
+
+  std::vector<int> fin((size_t)msize, 0);   // round at whose end M[x] holds its final value (0 = input)
+  std::map<int, std::vector<Item>> rounds;
+  int base = 0, phase_max = 0;
+  int phase = entries.empty() ? 0 : entries[0].phase;
+
+  for (size_t e = 0; e < entries.size(); e++) {
+    VmEntry& E = entries[e];
+    if (E.phase != phase) {
+      if (E.phase < phase) throw std::invalid_argument("entries must be ordered by phase");
+      phase = E.phase;
+      base = std::max(base, phase_max);     // the next phase starts after every round of the previous one
+    }
+    const int n = (int)E.upd.size();
+    if (n == 0 && E.dv < 0) continue;       // nothing to do, value stays as it is
+    std::vector<int> ru((size_t)n);
+    for (int i = 0; i < n; i++) {
+      int a = E.upd[i].first, b = E.upd[i].second;
+      if (a == E.tgt || b == E.tgt) throw std::invalid_argument("VM entry reads its own target");
+      ru[i] = std::max({base + 1, fin[a] + 1, fin[b] + 1});      // operands must be final
+    }
+    if (E.keep_order) {
+      for (int i = 1; i < n; i++) ru[i] = std::max(ru[i], ru[i - 1]);   // chunks keep the given order
+    } else {
+      std::vector<int> perm((size_t)n);
+      std::iota(perm.begin(), perm.end(), 0);
+      std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return ru[x] < ru[y]; });
+      std::vector<std::pair<int, int>> u2((size_t)n);
+      std::vector<int> r2((size_t)n);
+      for (int i = 0; i < n; i++) { u2[i] = E.upd[(size_t)perm[i]]; r2[i] = ru[(size_t)perm[i]]; }
+      E.upd.swap(u2);
+      ru.swap(r2);
+    }
+    const int last = n ? ru[n - 1] : base;
+    int rdiv = -1;
+    if (E.dv >= 0) rdiv = std::max({last, fin[E.dv] + 1, base + 1});
+    for (int i = 0; i < n;) {
+      int j = i;
+      while (j < n && ru[j] == ru[i]) j++;
+      bool div = (j == n) && E.dv >= 0 && rdiv == ru[i];
+      rounds[ru[i]].push_back({(int)e, i, j - i, div});
+      i = j;
+    }
+    if (E.dv >= 0 && (n == 0 || rdiv != last)) rounds[rdiv].push_back({(int)e, n, 0, true});
+    int f = E.dv >= 0 ? rdiv : last;
+    fin[E.tgt] = f;
+    phase_max = std::max(phase_max, f);
+  }
+
+  P.nrounds = (int)rounds.size();
+  P.blk_base.assign((size_t)P.nrounds * P.nw, 0);
+  P.blk_n.assign((size_t)P.nrounds * P.nw, 0);
+  int ridx = 0;
+  for (auto& kv : rounds) {
+    std::vector<Item>& items = kv.second;
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost() > b.cost(); });
+    std::vector<int> lane = deal((int)items.size(), nt);
+    std::vector<std::vector<uint32_t>> prog((size_t)nt);
+    for (size_t k = 0; k < items.size(); k++) {
+      const Item& it = items[k];
+      const VmEntry& E = entries[(size_t)it.entry];
+      std::vector<uint32_t>& w = prog[(size_t)lane[k]];
+      uint32_t fin_flags = VM_END | (it.div ? VM_DIV : 0u);
+      // the header's second operand is the divisor only in the chunk that divides; otherwise a harmless re-read of tgt
+      w.push_back(vm_word(E.tgt, it.div ? E.dv : E.tgt, VM_HDR | (it.count == 0 ? fin_flags : 0u)));
+      for (int i = 0; i < it.count; i++) {
+        const auto& u = E.upd[(size_t)(it.first + i)];
+        w.push_back(vm_word(u.first, u.second, i == it.count - 1 ? fin_flags : 0u));
+      }
+      P.n_updates += it.count;
+      P.n_items++;
+    }
+    int crit = 0;
+    for (int wv = 0; wv < P.nw; wv++) {
+      size_t n = 0;
+      for (int l = 0; l < 64; l++) n = std::max(n, prog[(size_t)wv * 64 + l].size());
+      if (n > 0xFFFF) throw std::logic_error("VM block too long");
+      P.blk_base[(size_t)ridx * P.nw + wv] = (uint32_t)(P.words.size() / 64);
+      P.blk_n[(size_t)ridx * P.nw + wv] = (uint16_t)n;
+      for (size_t s = 0; s < n; s++)
+        for (int l = 0; l < 64; l++) {
+          const auto& w = prog[(size_t)wv * 64 + l];
+          P.words.push_back(s < w.size() ? w[s] : VM_NOP);
+        }
+      P.wave_slots += (int64_t)n;
+      crit = std::max(crit, (int)n);
+    }
+    P.crit_slots += crit;
+    ridx++;
+  }
+  return P;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// KppDecomp_x (gas.f:6142-6176), entry view: slot p=(k,c) of row k gets  - L(k,j)*U(j,c)  for every j < min(k,c) with
+// both factors present, ascending j (the order in which the reference's kk/jj loops touch W(c)); entries left of
+// the diagonal are then divided by the pivot U(c,c) (reference: a = -W(j)/JVS(LU_DIAG(j)); W(j) = -a).
+std::vector<VmEntry> lu_entries(const MechTables& m) {
+  const int n = m.nvar;
+  std::vector<VmEntry> out((size_t)m.nnz);
+  std::vector<int> where((size_t)n, -1);    // column -> slot in the current row
+  for (int k = 0; k < n; k++) {
+    for (int p = m.crow[k]; p < m.crow[k + 1]; p++) where[(size_t)m.icol[p]] = p;
+    for (int p = m.crow[k]; p < m.crow[k + 1]; p++) {
+      VmEntry& E = out[(size_t)p];
+      E.tgt = p;
+      E.phase = 0;
+      int c = m.icol[p];
+      E.dv = c < k ? m.diag[(size_t)c] : -1;
+    }
+    for (int pl = m.crow[k]; pl < m.diag[k]; pl++) {
+      int j = m.icol[pl];
+      for (int pu = m.diag[j] + 1; pu < m.crow[j + 1]; pu++) {
+        int t = where[(size_t)m.icol[pu]];
+        if (t < 0) throw std::logic_error("LU pattern is not closed under fill-in");
+        out[(size_t)t].upd.emplace_back(pl, pu);
+      }
+    }
+    for (int p = m.crow[k]; p < m.crow[k + 1]; p++) where[(size_t)m.icol[p]] = -1;
+  }
+  return out;
+}
+
+// KppSolve_x (gas.f:6206-6608): phase 0 forward sweep with unit L, phase 1 backward sweep with division by U(i,i).
+// X lives behind Ghimj in VM memory: M[nnz + i].
+std::vector<VmEntry> solve_entries(const MechTables& m) {
+  const int n = m.nvar, xo = m.nnz;
+  std::vector<VmEntry> out;
+  for (int i = 0; i < n; i++) {
+    if (m.diag[i] == m.crow[i]) continue;
+    VmEntry E;
+    E.tgt = xo + i;
+    E.phase = 0;
+    for (int p = m.crow[i]; p < m.diag[i]; p++) E.upd.emplace_back(p, xo + m.icol[p]);
+    out.push_back(std::move(E));
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    VmEntry E;
+    E.tgt = xo + i;
+    E.phase = 1;
+    E.keep_order = false;        // see schedule.hpp: readiness order instead of the reference's ascending columns
+    E.dv = m.diag[i];
+    for (int p = m.diag[i] + 1; p < m.crow[i + 1]; p++) E.upd.emplace_back(p, xo + m.icol[p]);
+    out.push_back(std::move(E));
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,
+                               const std::vector<int>& slot_of_output, int nq, int nt) {
+  GsumProgram P;
+  P.nt = nt;
+  P.nw = nt / 64;
+  P.nq = nq;
+  std::vector<int> output_of_slot((size_t)nq * nt, -1);
+  for (size_t o = 0; o < outputs.size(); o++) {
+    int s = slot_of_output[o];
+    if (s < 0 || s >= nq * nt || output_of_slot[(size_t)s] >= 0) throw std::logic_error("bad gsum slot map");
+    output_of_slot[(size_t)s] = (int)o;
+  }
+  P.blk_base.assign((size_t)nq * P.nw, 0);
+  P.blk_n.assign((size_t)nq * P.nw, 0);
+  for (int q = 0; q < nq; q++)
+    for (int w = 0; w < P.nw; w++) {
+      size_t n = 0;
+      for (int l = 0; l < 64; l++) {
+        int o = output_of_slot[(size_t)q * nt + w * 64 + l];
+        if (o >= 0) n = std::max(n, outputs[(size_t)o].size());
+      }
+      if (n > 0xFFFF) throw std::logic_error("gsum block too long");
+      P.blk_base[(size_t)q * P.nw + w] = (uint32_t)(P.idx.size() / 64);
+      P.blk_n[(size_t)q * P.nw + w] = (uint16_t)n;
+      for (size_t s = 0; s < n; s++)
+        for (int l = 0; l < 64; l++) {
+          int o = output_of_slot[(size_t)q * nt + w * 64 + l];
+          if (o >= 0 && s < outputs[(size_t)o].size()) {
+            const auto& term = outputs[(size_t)o][s];
+            float cf = (float)term.second;
+            if ((double)cf != term.second) throw std::logic_error("stoichiometric coefficient is not a float32 value");
+            if (term.first < 0 || term.first > 0xFFFF) throw std::logic_error("gsum source index out of range");
+            P.idx.push_back((uint32_t)term.first | (s == 0 ? GS_FIRST : 0u));
+            P.coef.push_back(cf);
+            P.n_terms++;
+          } else {
+            P.idx.push_back(GS_NOP);
+            P.coef.push_back(0.0f);
+          }
+        }
+      P.wave_slots += (int64_t)n;
+    }
+  return P;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+KernelSchedule build_kernel_schedule(const MechTables& m, int nt) {
+  if (nt % 64 != 0 || nt <= 0 || nt > 1024) throw std::invalid_argument("nt must be a multiple of 64 in (0,1024]");
+  if (m.nnz + m.nvar > (int)VM_IDX_MASK + 1) throw std::invalid_argument("mechanism too large for the LDS VM index space");
+  if (m.nx() > 0xFFFF || m.nb >= 0xFFFF || m.nreact > 0xFFFF) throw std::invalid_argument("mechanism too large");
+  KernelSchedule S;
+  S.nt = nt;
+  S.nw = nt / 64;
+  S.spt = ceil_div(m.nvar, nt);
+  S.rpt = ceil_div(m.nreact, nt);
+  const uint64_t one = (uint64_t)(m.nvar + m.nfix);       // X slot of the constant 1.0
+
+  // ---- Fun_x products
+  S.fun_fac.assign((size_t)S.rpt * nt, one | (one << 16) | (one << 32));
+  for (int r = 0; r < m.nreact; r++) {
+    uint64_t f[3] = {one, one, one};
+    int nf = m.a_ptr[r + 1] - m.a_ptr[r];
+    if (nf > 3) throw std::logic_error("reaction with more than 3 factors");
+    for (int i = 0; i < nf; i++) f[i] = (uint64_t)m.a_fac[(size_t)m.a_ptr[r] + i];
+    S.fun_fac[(size_t)r] = f[0] | (f[1] << 16) | (f[2] << 32) | (1ull << 48);
+  }
+  {
+    std::vector<std::vector<std::pair<int, double>>> outs((size_t)m.nvar);
+    std::vector<int> slot((size_t)m.nvar);
+    for (int s = 0; s < m.nvar; s++) {
+      slot[(size_t)s] = s;
+      for (int p = m.vd_ptr[s]; p < m.vd_ptr[s + 1]; p++) outs[(size_t)s].emplace_back(m.vd_idx[(size_t)p], m.vd_coef[(size_t)p]);
+    }
+    S.vdot = build_gsum_program(outs, slot, S.spt, nt);
+  }
+
+  // ---- Jac_SP_x products, under the owning reaction
+  S.jac_fac.assign((size_t)S.rpt * 3 * nt, one | (one << 16) | (one << 32) | (0xFFFFull << 48));
+  {
+    std::vector<int> used((size_t)m.nreact, 0);
+    for (int b = 0; b < m.nb; b++) {
+      int r = m.b_rct[(size_t)b];
+      int k = used[(size_t)r]++;
+      if (k >= 3) throw std::logic_error("more than 3 Jacobian products for one reaction");
+      uint64_t f[3] = {one, one, one};
+      int nf = m.b_ptr[b + 1] - m.b_ptr[b];
+      if (nf > 3) throw std::logic_error("Jacobian product with more than 3 factors");
+      for (int i = 0; i < nf; i++) f[i] = (uint64_t)m.b_fac[(size_t)m.b_ptr[b] + i];
+      int q = r / nt, t = r % nt;
+      S.jac_fac[((size_t)q * 3 + k) * nt + t] = f[0] | (f[1] << 16) | (f[2] << 32) | ((uint64_t)b << 48);
+    }
+  }
+  // ---- JVS construction: structurally non-zero slots become register-resident outputs, balanced over threads
+  {
+    std::vector<int> nz, zero;
+    for (int k = 0; k < m.nnz; k++) (m.jv_ptr[k + 1] > m.jv_ptr[k] ? nz : zero).push_back(k);
+    S.n_jnz = (int)nz.size();
+    S.n_jzero = (int)zero.size();
+    S.jpt = std::max(1, ceil_div(S.n_jnz, nt));
+    S.zpt = std::max(1, ceil_div(S.n_jzero, nt));
+    std::vector<char> is_diag((size_t)m.nnz, 0);
+    for (int s = 0; s < m.nvar; s++) is_diag[(size_t)m.diag[(size_t)s]] = 1;
+    std::stable_sort(nz.begin(), nz.end(), [&](int a, int b) {
+      return m.jv_ptr[a + 1] - m.jv_ptr[a] > m.jv_ptr[b + 1] - m.jv_ptr[b];
+    });
+    std::vector<std::vector<std::pair<int, double>>> outs(nz.size());
+    std::vector<int> slot(nz.size());
+    S.jvs_pos.assign((size_t)S.jpt * nt, POS_NONE);
+    for (size_t i = 0; i < nz.size(); i++) {
+      int k = nz[i];
+      int pass = (int)(i / (size_t)nt), pos = (int)(i % (size_t)nt);
+      int t = (pass & 1) ? nt - 1 - pos : pos;
+      slot[i] = pass * nt + t;
+      for (int p = m.jv_ptr[k]; p < m.jv_ptr[k + 1]; p++) outs[i].emplace_back(m.jv_idx[(size_t)p], m.jv_coef[(size_t)p]);
+      S.jvs_pos[(size_t)slot[i]] = (uint16_t)(k | (is_diag[(size_t)k] ? POS_DIAG : 0));
+    }
+    S.jvs = build_gsum_program(outs, slot, S.jpt, nt);
+    S.zero_pos.assign((size_t)S.zpt * nt, POS_NONE);
+    for (size_t i = 0; i < zero.size(); i++) S.zero_pos[i] = (uint16_t)(zero[i] | (is_diag[(size_t)zero[i]] ? POS_DIAG : 0));
+  }
+  S.diag_pos.assign((size_t)S.spt * nt, POS_NONE);
+  for (int s = 0; s < m.nvar; s++) S.diag_pos[(size_t)s] = (uint16_t)m.diag[(size_t)s];
+
+  S.lu = build_vm_program(lu_entries(m), m.nnz + m.nvar, nt);
+  S.solve = build_vm_program(solve_entries(m), m.nnz + m.nvar, nt);
+  return S;
+}
+
+std::string describe(const KernelSchedule& s) {
+  char buf[1024];
+  std::snprintf(buf, sizeof buf,
+                "nt=%d spt=%d rpt=%d jpt=%d zpt=%d | vdot: %lld terms, %lld wave-slots | jvs: %lld terms, %lld wave-slots | "
+                "LU: %d rounds, %lld updates in %lld items, %lld wave-slots, critical %lld | "
+                "solve: %d rounds, %lld updates in %lld items, %lld wave-slots, critical %lld",
+                s.nt, s.spt, s.rpt, s.jpt, s.zpt, (long long)s.vdot.n_terms, (long long)s.vdot.wave_slots,
+                (long long)s.jvs.n_terms, (long long)s.jvs.wave_slots, s.lu.nrounds, (long long)s.lu.n_updates,
+                (long long)s.lu.n_items, (long long)s.lu.wave_slots, (long long)s.lu.crit_slots, s.solve.nrounds,
+                (long long)s.solve.n_updates, (long long)s.solve.n_items, (long long)s.solve.wave_slots,
+                (long long)s.solve.crit_slots);
+  return buf;
+}
+
+}  // namespace mistra

@@ -1,0 +1,99 @@
+// Host-side schedule compiler: mechanism tables -> static per-thread programs for the one-workgroup-per-cell
+// Rosenbrock kernel (ros3_kernel.hip).  Everything here is integer bookkeeping done once per mechanism at init.
+//
+// Two tiny "machines" run inside the kernel, both over LDS-resident data:
+//
+//  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) ].  A program is a list of rounds separated by
+//    workgroup barriers; inside a round every lane walks its own word list:
+//        word = i1 | i2<<14 | flags          x = M[i1], y = M[i2]
+//        HDR : acc = x, dv = y, tg = i1      (start of a chunk of updates on entry tg)
+//        else: acc = acc - x*y               (one multiply, one subtract, no contraction)
+//        END : M[tg] = DIV ? acc/dv : acc
+//    It expresses the sparse LU (KppDecomp_x, gas.f:6142: entry (k,c) receives  -L(k,j)*U(j,c)  for ascending j,
+//    L entries are divided by the pivot) and both triangular sweeps of KppSolve_x (gas.f:6206) with the reference's
+//    per-entry operation ORDER preserved where that is free: an entry's updates are cut into chunks, a chunk is
+//    issued in the first round in which its operands are final ("eager" schedule), chunks of one entry stay in
+//    ascending-j order.  That cuts the LU's dependency depth from ~9600 serial updates (tot) to ~165 rounds of 1-25
+//    updates.  The backward sweep is the exception: the reference subtracts U(i,c)*X(c) for ASCENDING c while the
+//    X(c) become known in DESCENDING c, which would serialise whole dot products; there the updates are applied in
+//    readiness order (keep_order = false) — same terms, different summation order, differences at round-off level.
+//
+//  * the gather-sum machine ("gsum"): out = c0*src[i0] + c1*src[i1] + ... left to right, coefficient as float
+//    (every stoichiometric coefficient in the reference is a default-REAL literal or a small integer).
+//    It expresses the Vdot aggregation of Fun_x (gas.f:2395) and the JVS construction of Jac_SP_x (gas.f:3812).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mech_tables.hpp"
+
+namespace mistra {
+
+constexpr uint32_t VM_IDX_BITS = 14;
+constexpr uint32_t VM_IDX_MASK = (1u << VM_IDX_BITS) - 1;
+constexpr uint32_t VM_HDR = 1u << 28;
+constexpr uint32_t VM_END = 1u << 29;
+constexpr uint32_t VM_DIV = 1u << 30;
+constexpr uint32_t VM_NOP = 1u << 31;
+
+constexpr uint32_t GS_FIRST = 1u << 16;
+constexpr uint32_t GS_NOP = 1u << 17;
+
+constexpr uint16_t POS_DIAG = 0x8000;   // flag on a Ghimj slot number: the slot is a diagonal
+constexpr uint16_t POS_NONE = 0xFFFF;
+
+struct VmEntry {
+  int tgt = 0;                                  // M index updated
+  int dv = -1;                                  // M index of the divisor applied after the last update, -1 = none
+  int phase = 0;                                // phases run strictly one after the other
+  bool keep_order = true;                       // false: updates may be applied in the order their operands get ready
+  std::vector<std::pair<int, int>> upd;         // (i1, i2) pairs, applied in this order (if keep_order)
+};
+
+struct VmProgram {
+  int nt = 0, nw = 0, nrounds = 0;
+  std::vector<uint32_t> blk_base;               // [nrounds*nw] first 64-word block of (round, wave)
+  std::vector<uint16_t> blk_n;                  // [nrounds*nw] slots of (round, wave)
+  std::vector<uint32_t> words;                  // [(blk_base + slot)*64 + lane]
+  // census
+  int64_t n_updates = 0, n_items = 0, wave_slots = 0, crit_slots = 0;
+};
+
+struct GsumProgram {
+  int nt = 0, nw = 0, nq = 0;
+  std::vector<uint32_t> blk_base;               // [nq*nw]
+  std::vector<uint16_t> blk_n;                  // [nq*nw]
+  std::vector<uint32_t> idx;                    // [(blk_base + slot)*64 + lane]  src index | GS_FIRST | GS_NOP
+  std::vector<float> coef;                      // same indexing
+  int64_t n_terms = 0, wave_slots = 0;
+};
+
+struct KernelSchedule {
+  int nt = 0, nw = 0;
+  int spt = 0;   // species per thread          s = q*nt + t
+  int rpt = 0;   // reactions per thread        r = q*nt + t
+  int jpt = 0;   // structurally non-zero Jacobian entries per thread
+  int zpt = 0;   // structurally zero (fill-in) entries per thread
+  int n_jnz = 0, n_jzero = 0;
+  // Fun_x products: A(r) = RCT(r)*X[f1]*X[f2]*X[f3], padded with the constant 1.0
+  std::vector<uint64_t> fun_fac;                // [rpt*nt]  f1 | f2<<16 | f3<<32 | valid<<48
+  GsumProgram vdot;                             // src = A (LDS), output (q,t) = species q*nt+t
+  // Jac_SP_x products, grouped under the reaction that owns the rate constant: up to 3 B's per reaction
+  std::vector<uint64_t> jac_fac;                // [(q*3 + b)*nt + t]  f1 | f2<<16 | f3<<32 | out<<48 (0xFFFF = none)
+  GsumProgram jvs;                              // src = B (LDS), output (q,t) = jac0 register q of thread t
+  std::vector<uint16_t> jvs_pos;                // [jpt*nt] Ghimj slot (| POS_DIAG) of that output, POS_NONE = idle
+  std::vector<uint16_t> zero_pos;               // [zpt*nt] Ghimj slots that Jac_SP_x sets to 0 (| POS_DIAG)
+  std::vector<uint16_t> diag_pos;               // [spt*nt] Ghimj slot of (s,s), POS_NONE past nvar
+  VmProgram lu, solve;
+};
+
+VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int nt);
+std::vector<VmEntry> lu_entries(const MechTables& m);
+std::vector<VmEntry> solve_entries(const MechTables& m);
+GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,
+                               const std::vector<int>& slot_of_output, int nq, int nt);
+KernelSchedule build_kernel_schedule(const MechTables& m, int nt);
+std::string describe(const KernelSchedule& s);
+
+}  // namespace mistra

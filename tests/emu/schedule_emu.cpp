@@ -1,0 +1,206 @@
+// TEST-ONLY host emulator of the kernel's static programs (LDS VM + gather-sum machine, see
+// mistra_amd/csrc/schedule.hpp).  It lets the CPU test-suite check the schedule compiler against the oracle
+// without a GPU: same words, same per-lane order, lanes executed one after the other, with a hazard check that no
+// lane reads an M slot another lane writes in the same round.  It is NOT part of the product library and is never
+// a fallback: mistra_amd/ does not link it.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../mistra_amd/csrc/mech_tables.hpp"
+#include "../../mistra_amd/csrc/schedule.hpp"
+
+using namespace mistra;
+
+struct Emu {
+  MechTables m;
+  KernelSchedule s;
+  std::string text;
+};
+
+static int run_vm(const VmProgram& P, std::vector<double>& M) {
+  const int nt = P.nt;
+  std::vector<int> writer(M.size());
+  for (int r = 0; r < P.nrounds; r++) {
+    std::fill(writer.begin(), writer.end(), -1);
+    std::vector<std::pair<int, int>> reads;   // (slot, lane)
+    std::vector<double> snapshot = M;         // every lane of a round sees the pre-round memory of OTHER lanes
+    for (int w = 0; w < P.nw; w++) {
+      const uint32_t base = P.blk_base[(size_t)r * P.nw + w];
+      const int n = P.blk_n[(size_t)r * P.nw + w];
+      for (int l = 0; l < 64; l++) {
+        const int lane = w * 64 + l;
+        if (lane >= nt) break;
+        double acc = 0, dv = 1;
+        int tg = -1;
+        for (int sidx = 0; sidx < n; sidx++) {
+          uint32_t word = P.words[((size_t)base + sidx) * 64 + l];
+          if (word & VM_NOP) continue;
+          int i1 = word & VM_IDX_MASK, i2 = (word >> VM_IDX_BITS) & VM_IDX_MASK;
+          // a lane may re-read what it wrote itself earlier in the round (in-order LDS); others must not
+          double x = (writer[i1] == lane) ? M[i1] : snapshot[i1];
+          double y = (writer[i2] == lane) ? M[i2] : snapshot[i2];
+          reads.emplace_back(i1, lane);
+          reads.emplace_back(i2, lane);
+          if (word & VM_HDR) { acc = x; dv = y; tg = i1; }
+          else { double p = x * y; acc = acc - p; }
+          if (word & VM_END) {
+            if (tg < 0) return -1;
+            M[tg] = (word & VM_DIV) ? acc / dv : acc;
+            if (writer[tg] >= 0 && writer[tg] != lane) return -2;   // two lanes write one slot in a round
+            writer[tg] = lane;
+          }
+        }
+      }
+    }
+    for (auto& rd : reads)
+      if (writer[rd.first] >= 0 && writer[rd.first] != rd.second) {
+        return -3;   // read of a slot that another lane writes in the same round
+      }
+  }
+  return 0;
+}
+
+static void run_gsum(const GsumProgram& P, const std::vector<double>& src, std::vector<double>& out) {
+  out.assign((size_t)P.nq * P.nt, 0.0);
+  for (int q = 0; q < P.nq; q++)
+    for (int w = 0; w < P.nw; w++) {
+      const uint32_t base = P.blk_base[(size_t)q * P.nw + w];
+      const int n = P.blk_n[(size_t)q * P.nw + w];
+      for (int l = 0; l < 64; l++) {
+        double acc = 0.0;
+        for (int sidx = 0; sidx < n; sidx++) {
+          uint32_t word = P.idx[((size_t)base + sidx) * 64 + l];
+          float cf = P.coef[((size_t)base + sidx) * 64 + l];
+          if (word & GS_NOP) continue;
+          double t = (double)cf * src[word & 0xFFFF];
+          acc = (word & GS_FIRST) ? t : acc + t;
+        }
+        out[(size_t)q * P.nt + w * 64 + l] = acc;
+      }
+    }
+}
+
+extern "C" {
+
+void* emu_create(const char* mech_path, int nt) {
+  Emu* e = new Emu;
+  std::string err;
+  if (!e->m.load(mech_path, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); delete e; return nullptr; }
+  try {
+    e->s = build_kernel_schedule(e->m, nt);
+  } catch (const std::exception& ex) {
+    std::fprintf(stderr, "schedule: %s\n", ex.what());
+    delete e;
+    return nullptr;
+  }
+  e->text = describe(e->s);
+  return e;
+}
+void emu_destroy(void* h) { delete (Emu*)h; }
+const char* emu_describe(void* h) { return ((Emu*)h)->text.c_str(); }
+
+// KppDecomp on G (nnz doubles, in place) through the LU program.  Returns 0 or a negative hazard code.
+int emu_lu(void* h, double* G) {
+  Emu* e = (Emu*)h;
+  std::vector<double> M((size_t)e->m.nnz + e->m.nvar, 0.0);
+  std::memcpy(M.data(), G, sizeof(double) * e->m.nnz);
+  int rc = run_vm(e->s.lu, M);
+  std::memcpy(G, M.data(), sizeof(double) * e->m.nnz);
+  return rc;
+}
+
+int emu_solve(void* h, const double* LU, double* X) {
+  Emu* e = (Emu*)h;
+  std::vector<double> M((size_t)e->m.nnz + e->m.nvar);
+  std::memcpy(M.data(), LU, sizeof(double) * e->m.nnz);
+  std::memcpy(M.data() + e->m.nnz, X, sizeof(double) * e->m.nvar);
+  int rc = run_vm(e->s.solve, M);
+  std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
+  return rc;
+}
+
+static void make_x(const Emu* e, const double* V, const double* F, std::vector<double>& X) {
+  X.resize((size_t)e->m.nx());
+  std::memcpy(X.data(), V, sizeof(double) * e->m.nvar);
+  std::memcpy(X.data() + e->m.nvar, F, sizeof(double) * e->m.nfix);
+  std::memcpy(X.data() + e->m.nspec(), e->m.consts.data(), sizeof(double) * e->m.nconst);
+}
+
+void emu_fun(void* h, const double* V, const double* F, const double* RCT, double* Vdot) {
+  Emu* e = (Emu*)h;
+  const KernelSchedule& s = e->s;
+  std::vector<double> X, A((size_t)s.rpt * s.nt, 0.0), out;
+  make_x(e, V, F, X);
+  for (int q = 0; q < s.rpt; q++)
+    for (int t = 0; t < s.nt; t++) {
+      uint64_t w = s.fun_fac[(size_t)q * s.nt + t];
+      if (!((w >> 48) & 1)) continue;
+      int r = q * s.nt + t;
+      double a = RCT[r];
+      a = a * X[w & 0xFFFF];
+      a = a * X[(w >> 16) & 0xFFFF];
+      a = a * X[(w >> 32) & 0xFFFF];
+      A[(size_t)r] = a;
+    }
+  run_gsum(s.vdot, A, out);
+  for (int i = 0; i < e->m.nvar; i++) Vdot[i] = out[(size_t)i];
+}
+
+// Jac_SP followed by the kernel's matrix preparation: G = -Jac0 (+ghinv on the diagonal), fill-in slots -0.0.
+// With ghinv = 0 and negate = 0 the plain JVS array comes back (fill-in slots +0.0).
+void emu_jac_prepare(void* h, const double* V, const double* F, const double* RCT, double ghinv, int negate, double* G) {
+  Emu* e = (Emu*)h;
+  const KernelSchedule& s = e->s;
+  std::vector<double> X, B((size_t)e->m.nb + 1, 0.0), jac0;
+  make_x(e, V, F, X);
+  for (int q = 0; q < s.rpt; q++)
+    for (int b = 0; b < 3; b++)
+      for (int t = 0; t < s.nt; t++) {
+        uint64_t w = s.jac_fac[((size_t)q * 3 + b) * s.nt + t];
+        int out = (int)((w >> 48) & 0xFFFF);
+        if (out == 0xFFFF) continue;
+        double v = RCT[q * s.nt + t];
+        v = v * X[w & 0xFFFF];
+        v = v * X[(w >> 16) & 0xFFFF];
+        v = v * X[(w >> 32) & 0xFFFF];
+        B[(size_t)out] = v;
+      }
+  run_gsum(s.jvs, B, jac0);
+  for (int i = 0; i < e->m.nnz; i++) G[i] = std::nan("");
+  for (size_t i = 0; i < s.jvs_pos.size(); i++) {
+    uint16_t p = s.jvs_pos[i];
+    if (p == POS_NONE) continue;
+    double v = negate ? -jac0[i] : jac0[i];
+    if (p & POS_DIAG) v = v + ghinv;
+    G[p & 0x7FFF] = v;
+  }
+  for (size_t i = 0; i < s.zero_pos.size(); i++) {
+    uint16_t p = s.zero_pos[i];
+    if (p == POS_NONE) continue;
+    double v = negate ? -0.0 : 0.0;
+    if (p & POS_DIAG) v = v + ghinv;
+    G[p & 0x7FFF] = v;
+  }
+}
+
+}  // extern "C"
+
+// per-round critical slot counts of a VM program (which: 0 = LU, 1 = solve); returns the number of rounds
+extern "C" int emu_round_profile(void* h, int which, int* crit, int* total, int cap) {
+  Emu* e = (Emu*)h;
+  const VmProgram& P = which ? e->s.solve : e->s.lu;
+  for (int r = 0; r < P.nrounds && r < cap; r++) {
+    int c = 0, t = 0;
+    for (int w = 0; w < P.nw; w++) {
+      int n = P.blk_n[(size_t)r * P.nw + w];
+      c = n > c ? n : c;
+      t += n;
+    }
+    crit[r] = c;
+    total[r] = t;
+  }
+  return P.nrounds;
+}

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/integrate_<mech>.npz from a capture of the running reference model.
+
+Provenance (all steps happen in the build container, where /root/reference exists):
+  1. oracle/build_ref.sh all          compiles the reference's own Fortran sources with flang -O2 -ffp-contract=off
+  2. oracle/capture_run.sh BTZ96 1 ...  runs the reference's shipped stratus case (namelists/namelist.BTZ96 with chem=T,
+                                       netcdf=F, 1 model hour) through oracle/column_driver.f90 and records real
+                                       INTEGRATE_g/a/t calls (oracle/capture_wrap.c): /GDATA_x/ before and after, /Statistics/
+  3. this script                        converts the records into the small fixtures committed here
+
+The fixtures are DATA: inputs (VAR, FIX, RCONST, TIN, TOUT) and the reference's outputs (VAR, statistics, exit time,
+last step).  The exact capture command is stored in each file's `provenance` field.
+"""
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle.oracle import read_capture  # noqa: E402
+
+CAPTURE = os.path.join(HERE, "..", "..", "oracle", "_ref", "capture_BTZ96.bin")
+CMD = ("oracle/capture_run.sh BTZ96 1 MISTRA_CAPTURE_SKIP_t=1500 MISTRA_CAPTURE_EVERY_t=241 MISTRA_CAPTURE_MAX_t=64 "
+       "MISTRA_CAPTURE_SKIP_a=1000 MISTRA_CAPTURE_EVERY_a=331 MISTRA_CAPTURE_MAX_a=32 "
+       "MISTRA_CAPTURE_SKIP_g=2000 MISTRA_CAPTURE_EVERY_g=701 MISTRA_CAPTURE_MAX_g=32")
+
+
+def main():
+    recs = read_capture(CAPTURE)
+    info = open(os.path.join(HERE, "..", "..", "oracle", "_ref", "BUILD_INFO")).read()
+    for mech in ("gas", "aer", "tot"):
+        rs = [r for r in recs if r["mech"] == mech]
+        out = dict(
+            var_in=np.stack([r["var_in"] for r in rs]), fix=np.stack([r["fix"] for r in rs]),
+            rconst=np.stack([r["rconst"] for r in rs]), var_out=np.stack([r["var_out"] for r in rs]),
+            stats=np.stack([r["stats"] for r in rs]).astype(np.int32),
+            tin=np.array([r["tin"] for r in rs]), tout=np.array([r["tout"] for r in rs]),
+            tin_out=np.array([r["tin_out"] for r in rs]), stepmin_out=np.array([r["stepmin_out"] for r in rs]),
+            callno=np.array([r["callno"] for r in rs], np.int32),
+            provenance=np.array("reference namelist.BTZ96 (chem=T, netcdf=F, lstmax=1); " + CMD + "; " + info.replace("\n", "; ")))
+        path = os.path.join(HERE, "integrate_%s.npz" % mech)
+        np.savez_compressed(path, **out)
+        print(mech, len(rs), "records ->", path, os.path.getsize(path), "bytes; steps", out["stats"][:, 2].min(), "..", out["stats"][:, 2].max())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""The C-ABI library: loads on a machine without a GPU, exports every symbol include/mistra_chem.h declares, and
+refuses to compute without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mistra_amd.build import build_lib
+    build_lib()
+    from mistra_amd import chem
+    return chem.lib()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "mistra_chem.h")).read()
+    names = set(re.findall(r"\b(mistra_chem_\w+)\s*\(", hdr))
+    assert {"mistra_chem_init", "mistra_chem_integrate", "mistra_chem_integrate_device", "mistra_chem_integrate_common",
+            "mistra_chem_finalize", "mistra_chem_dims", "mistra_chem_last_error", "mistra_chem_describe"} <= names
+    for n in names:
+        assert hasattr(lib, n), "symbol %s declared in the header is not exported" % n
+
+
+def test_dims(lib):
+    from mistra_amd.chem import DIMS
+    for mech, name in enumerate(("gas", "aer", "tot")):
+        v = [C.c_int32() for _ in range(4)]
+        assert lib.mistra_chem_dims(mech, *[C.byref(x) for x in v]) == 0
+        assert tuple(x.value for x in v) == DIMS[name]
+    assert lib.mistra_chem_dims(7, None, None, None, None) != 0
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from mistra_amd import chem
+    assert lib.mistra_chem_init(0) != 0
+    assert b"no HIP device" in lib.mistra_chem_last_error()
+    with pytest.raises(chem.MistraChemError):
+        chem.integrate("gas", np.zeros((1, 102)), np.zeros((1, 3)), np.zeros((1, 331)))
+    # compute entry point without init: error, not a silent result
+    out = np.zeros(102)
+    dp = C.POINTER(C.c_double)
+    rc = lib.mistra_chem_integrate(0, 1, out.ctypes.data_as(dp), out.ctypes.data_as(dp), out.ctypes.data_as(dp), 0.0, 10.0,
+                                   out.ctypes.data_as(dp), None, None)
+    assert rc != 0
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under mistra_amd/ may reference it."""
+    for root, _, files in os.walk(os.path.join(REPO, "mistra_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "oracle." not in text and "oracle/" not in text and "kpp_ros3" not in text and "libmistra_ref" not in text, f

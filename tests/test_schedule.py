@@ -1,0 +1,83 @@
+"""Host logic: the schedule compiler (mistra_amd/csrc/schedule.cpp) run through the TEST-ONLY emulator
+(tests/emu/schedule_emu.cpp) against the oracle.  Fun, Jac, matrix preparation and the LU keep the reference's
+operation order, so they must be bit-exact; the solve applies the backward-sweep updates in readiness order and is
+checked to round-off."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+EMU_DIR = os.path.join(REPO, "tests", "emu")
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+GAMMA1 = 0.43586652150845899941601945119356
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.run(["make", "-s", "-C", EMU_DIR], check=True)
+    lib = C.CDLL(os.path.join(EMU_DIR, "libschedule_emu.so"))
+    lib.emu_create.restype = C.c_void_p
+    lib.emu_create.argtypes = [C.c_char_p, C.c_int]
+    lib.emu_describe.restype = C.c_char_p
+    lib.emu_describe.argtypes = [C.c_void_p]
+    lib.emu_lu.argtypes = [C.c_void_p, dp]
+    lib.emu_solve.argtypes = [C.c_void_p, dp, dp]
+    lib.emu_fun.argtypes = [C.c_void_p, dp, dp, dp, dp]
+    lib.emu_jac_prepare.argtypes = [C.c_void_p, dp, dp, dp, C.c_double, C.c_int, dp]
+    lib.emu_round_profile.argtypes = [C.c_void_p, C.c_int, ip, ip, C.c_int]
+    return lib
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+# the workgroup sizes the library instantiates (capi.cpp) plus one more per mechanism
+@pytest.mark.parametrize("mech,nt", [("gas", 128), ("gas", 64), ("aer", 512), ("aer", 320), ("tot", 512), ("tot", 1024)])
+def test_programs_match_oracle(emu, mech, nt, golden, oracles):
+    from mistra_amd.mechtab import load
+    o, g, t = oracles[mech], golden[mech], load(mech)
+    h = emu.emu_create(os.path.join(REPO, "mistra_amd", "mech", mech + ".mech").encode(), nt)
+    assert h, "schedule compiler failed"
+    assert b"LU:" in emu.emu_describe(h)
+    rng = np.random.default_rng(11)
+    for i in (0, g["var_in"].shape[0] - 1):
+        V, F, K = (np.ascontiguousarray(g[k][i]) for k in ("var_in", "fix", "rconst"))
+        f = np.empty(o.nvar)
+        emu.emu_fun(h, P(V), P(F), P(K), P(f))
+        assert np.array_equal(f, o.fun(V, F, K))
+        J = np.empty(o.nnz)
+        emu.emu_jac_prepare(h, P(V), P(F), P(K), 0.0, 0, P(J))
+        j_ref = o.jac_sp(V, F, K)
+        assert np.array_equal(J, j_ref)
+        ghinv = 1.0 / (1e-3 * GAMMA1)
+        G = np.empty(o.nnz)
+        emu.emu_jac_prepare(h, P(V), P(F), P(K), ghinv, 1, P(G))
+        G_ref = -j_ref
+        G_ref[t.diag] += ghinv
+        assert np.array_equal(G, G_ref) and np.array_equal(np.signbit(G), np.signbit(G_ref))
+        lu_ref, ier = o.decomp(G_ref)
+        assert ier == 0
+        assert emu.emu_lu(h, P(G)) == 0, "hazard inside an LU round"
+        assert np.array_equal(G, lu_ref)
+        b = rng.normal(size=o.nvar) * np.abs(o.fun(V, F, K)).max()
+        x = b.copy()
+        assert emu.emu_solve(h, P(lu_ref), P(x)) == 0, "hazard inside a solve round"
+        x_ref = o.solve(lu_ref, b)
+        assert np.abs(x - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
+
+
+def test_round_structure_tot(emu):
+    """The eager schedule keeps the critical path short: ~165 LU rounds / ~170 solve rounds for tot."""
+    h = emu.emu_create(os.path.join(REPO, "mistra_amd", "mech", "tot.mech").encode(), 512)
+    crit = np.zeros(512, np.int32)
+    tot = np.zeros(512, np.int32)
+    n_lu = emu.emu_round_profile(h, 0, crit.ctypes.data_as(ip), tot.ctypes.data_as(ip), 512)
+    assert 100 < n_lu < 200 and crit[:n_lu].sum() < 1500
+    n_sv = emu.emu_round_profile(h, 1, crit.ctypes.data_as(ip), tot.ctypes.data_as(ip), 512)
+    assert 100 < n_sv < 200 and crit[:n_sv].sum() < 800
