@@ -62,18 +62,18 @@ struct DevBuf {
 };
 
 struct VmBufs {
-  DevBuf<uint32_t> blk_base, words;
+  DevBuf<uint32_t> wave_base, recs;
   DevBuf<uint16_t> blk_n;
   int nrounds = 0;
   hipError_t upload(const VmProgram& P) {
     nrounds = P.nrounds;
     hipError_t e;
-    if ((e = blk_base.upload(P.blk_base)) != hipSuccess) return e;
+    if ((e = wave_base.upload(P.wave_base)) != hipSuccess) return e;
     if ((e = blk_n.upload(P.blk_n)) != hipSuccess) return e;
-    return words.upload(P.words);
+    return recs.upload(P.recs);
   }
-  VmDev dev() const { return VmDev{blk_base.p, blk_n.p, words.p, nrounds}; }
-  void release() { blk_base.release(); words.release(); blk_n.release(); }
+  VmDev dev() const { return VmDev{wave_base.p, blk_n.p, recs.p, nrounds}; }
+  void release() { wave_base.release(); recs.release(); blk_n.release(); }
 };
 
 struct GsBufs {

@@ -5,9 +5,9 @@
 namespace mistra {
 
 struct VmDev {                 // LDS VM program in device memory (see schedule.hpp)
-  const uint32_t* blk_base;
-  const uint16_t* blk_n;
-  const uint32_t* words;
+  const uint32_t* wave_base;   // [NW]         first record row of each wave's stream
+  const uint16_t* blk_n;       // [nrounds*NW] record rows per (round, wave)
+  const uint32_t* recs;        // uint4 per lane and row, 16-byte aligned
   int nrounds;
 };
 

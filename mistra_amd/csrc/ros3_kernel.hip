@@ -23,9 +23,18 @@ namespace mistra {
 namespace {
 
 constexpr uint32_t kVmIdxBits = 14, kVmIdxMask = (1u << 14) - 1;
-constexpr uint32_t kVmHdr = 1u << 28, kVmEnd = 1u << 29, kVmDiv = 1u << 30, kVmNop = 1u << 31;
+constexpr uint32_t kVmFirst = 1u << 28, kVmLast = 1u << 29, kVmDiv = 1u << 30, kVmActive = 1u << 31;
 constexpr uint32_t kGsFirst = 1u << 16, kGsNop = 1u << 17;
 constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
+constexpr int kPrefetch = 3;   // records / groups a lane's table loads run ahead (schedule.cpp appends that much slack)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. wait for the
+// schedule-table prefetches that are deliberately kept in flight across rounds.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // Ros3_x (gas.f:1596-1626)
 constexpr double kRosA1 = 1.0;
@@ -46,34 +55,45 @@ constexpr double kRosElo = 3.0;
 __device__ __forceinline__ double fmin_f(double a, double b) { return (a < b || b != b) ? a : b; }   // Fortran MIN
 __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || b != b) ? a : b; }   // Fortran MAX
 
-// ---- the LDS VM (schedule.hpp): one program = rounds separated by workgroup barriers
+// ---- the LDS VM (schedule.hpp): rounds separated by LDS barriers; each lane walks 16-byte records of its wave's
+//      linear stream, table loads running kPrefetch records ahead of use
 template <int NT>
 __device__ __forceinline__ void vm_run(const VmDev& P, double* __restrict__ M, int wave, int lane) {
   constexpr int NW = NT / 64;
+  const uint4* __restrict__ rp = reinterpret_cast<const uint4*>(P.recs) + (size_t)P.wave_base[wave] * 64 + lane;
+  uint4 q0 = rp[0], q1 = rp[64], q2 = rp[128];
+  double acc = 0.0;
   for (int r = 0; r < P.nrounds; r++) {
     const int n = P.blk_n[r * NW + wave];
-    const uint32_t* __restrict__ wp = P.words + (size_t)P.blk_base[r * NW + wave] * 64 + lane;
-    double acc = 0.0, dv = 1.0;
-    uint32_t tg = 0;
     for (int i = 0; i < n; i++) {
-      const uint32_t wd = wp[(size_t)i * 64];
-      const uint32_t i1 = wd & kVmIdxMask, i2 = (wd >> kVmIdxBits) & kVmIdxMask;
-      const double x = M[i1], y = M[i2];
-      if (wd & kVmHdr) {
-        acc = x;
-        dv = y;
-        tg = i1;
-      } else if (!(wd & kVmNop)) {
-        const double p = x * y;
-        acc = acc - p;
+      const uint4 cur = q0;
+      q0 = q1;
+      q1 = q2;
+      q2 = rp[kPrefetch * 64];
+      rp += 64;
+      const uint32_t tgt = cur.x & kVmIdxMask;
+      const double x0 = M[tgt], d = M[(cur.x >> kVmIdxBits) & kVmIdxMask];
+      const double a1 = M[cur.y & kVmIdxMask], b1 = M[(cur.y >> kVmIdxBits) & kVmIdxMask];
+      const double a2 = M[cur.z & kVmIdxMask], b2 = M[(cur.z >> kVmIdxBits) & kVmIdxMask];
+      const double a3 = M[cur.w & kVmIdxMask], b3 = M[(cur.w >> kVmIdxBits) & kVmIdxMask];
+      acc = (cur.x & kVmFirst) ? x0 : acc;
+      acc = acc - a1 * b1;
+      acc = acc - a2 * b2;
+      acc = acc - a3 * b3;
+      const bool fin = (cur.x & (kVmLast | kVmActive)) == (kVmLast | kVmActive);
+      const bool dodiv = fin && (cur.x & kVmDiv);
+      double res = acc;
+      if (__any(dodiv)) {
+        const double qv = acc / d;
+        res = dodiv ? qv : acc;
       }
-      if (wd & kVmEnd) M[tg] = (wd & kVmDiv) ? acc / dv : acc;
+      if (fin) M[tgt] = res;
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
-// ---- the gather-sum machine: out[q] = c0*src[i0] + c1*src[i1] + ...  (left to right)
+// ---- the gather-sum machine: out[q] = c0*src[i0] + c1*src[i1] + ...  (left to right), four terms per table row
 template <int NT, int NQ>
 __device__ __forceinline__ void gsum_run(const GsDev& P, const double* __restrict__ src, double (&out)[NQ], int wave, int lane) {
   constexpr int NW = NT / 64;
@@ -81,12 +101,24 @@ __device__ __forceinline__ void gsum_run(const GsDev& P, const double* __restric
   for (int q = 0; q < NQ; q++) {
     const int n = P.blk_n[q * NW + wave];
     const size_t off = (size_t)P.blk_base[q * NW + wave] * 64 + lane;
+    const uint4* __restrict__ ip = reinterpret_cast<const uint4*>(P.idx) + off;
+    const float4* __restrict__ cp = reinterpret_cast<const float4*>(P.coef) + off;
+    uint4 i0 = ip[0], i1 = ip[64], i2 = ip[128];
+    float4 c0 = cp[0], c1 = cp[64], c2 = cp[128];
     double acc = 0.0;
-    for (int i = 0; i < n; i++) {
-      const uint32_t wd = P.idx[off + (size_t)i * 64];
-      const float cf = P.coef[off + (size_t)i * 64];
-      const double term = (double)cf * src[wd & 0xFFFFu];
-      if (!(wd & kGsNop)) acc = (wd & kGsFirst) ? term : acc + term;
+    for (int g = 0; g < n; g++) {
+      const uint4 ci = i0;
+      const float4 cc = c0;
+      i0 = i1; i1 = i2; i2 = ip[kPrefetch * 64];
+      c0 = c1; c1 = c2; c2 = cp[kPrefetch * 64];
+      ip += 64;
+      cp += 64;
+      const double x0 = src[ci.x & 0xFFFFu], x1 = src[ci.y & 0xFFFFu], x2 = src[ci.z & 0xFFFFu], x3 = src[ci.w & 0xFFFFu];
+      const double t0 = (double)cc.x * x0, t1 = (double)cc.y * x1, t2 = (double)cc.z * x2, t3 = (double)cc.w * x3;
+      acc = (ci.x & kGsNop) ? acc : ((ci.x & kGsFirst) ? t0 : acc + t0);
+      acc = (ci.y & kGsNop) ? acc : acc + t1;
+      acc = (ci.z & kGsNop) ? acc : acc + t2;
+      acc = (ci.w & kGsNop) ? acc : acc + t3;
     }
     out[q] = acc;
   }
@@ -128,6 +160,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
   }
   if (t < NFIX) X[NVAR + t] = a.fix[(size_t)cell * NFIX + t];
   if (t < NCONST) X[NVAR + NFIX + t] = a.consts[t];
+  if (t == 0) M[NNZ + NVAR] = 0.0;   // the VM's 0.0 cell (operand of padding update slots)
 
   // ---- Fun_x (gas.f:2043): X <- v; A(r) = RCT(r)*X*X*X; Vdot = signed sums of A
   auto fun = [&](const double (&v)[SPT], double (&out)[SPT]) {
@@ -136,7 +169,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       const int s = q * NT + t;
       if (s < NVAR) X[s] = v[q];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < RPT; q++) {
       const uint64_t w = a.fun_fac[q * NT + t];
@@ -145,14 +178,14 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       p = p * X[(w >> 32) & 0xFFFFu];
       if ((w >> 48) & 1u) AB[q * NT + t] = p;
     }
-    __syncthreads();
+    lds_barrier();
     gsum_run<NT, SPT>(a.vdot, AB, out, wave, lane);
   };
 
   // ---- Jac_SP_x (gas.f:2656) on the V already in X: B products under their reaction, JVS sums into registers
   double jac0[JPT];
   auto jac = [&]() {
-    __syncthreads();   // every lane is done reading AB as A
+    lds_barrier();   // every lane is done reading AB as A
 #pragma unroll
     for (int q = 0; q < RPT; q++) {
 #pragma unroll
@@ -165,7 +198,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
         if (o != 0xFFFFu) AB[o] = p;
       }
     }
-    __syncthreads();
+    lds_barrier();
     gsum_run<NT, JPT>(a.jvs, AB, jac0, wave, lane);
   };
 
@@ -173,7 +206,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
   //      Returns (workgroup-uniform) whether a diagonal is exactly zero, the condition KppDecomp_x tests (gas.f:6157).
   auto prepare = [&](double ghinv) -> bool {
     if (t == 0) flags[0] = 0;
-    __syncthreads();   // also: all readers of M from the previous attempt are done
+    lds_barrier();   // also: all readers of M from the previous attempt are done
     bool zero_diag = false;
 #pragma unroll
     for (int q = 0; q < JPT; q++) {
@@ -200,7 +233,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       }
     }
     if (zero_diag) flags[0] = 1;
-    __syncthreads();
+    lds_barrier();
     return flags[0] != 0;
   };
 
@@ -211,7 +244,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       const int s = q * NT + t;
       if (s < NVAR) XS[s] = k[q];
     }
-    __syncthreads();
+    lds_barrier();
     vm_run<NT>(a.solve, M, wave, lane);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
@@ -235,9 +268,9 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    __syncthreads();   // red[] may still be read from the previous step
+    lds_barrier();   // red[] may still be read from the previous step
     if (lane == 0) red[wave] = part;
-    __syncthreads();
+    lds_barrier();
     double sum = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; w++) sum += red[w];
@@ -281,7 +314,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
           singular = prepare(ghinv);
           ndec += 1;
           if (singular) {
-            __syncthreads();   // everyone has read flags[0] before the retry clears it
+            lds_barrier();   // everyone has read flags[0] before the retry clears it
             nsng += 1;
             nconsecutive += 1;
             if (nconsecutive <= 5) H = H * 0.5;

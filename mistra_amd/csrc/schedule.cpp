@@ -41,12 +41,14 @@ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
-VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int nt) {
+VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int zero_slot, int nt, int merge_budget) {
   if (nt % 64 != 0 || nt <= 0) throw std::invalid_argument("nt must be a positive multiple of 64");
-  if ((uint32_t)msize > VM_IDX_MASK + 1) throw std::invalid_argument("VM memory exceeds the 14-bit index space");
+  if ((uint32_t)msize > VM_IDX_MASK + 1 || zero_slot < 0 || zero_slot >= msize)
+    throw std::invalid_argument("VM memory exceeds the 14-bit index space");
   VmProgram P;
   P.nt = nt;
   P.nw = nt / 64;
+  P.zero_slot = zero_slot;
 
   std::vector<int> fin((size_t)msize, 0);   // round at whose end M[x] holds its final value (0 = input)
   std::map<int, std::vector<Item>> rounds;
@@ -83,12 +85,35 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int nt) {
     const int last = n ? ru[n - 1] : base;
     int rdiv = -1;
     if (E.dv >= 0) rdiv = std::max({last, fin[E.dv] + 1, base + 1});
+    // eager chunks: maximal runs of equal readiness round
+    struct Chunk { int round, first, count; };
+    std::vector<Chunk> chunks;
     for (int i = 0; i < n;) {
       int j = i;
       while (j < n && ru[j] == ru[i]) j++;
-      bool div = (j == n) && E.dv >= 0 && rdiv == ru[i];
-      rounds[ru[i]].push_back({(int)e, i, j - i, div});
+      chunks.push_back({ru[i], i, j - i});
       i = j;
+    }
+    // merge forward: a chunk may run later, together with the entry's next chunk (same order, fewer headers).
+    // The entry's last chunk decides when the entry is final, so it only grows up to one record.
+    std::vector<Chunk> merged;
+    for (int k = (int)chunks.size() - 1; k >= 0; k--) {
+      if (!merged.empty()) {
+        Chunk& cur = merged.back();
+        bool cur_is_final = merged.size() == 1;
+        int limit = cur_is_final ? VM_UPD_PER_REC : merge_budget;
+        if (cur.count + chunks[(size_t)k].count <= limit) {
+          cur.first = chunks[(size_t)k].first;
+          cur.count += chunks[(size_t)k].count;
+          continue;
+        }
+      }
+      merged.push_back(chunks[(size_t)k]);
+    }
+    for (int k = (int)merged.size() - 1; k >= 0; k--) {
+      const Chunk& c = merged[(size_t)k];
+      bool div = (k == 0) && E.dv >= 0 && rdiv == c.round;
+      rounds[c.round].push_back({(int)e, c.first, c.count, div});
     }
     if (E.dv >= 0 && (n == 0 || rdiv != last)) rounds[rdiv].push_back({(int)e, n, 0, true});
     int f = E.dv >= 0 ? rdiv : last;
@@ -97,45 +122,75 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int nt) {
   }
 
   P.nrounds = (int)rounds.size();
-  P.blk_base.assign((size_t)P.nrounds * P.nw, 0);
   P.blk_n.assign((size_t)P.nrounds * P.nw, 0);
+  // per-wave linear record streams: stream[w] = rows of 64 uint4
+  std::vector<std::vector<uint32_t>> stream((size_t)P.nw);
+  const uint32_t z = (uint32_t)zero_slot;
+  const uint32_t pad_upd = z | (z << VM_IDX_BITS);
   int ridx = 0;
   for (auto& kv : rounds) {
     std::vector<Item>& items = kv.second;
-    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cost() > b.cost(); });
+    auto nrec = [](const Item& it) { return std::max(1, (it.count + VM_UPD_PER_REC - 1) / VM_UPD_PER_REC); };
+    std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return nrec(a) > nrec(b); });
     std::vector<int> lane = deal((int)items.size(), nt);
-    std::vector<std::vector<uint32_t>> prog((size_t)nt);
+    std::vector<std::vector<uint32_t>> prog((size_t)nt);     // 4 words per record
     for (size_t k = 0; k < items.size(); k++) {
       const Item& it = items[k];
       const VmEntry& E = entries[(size_t)it.entry];
       std::vector<uint32_t>& w = prog[(size_t)lane[k]];
-      uint32_t fin_flags = VM_END | (it.div ? VM_DIV : 0u);
-      // the header's second operand is the divisor only in the chunk that divides; otherwise a harmless re-read of tgt
-      w.push_back(vm_word(E.tgt, it.div ? E.dv : E.tgt, VM_HDR | (it.count == 0 ? fin_flags : 0u)));
-      for (int i = 0; i < it.count; i++) {
-        const auto& u = E.upd[(size_t)(it.first + i)];
-        w.push_back(vm_word(u.first, u.second, i == it.count - 1 ? fin_flags : 0u));
+      const int nr = nrec(it);
+      for (int r = 0; r < nr; r++) {
+        uint32_t flags = VM_ACTIVE;
+        if (r == 0) flags |= VM_FIRST;
+        if (r == nr - 1) flags |= VM_LAST | (it.div ? VM_DIV : 0u);
+        // the divisor operand is only meaningful in the record that divides; otherwise a harmless re-read of tgt
+        w.push_back(vm_word(E.tgt, (r == nr - 1 && it.div) ? E.dv : E.tgt, flags));
+        for (int u = 0; u < VM_UPD_PER_REC; u++) {
+          int i = r * VM_UPD_PER_REC + u;
+          if (i < it.count) {
+            const auto& up = E.upd[(size_t)(it.first + i)];
+            w.push_back(vm_word(up.first, up.second, 0));
+          } else {
+            w.push_back(pad_upd);
+          }
+        }
       }
       P.n_updates += it.count;
       P.n_items++;
+      P.n_records += nr;
     }
     int crit = 0;
     for (int wv = 0; wv < P.nw; wv++) {
       size_t n = 0;
-      for (int l = 0; l < 64; l++) n = std::max(n, prog[(size_t)wv * 64 + l].size());
+      for (int l = 0; l < 64; l++) n = std::max(n, prog[(size_t)wv * 64 + l].size() / 4);
       if (n > 0xFFFF) throw std::logic_error("VM block too long");
-      P.blk_base[(size_t)ridx * P.nw + wv] = (uint32_t)(P.words.size() / 64);
       P.blk_n[(size_t)ridx * P.nw + wv] = (uint16_t)n;
-      for (size_t s = 0; s < n; s++)
+      for (size_t r = 0; r < n; r++)
         for (int l = 0; l < 64; l++) {
           const auto& w = prog[(size_t)wv * 64 + l];
-          P.words.push_back(s < w.size() ? w[s] : VM_NOP);
+          if (r * 4 < w.size()) {
+            for (int q = 0; q < 4; q++) stream[(size_t)wv].push_back(w[r * 4 + q]);
+          } else {   // idle record: loads the 0.0 cell, stores nothing
+            stream[(size_t)wv].push_back(vm_word(zero_slot, zero_slot, VM_FIRST));
+            for (int q = 0; q < 3; q++) stream[(size_t)wv].push_back(pad_upd);
+          }
         }
-      P.wave_slots += (int64_t)n;
+      P.wave_rows += (int64_t)n;
       crit = std::max(crit, (int)n);
     }
-    P.crit_slots += crit;
+    P.crit_rows += crit;
     ridx++;
+  }
+  P.wave_base.assign((size_t)P.nw, 0);
+  for (int wv = 0; wv < P.nw; wv++) {
+    P.wave_base[(size_t)wv] = (uint32_t)(P.recs.size() / 256);
+    P.recs.insert(P.recs.end(), stream[(size_t)wv].begin(), stream[(size_t)wv].end());
+    // idle rows of slack so that the executor's look-ahead loads past the last record stay in bounds
+    for (int rr = 0; rr < VM_LOOKAHEAD_ROWS; rr++)
+      for (int l = 0; l < 64; l++) {
+        P.recs.push_back(vm_word(zero_slot, zero_slot, VM_FIRST));
+        for (int q = 0; q < 3; q++) P.recs.push_back(pad_upd);
+      }
   }
   return P;
 }
@@ -217,34 +272,40 @@ GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, doub
         int o = output_of_slot[(size_t)q * nt + w * 64 + l];
         if (o >= 0) n = std::max(n, outputs[(size_t)o].size());
       }
-      if (n > 0xFFFF) throw std::logic_error("gsum block too long");
-      P.blk_base[(size_t)q * P.nw + w] = (uint32_t)(P.idx.size() / 64);
-      P.blk_n[(size_t)q * P.nw + w] = (uint16_t)n;
-      for (size_t s = 0; s < n; s++)
+      const size_t rows = (n + 3) / 4;          // groups of four terms
+      if (rows > 0xFFFF) throw std::logic_error("gsum block too long");
+      P.blk_base[(size_t)q * P.nw + w] = (uint32_t)(P.idx.size() / 256);
+      P.blk_n[(size_t)q * P.nw + w] = (uint16_t)rows;
+      for (size_t r = 0; r < rows; r++)
         for (int l = 0; l < 64; l++) {
           int o = output_of_slot[(size_t)q * nt + w * 64 + l];
-          if (o >= 0 && s < outputs[(size_t)o].size()) {
-            const auto& term = outputs[(size_t)o][s];
-            float cf = (float)term.second;
-            if ((double)cf != term.second) throw std::logic_error("stoichiometric coefficient is not a float32 value");
-            if (term.first < 0 || term.first > 0xFFFF) throw std::logic_error("gsum source index out of range");
-            P.idx.push_back((uint32_t)term.first | (s == 0 ? GS_FIRST : 0u));
-            P.coef.push_back(cf);
-            P.n_terms++;
-          } else {
-            P.idx.push_back(GS_NOP);
-            P.coef.push_back(0.0f);
+          for (size_t k = 0; k < 4; k++) {
+            size_t s = r * 4 + k;
+            if (o >= 0 && s < outputs[(size_t)o].size()) {
+              const auto& term = outputs[(size_t)o][s];
+              float cf = (float)term.second;
+              if ((double)cf != term.second) throw std::logic_error("stoichiometric coefficient is not a float32 value");
+              if (term.first < 0 || term.first > 0xFFFF) throw std::logic_error("gsum source index out of range");
+              P.idx.push_back((uint32_t)term.first | (s == 0 ? GS_FIRST : 0u));
+              P.coef.push_back(cf);
+              P.n_terms++;
+            } else {
+              P.idx.push_back(GS_NOP);
+              P.coef.push_back(0.0f);
+            }
           }
         }
-      P.wave_slots += (int64_t)n;
+      P.wave_rows += (int64_t)rows;
     }
+  // slack rows for the executor's look-ahead loads
+  for (int i = 0; i < 256 * VM_LOOKAHEAD_ROWS; i++) { P.idx.push_back(GS_NOP); P.coef.push_back(0.0f); }
   return P;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 KernelSchedule build_kernel_schedule(const MechTables& m, int nt) {
   if (nt % 64 != 0 || nt <= 0 || nt > 1024) throw std::invalid_argument("nt must be a multiple of 64 in (0,1024]");
-  if (m.nnz + m.nvar > (int)VM_IDX_MASK + 1) throw std::invalid_argument("mechanism too large for the LDS VM index space");
+  if (m.nnz + m.nvar + 1 > (int)VM_IDX_MASK + 1) throw std::invalid_argument("mechanism too large for the LDS VM index space");
   if (m.nx() > 0xFFFF || m.nb >= 0xFFFF || m.nreact > 0xFFFF) throw std::invalid_argument("mechanism too large");
   KernelSchedule S;
   S.nt = nt;
@@ -319,22 +380,23 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt) {
   S.diag_pos.assign((size_t)S.spt * nt, POS_NONE);
   for (int s = 0; s < m.nvar; s++) S.diag_pos[(size_t)s] = (uint16_t)m.diag[(size_t)s];
 
-  S.lu = build_vm_program(lu_entries(m), m.nnz + m.nvar, nt);
-  S.solve = build_vm_program(solve_entries(m), m.nnz + m.nvar, nt);
+  const int msize = m.nnz + m.nvar + 1, zero_slot = m.nnz + m.nvar;     // M = [Ghimj | XS | 0.0]
+  S.lu = build_vm_program(lu_entries(m), msize, zero_slot, nt);
+  S.solve = build_vm_program(solve_entries(m), msize, zero_slot, nt);
   return S;
 }
 
 std::string describe(const KernelSchedule& s) {
   char buf[1024];
   std::snprintf(buf, sizeof buf,
-                "nt=%d spt=%d rpt=%d jpt=%d zpt=%d | vdot: %lld terms, %lld wave-slots | jvs: %lld terms, %lld wave-slots | "
-                "LU: %d rounds, %lld updates in %lld items, %lld wave-slots, critical %lld | "
-                "solve: %d rounds, %lld updates in %lld items, %lld wave-slots, critical %lld",
-                s.nt, s.spt, s.rpt, s.jpt, s.zpt, (long long)s.vdot.n_terms, (long long)s.vdot.wave_slots,
-                (long long)s.jvs.n_terms, (long long)s.jvs.wave_slots, s.lu.nrounds, (long long)s.lu.n_updates,
-                (long long)s.lu.n_items, (long long)s.lu.wave_slots, (long long)s.lu.crit_slots, s.solve.nrounds,
-                (long long)s.solve.n_updates, (long long)s.solve.n_items, (long long)s.solve.wave_slots,
-                (long long)s.solve.crit_slots);
+                "nt=%d spt=%d rpt=%d jpt=%d zpt=%d | vdot: %lld terms, %lld wave-rows | jvs: %lld terms, %lld wave-rows | "
+                "LU: %d rounds, %lld updates in %lld items / %lld records, %lld wave-rows, critical %lld | "
+                "solve: %d rounds, %lld updates in %lld items / %lld records, %lld wave-rows, critical %lld",
+                s.nt, s.spt, s.rpt, s.jpt, s.zpt, (long long)s.vdot.n_terms, (long long)s.vdot.wave_rows,
+                (long long)s.jvs.n_terms, (long long)s.jvs.wave_rows, s.lu.nrounds, (long long)s.lu.n_updates,
+                (long long)s.lu.n_items, (long long)s.lu.n_records, (long long)s.lu.wave_rows, (long long)s.lu.crit_rows,
+                s.solve.nrounds, (long long)s.solve.n_updates, (long long)s.solve.n_items, (long long)s.solve.n_records,
+                (long long)s.solve.wave_rows, (long long)s.solve.crit_rows);
   return buf;
 }
 

@@ -3,23 +3,28 @@
 //
 // Two tiny "machines" run inside the kernel, both over LDS-resident data:
 //
-//  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) ].  A program is a list of rounds separated by
-//    workgroup barriers; inside a round every lane walks its own word list:
-//        word = i1 | i2<<14 | flags          x = M[i1], y = M[i2]
-//        HDR : acc = x, dv = y, tg = i1      (start of a chunk of updates on entry tg)
-//        else: acc = acc - x*y               (one multiply, one subtract, no contraction)
-//        END : M[tg] = DIV ? acc/dv : acc
+//  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) | 0.0 ].  A program is a list of rounds separated
+//    by workgroup barriers; inside a round every lane walks its own list of fixed 16-byte RECORDS:
+//        w0 = tgt | dv<<14 | FIRST | LAST | DIV | ACTIVE        w1..w3 = i1 | i2<<14   (three update slots)
+//        FIRST : acc = M[tgt]                 (else the lane's acc carries over from its previous record)
+//        each update slot: acc = acc - M[i1]*M[i2]   (one multiply, one subtract, no contraction; an unused slot
+//                                                     points both indices at the 0.0 cell: acc - 0*0 = acc exactly)
+//        LAST  : M[tgt] = DIV ? acc / M[dv] : acc     (only if ACTIVE; idle padding records are not)
+//    A wave's records form one linear stream over all rounds, so the next record is always prefetched while the
+//    current one executes, whatever the round structure.
 //    It expresses the sparse LU (KppDecomp_x, gas.f:6142: entry (k,c) receives  -L(k,j)*U(j,c)  for ascending j,
 //    L entries are divided by the pivot) and both triangular sweeps of KppSolve_x (gas.f:6206) with the reference's
 //    per-entry operation ORDER preserved where that is free: an entry's updates are cut into chunks, a chunk is
-//    issued in the first round in which its operands are final ("eager" schedule), chunks of one entry stay in
-//    ascending-j order.  That cuts the LU's dependency depth from ~9600 serial updates (tot) to ~165 rounds of 1-25
-//    updates.  The backward sweep is the exception: the reference subtracts U(i,c)*X(c) for ASCENDING c while the
-//    X(c) become known in DESCENDING c, which would serialise whole dot products; there the updates are applied in
-//    readiness order (keep_order = false) — same terms, different summation order, differences at round-off level.
+//    issued no earlier than the first round in which its operands are final, chunks of one entry stay in ascending-j
+//    order.  That cuts the LU's dependency depth from ~9600 serial updates (tot) to ~165 rounds.  Chunks that are not
+//    on the critical path are merged forward (issued later, together with the entry's next chunk) to save record
+//    headers.  The backward sweep is the exception to order-keeping: the reference subtracts U(i,c)*X(c) for ASCENDING
+//    c while the X(c) become known in DESCENDING c, which would serialise whole dot products; there the updates are
+//    applied in readiness order (keep_order = false) — same terms, different summation order, round-off level.
 //
 //  * the gather-sum machine ("gsum"): out = c0*src[i0] + c1*src[i1] + ... left to right, coefficient as float
-//    (every stoichiometric coefficient in the reference is a default-REAL literal or a small integer).
+//    (every stoichiometric coefficient in the reference is a default-REAL literal or a small integer),
+//    stored as groups of four terms (one 16-byte index load + one 16-byte coefficient load per lane and group).
 //    It expresses the Vdot aggregation of Fun_x (gas.f:2395) and the JVS construction of Jac_SP_x (gas.f:3812).
 #pragma once
 #include <cstdint>
@@ -32,10 +37,12 @@ namespace mistra {
 
 constexpr uint32_t VM_IDX_BITS = 14;
 constexpr uint32_t VM_IDX_MASK = (1u << VM_IDX_BITS) - 1;
-constexpr uint32_t VM_HDR = 1u << 28;
-constexpr uint32_t VM_END = 1u << 29;
+constexpr uint32_t VM_FIRST = 1u << 28;
+constexpr uint32_t VM_LAST = 1u << 29;
 constexpr uint32_t VM_DIV = 1u << 30;
-constexpr uint32_t VM_NOP = 1u << 31;
+constexpr uint32_t VM_ACTIVE = 1u << 31;
+constexpr int VM_UPD_PER_REC = 3;
+constexpr int VM_LOOKAHEAD_ROWS = 4;     // >= the kernel's prefetch depth (ros3_kernel.hip: kPrefetch = 3)
 
 constexpr uint32_t GS_FIRST = 1u << 16;
 constexpr uint32_t GS_NOP = 1u << 17;
@@ -52,21 +59,21 @@ struct VmEntry {
 };
 
 struct VmProgram {
-  int nt = 0, nw = 0, nrounds = 0;
-  std::vector<uint32_t> blk_base;               // [nrounds*nw] first 64-word block of (round, wave)
-  std::vector<uint16_t> blk_n;                  // [nrounds*nw] slots of (round, wave)
-  std::vector<uint32_t> words;                  // [(blk_base + slot)*64 + lane]
+  int nt = 0, nw = 0, nrounds = 0, zero_slot = 0;
+  std::vector<uint32_t> wave_base;              // [nw]  first record row of each wave's linear stream
+  std::vector<uint16_t> blk_n;                  // [nrounds*nw] record rows of (round, wave)
+  std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*4 + k]   one uint4 per lane and row
   // census
-  int64_t n_updates = 0, n_items = 0, wave_slots = 0, crit_slots = 0;
+  int64_t n_updates = 0, n_items = 0, n_records = 0, wave_rows = 0, crit_rows = 0;
 };
 
 struct GsumProgram {
   int nt = 0, nw = 0, nq = 0;
-  std::vector<uint32_t> blk_base;               // [nq*nw]
-  std::vector<uint16_t> blk_n;                  // [nq*nw]
-  std::vector<uint32_t> idx;                    // [(blk_base + slot)*64 + lane]  src index | GS_FIRST | GS_NOP
+  std::vector<uint32_t> blk_base;               // [nq*nw]  first group row of (q, wave)
+  std::vector<uint16_t> blk_n;                  // [nq*nw]  group rows (4 terms per lane and row)
+  std::vector<uint32_t> idx;                    // [((blk_base + row)*64 + lane)*4 + k]  src index | GS_FIRST | GS_NOP
   std::vector<float> coef;                      // same indexing
-  int64_t n_terms = 0, wave_slots = 0;
+  int64_t n_terms = 0, wave_rows = 0;
 };
 
 struct KernelSchedule {
@@ -88,7 +95,7 @@ struct KernelSchedule {
   VmProgram lu, solve;
 };
 
-VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int nt);
+VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int zero_slot, int nt, int merge_budget = 6);
 std::vector<VmEntry> lu_entries(const MechTables& m);
 std::vector<VmEntry> solve_entries(const MechTables& m);
 GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,

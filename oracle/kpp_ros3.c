@@ -83,6 +83,14 @@ int kpp_mech_dim(const kpp_mech *m, int which) {
   return -1;
 }
 
+/* Sensitivity variants — NOT the reference's arithmetic; used only by tests/tools to measure how far the result moves
+ * under legal re-associations (what a different compiler or summation order does to the reference itself):
+ *   bit 0: backward sweep of KppSolve subtracts its terms in DESCENDING column order (the kernel's readiness order)
+ *   bit 1: a*b+c contracted to fma() in KppDecomp, KppSolve and the stoichiometric sums (-ffp-contract=fast on FMA hardware)
+ * Default 0 = the pinned, bit-exact restatement. */
+static int kpp_variant = 0;
+void kpp_set_variant(int v) { kpp_variant = v; }
+
 /* factor lookup into X = [V | F | consts] */
 static inline double xval(const kpp_mech *m, const double *V, const double *F, int code) {
   if (code < m->nvar) return V[code];
@@ -98,6 +106,7 @@ static inline double signed_sum(const int32_t *idx, const double *coef, int lo, 
     double c = coef[t];
     if (c == 1.0) acc = acc + src[idx[t]];
     else if (c == -1.0) acc = acc - src[idx[t]];
+    else if (kpp_variant & 2) acc = fma(c, src[idx[t]], acc);
     else acc = acc + c * src[idx[t]];
   }
   return acc;
@@ -135,7 +144,10 @@ int kpp_decomp(const kpp_mech *m, double *JVS, double *W) {
       int j = icol[kk];
       double a = -W[j] / JVS[diag[j]];
       W[j] = -a;
-      for (int jj = diag[j] + 1; jj < crow[j + 1]; jj++) W[icol[jj]] = W[icol[jj]] + a * JVS[jj];
+      if (kpp_variant & 2)
+        for (int jj = diag[j] + 1; jj < crow[j + 1]; jj++) W[icol[jj]] = fma(a, JVS[jj], W[icol[jj]]);
+      else
+        for (int jj = diag[j] + 1; jj < crow[j + 1]; jj++) W[icol[jj]] = W[icol[jj]] + a * JVS[jj];
     }
     for (int kk = crow[k]; kk < crow[k + 1]; kk++) JVS[kk] = W[icol[kk]];
   }
@@ -145,6 +157,21 @@ int kpp_decomp(const kpp_mech *m, double *JVS, double *W) {
 /* KppSolve_x (gas.f:6206): forward (unit L) then backward (divide by diagonal) substitution */
 void kpp_solve(const kpp_mech *m, const double *JVS, double *X) {
   const int32_t *crow = m->crow, *icol = m->icol, *diag = m->diag;
+  if (kpp_variant) {   /* sensitivity variants, see kpp_set_variant */
+    const int use_fma = kpp_variant & 2, desc = kpp_variant & 1;
+    for (int i = 0; i < m->nvar; i++) {
+      double acc = X[i];
+      for (int k = crow[i]; k < diag[i]; k++) acc = use_fma ? fma(-JVS[k], X[icol[k]], acc) : acc - JVS[k] * X[icol[k]];
+      X[i] = acc;
+    }
+    for (int i = m->nvar - 1; i >= 0; i--) {
+      double acc = X[i];
+      if (desc) for (int k = crow[i + 1] - 1; k > diag[i]; k--) acc = use_fma ? fma(-JVS[k], X[icol[k]], acc) : acc - JVS[k] * X[icol[k]];
+      else for (int k = diag[i] + 1; k < crow[i + 1]; k++) acc = use_fma ? fma(-JVS[k], X[icol[k]], acc) : acc - JVS[k] * X[icol[k]];
+      X[i] = acc / JVS[diag[i]];
+    }
+    return;
+  }
   for (int i = 0; i < m->nvar; i++) {
     double acc = X[i];
     for (int k = crow[i]; k < diag[i]; k++) acc = acc - JVS[k] * X[icol[k]];

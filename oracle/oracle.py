@@ -53,9 +53,15 @@ def _oracle_lib():
         lib.kpp_decomp.argtypes = [C.c_void_p, _dp, _dp]
         lib.kpp_solve.argtypes = [C.c_void_p, _dp, _dp]
         lib.kpp_integrate.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _dp, _dp, _dp]
+        lib.kpp_set_variant.argtypes = [C.c_int]
         lib.kpp_integrate_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _ip]
         _lib = lib
     return _lib
+
+
+def set_variant(v):
+    """0 = pinned restatement; 1 = descending backward sweep; 2 = fma-contracted (sensitivity studies only)"""
+    _oracle_lib().kpp_set_variant(int(v))
 
 
 class Oracle:

@@ -23,42 +23,48 @@ struct Emu {
 static int run_vm(const VmProgram& P, std::vector<double>& M) {
   const int nt = P.nt;
   std::vector<int> writer(M.size());
+  std::vector<uint32_t> row_of_wave((size_t)P.nw, 0);
+  std::vector<double> acc_of_lane((size_t)nt, 0.0);
+  M[(size_t)P.zero_slot] = 0.0;
   for (int r = 0; r < P.nrounds; r++) {
     std::fill(writer.begin(), writer.end(), -1);
     std::vector<std::pair<int, int>> reads;   // (slot, lane)
     std::vector<double> snapshot = M;         // every lane of a round sees the pre-round memory of OTHER lanes
     for (int w = 0; w < P.nw; w++) {
-      const uint32_t base = P.blk_base[(size_t)r * P.nw + w];
       const int n = P.blk_n[(size_t)r * P.nw + w];
+      const size_t base = (size_t)P.wave_base[(size_t)w] + row_of_wave[(size_t)w];
+      row_of_wave[(size_t)w] += (uint32_t)n;
       for (int l = 0; l < 64; l++) {
         const int lane = w * 64 + l;
         if (lane >= nt) break;
-        double acc = 0, dv = 1;
-        int tg = -1;
-        for (int sidx = 0; sidx < n; sidx++) {
-          uint32_t word = P.words[((size_t)base + sidx) * 64 + l];
-          if (word & VM_NOP) continue;
-          int i1 = word & VM_IDX_MASK, i2 = (word >> VM_IDX_BITS) & VM_IDX_MASK;
-          // a lane may re-read what it wrote itself earlier in the round (in-order LDS); others must not
-          double x = (writer[i1] == lane) ? M[i1] : snapshot[i1];
-          double y = (writer[i2] == lane) ? M[i2] : snapshot[i2];
-          reads.emplace_back(i1, lane);
-          reads.emplace_back(i2, lane);
-          if (word & VM_HDR) { acc = x; dv = y; tg = i1; }
-          else { double p = x * y; acc = acc - p; }
-          if (word & VM_END) {
-            if (tg < 0) return -1;
-            M[tg] = (word & VM_DIV) ? acc / dv : acc;
-            if (writer[tg] >= 0 && writer[tg] != lane) return -2;   // two lanes write one slot in a round
-            writer[tg] = lane;
+        double acc = acc_of_lane[(size_t)lane];
+        for (int ridx = 0; ridx < n; ridx++) {
+          const uint32_t* rec = &P.recs[((base + ridx) * 64 + l) * 4];
+          const uint32_t w0 = rec[0];
+          const int tgt = w0 & VM_IDX_MASK, dvi = (w0 >> VM_IDX_BITS) & VM_IDX_MASK;
+          auto rd = [&](int i) {
+            reads.emplace_back(i, lane);
+            return (writer[i] == lane) ? M[i] : snapshot[i];
+          };
+          const double x0 = rd(tgt), d = rd(dvi);
+          if (w0 & VM_FIRST) acc = x0;
+          for (int u = 1; u <= VM_UPD_PER_REC; u++) {
+            const int i1 = rec[u] & VM_IDX_MASK, i2 = (rec[u] >> VM_IDX_BITS) & VM_IDX_MASK;
+            const double p = rd(i1) * rd(i2);
+            acc = acc - p;
+          }
+          if ((w0 & VM_LAST) && (w0 & VM_ACTIVE)) {
+            M[tgt] = (w0 & VM_DIV) ? acc / d : acc;
+            if (writer[tgt] >= 0 && writer[tgt] != lane) return -2;   // two lanes write one slot in a round
+            writer[tgt] = lane;
           }
         }
+        acc_of_lane[(size_t)lane] = acc;
       }
     }
     for (auto& rd : reads)
-      if (writer[rd.first] >= 0 && writer[rd.first] != rd.second) {
-        return -3;   // read of a slot that another lane writes in the same round
-      }
+      if (writer[rd.first] >= 0 && writer[rd.first] != rd.second) return -3;   // read of a slot another lane writes this round
+    if (M[(size_t)P.zero_slot] != 0.0) return -4;
   }
   return 0;
 }
@@ -71,13 +77,15 @@ static void run_gsum(const GsumProgram& P, const std::vector<double>& src, std::
       const int n = P.blk_n[(size_t)q * P.nw + w];
       for (int l = 0; l < 64; l++) {
         double acc = 0.0;
-        for (int sidx = 0; sidx < n; sidx++) {
-          uint32_t word = P.idx[((size_t)base + sidx) * 64 + l];
-          float cf = P.coef[((size_t)base + sidx) * 64 + l];
-          if (word & GS_NOP) continue;
-          double t = (double)cf * src[word & 0xFFFF];
-          acc = (word & GS_FIRST) ? t : acc + t;
-        }
+        for (int ridx = 0; ridx < n; ridx++)
+          for (int k = 0; k < 4; k++) {
+            const size_t at = (((size_t)base + ridx) * 64 + l) * 4 + k;
+            uint32_t word = P.idx[at];
+            float cf = P.coef[at];
+            if (word & GS_NOP) continue;
+            double t = (double)cf * src[word & 0xFFFF];
+            acc = (word & GS_FIRST) ? t : acc + t;
+          }
         out[(size_t)q * P.nt + w * 64 + l] = acc;
       }
     }
@@ -105,7 +113,7 @@ const char* emu_describe(void* h) { return ((Emu*)h)->text.c_str(); }
 // KppDecomp on G (nnz doubles, in place) through the LU program.  Returns 0 or a negative hazard code.
 int emu_lu(void* h, double* G) {
   Emu* e = (Emu*)h;
-  std::vector<double> M((size_t)e->m.nnz + e->m.nvar, 0.0);
+  std::vector<double> M((size_t)e->m.nnz + e->m.nvar + 1, 0.0);
   std::memcpy(M.data(), G, sizeof(double) * e->m.nnz);
   int rc = run_vm(e->s.lu, M);
   std::memcpy(G, M.data(), sizeof(double) * e->m.nnz);
@@ -114,7 +122,7 @@ int emu_lu(void* h, double* G) {
 
 int emu_solve(void* h, const double* LU, double* X) {
   Emu* e = (Emu*)h;
-  std::vector<double> M((size_t)e->m.nnz + e->m.nvar);
+  std::vector<double> M((size_t)e->m.nnz + e->m.nvar + 1, 0.0);
   std::memcpy(M.data(), LU, sizeof(double) * e->m.nnz);
   std::memcpy(M.data() + e->m.nnz, X, sizeof(double) * e->m.nvar);
   int rc = run_vm(e->s.solve, M);
@@ -132,7 +140,7 @@ static void make_x(const Emu* e, const double* V, const double* F, std::vector<d
 void emu_fun(void* h, const double* V, const double* F, const double* RCT, double* Vdot) {
   Emu* e = (Emu*)h;
   const KernelSchedule& s = e->s;
-  std::vector<double> X, A((size_t)s.rpt * s.nt, 0.0), out;
+  std::vector<double> X, A((size_t)s.rpt * s.nt + 1, 0.0), out;
   make_x(e, V, F, X);
   for (int q = 0; q < s.rpt; q++)
     for (int t = 0; t < s.nt; t++) {

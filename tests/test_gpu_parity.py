@@ -5,9 +5,13 @@ Tolerance.  The kernel keeps the reference's operation order in Fun, Jac_SP, the
 forward sweep, uses no FMA contraction and IEEE division; it departs from the reference in three places only:
 the error norm is a tree reduction (gas.f:1360 sums sequentially), pow() in the step-size factor is the device
 library's (<= 1 ulp from libm's), and the backward sweep subtracts its terms in readiness order.  Each perturbs a
-step size or a K vector at the 1e-16 level; through ~100 adaptive steps that stays far below the 1e-3 integration
-tolerance.  Stated bound: |dc| / (|c| + 1e-12 * max|c| of the cell) <= 1e-6 for every species, with identical
-accepted/rejected step counts.  (Typical measured values are printed; they are ~1e-10 or smaller.)
+step size or a K vector at the 1e-16 level.  How far such perturbations move the answer is a property of the
+chemistry, not of the kernel: the REFERENCE ALGORITHM ITSELF, re-associated the way another compiler would
+(a*b+c contracted to fma, or the backward sweep summed in the other direction — oracle.set_variant, measured in
+test_reference_sensitivity below and on the CPU in tests/test_oracle.py), moves by up to 1.9e-6 (aer), 2.4e-7 (tot),
+1e-16 (gas) in the worst species, which are trace species ~1e-9 of the largest concentration.
+Stated bound, every species of every cell:   |dc| / (|c| + 1e-12 * max|c| of the cell)  <=  2e-5   (10x that spread),
+species above 1e-6 of the cell maximum <= 1e-8, and identical step bookkeeping (COMMON /Statistics/).
 """
 import numpy as np
 import pytest
@@ -15,7 +19,17 @@ import pytest
 from conftest import MECHS, rel_diff
 
 pytestmark = pytest.mark.gpu
-RTOL = 1e-6
+RTOL = 2e-5          # all species, floor 1e-12 of the cell maximum
+RTOL_MAJOR = 1e-8    # species above 1e-6 of the cell maximum
+
+
+def check(got, want, tag=""):
+    d = rel_diff(got, want)
+    major = np.abs(want) >= 1e-6 * np.abs(want).max(axis=1, keepdims=True)
+    dm = np.where(major, d, 0.0)
+    print("%s max rel diff %.3e (all species), %.3e (major species), median of per-cell max %.3e"
+          % (tag, d.max() if d.size else 0.0, dm.max() if d.size else 0.0, np.median(d.max(axis=1)) if d.size else 0.0))
+    assert d.size == 0 or (d.max() <= RTOL and dm.max() <= RTOL_MAJOR)
 
 
 @pytest.fixture(scope="module")
@@ -32,9 +46,7 @@ def test_golden_reference_calls_host_buffers(chem, mech, golden):
     g = golden[mech]
     res = chem.integrate(mech, g["var_in"], g["fix"], g["rconst"], 0.0, 10.0)
     assert np.all(res.ierr == 1)
-    d = rel_diff(res.var, g["var_out"])
-    print("%s: %d reference calls, max rel diff %.3e, median of per-cell max %.3e" % (mech, len(d), d.max(), np.median(d.max(axis=1))))
-    assert d.max() <= RTOL
+    check(res.var, g["var_out"], "%s: %d reference calls," % (mech, len(res.var)))
     assert np.array_equal(res.stats, g["stats"]), "COMMON /Statistics/ differs from the reference"
 
 
@@ -46,7 +58,7 @@ def test_golden_reference_calls_device_buffers(chem, mech, golden):
     res = chem.integrate(mech, torch.tensor(g["var_in"], device=dev), torch.tensor(g["fix"], device=dev),
                          torch.tensor(g["rconst"], device=dev))
     torch.cuda.synchronize()
-    assert rel_diff(res.var.cpu().numpy(), g["var_out"]).max() <= RTOL
+    check(res.var.cpu().numpy(), g["var_out"], mech + " device buffers:")
     assert np.array_equal(res.stats.cpu().numpy()[:, 2:5], g["stats"][:, 2:5])
 
 
@@ -60,9 +72,7 @@ def test_synthetic_batch_against_oracle(chem, mech, ncell, oracles):
     torch.cuda.synchronize()
     want, ierr, st = oracles[mech].integrate_batch(var.cpu().numpy(), fix.cpu().numpy(), rconst.cpu().numpy())
     assert np.all(ierr == 1) and np.all(res.ierr.cpu().numpy() == 1)
-    d = rel_diff(res.var.cpu().numpy(), want)
-    print("%s: %d synthetic cells, max rel diff %.3e, steps/cell %.1f" % (mech, ncell, d.max(), st[:, 2].mean()))
-    assert d.max() <= RTOL
+    check(res.var.cpu().numpy(), want, "%s: %d synthetic cells, steps/cell %.1f," % (mech, ncell, st[:, 2].mean()))
     assert np.array_equal(res.stats.cpu().numpy(), st)
 
 
@@ -124,5 +134,5 @@ def test_full_size_properties(chem):
     torch.cuda.synchronize()
     assert torch.equal(again.var, res.var[sel]) and torch.equal(again.stats, res.stats[sel])
     want, ierr, st = Oracle("tot").integrate_batch(var[sel].cpu().numpy(), fix[sel].cpu().numpy(), rconst[sel].cpu().numpy())
-    assert rel_diff(res.var[sel].cpu().numpy(), want).max() <= RTOL
+    check(res.var[sel].cpu().numpy(), want, "tot 1e5 sample:")
     assert np.array_equal(res.stats[sel].cpu().numpy(), st)

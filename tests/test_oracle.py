@@ -72,3 +72,24 @@ def test_oracle_zero_pivot_and_failure_codes(mech, oracles):
     V = np.full(o.nvar, 1e-10)
     v, ierr, st, te, he = o.integrate(V, np.ones(o.nfix), np.ones(o.nreact), 5.0, 5.0)
     assert ierr == 1 and np.array_equal(v, V) and st[2] == 0 and te == 5.0
+
+
+@pytest.mark.parametrize("mech", MECHS)
+def test_reference_sensitivity_bounds_the_parity_tolerance(mech, golden, oracles):
+    """How far does the reference's own algorithm move under legal re-association (fma contraction, other summation
+    direction in the backward sweep)?  That spread is what the GPU parity tolerance (tests/test_gpu_parity.py) is set
+    against: 2e-5 for all species must be well above it, and the step bookkeeping must not change."""
+    from conftest import rel_diff
+    from oracle.oracle import set_variant
+    g, o = golden[mech], oracles[mech]
+    worst = 0.0
+    try:
+        for v in (1, 2, 3):
+            set_variant(v)
+            out, ierr, st = o.integrate_batch(g["var_in"], g["fix"], g["rconst"])
+            assert np.array_equal(st, g["stats"]) and np.all(ierr == 1)
+            worst = max(worst, rel_diff(out, g["var_out"]).max())
+    finally:
+        set_variant(0)
+    print("%s: reference spread under re-association %.3e" % (mech, worst))
+    assert worst <= 5e-6
