@@ -24,6 +24,7 @@ namespace {
 
 constexpr uint32_t kVmIdxBits = 14, kVmIdxMask = (1u << 14) - 1;
 constexpr uint32_t kVmFirst = 1u << 28, kVmLast = 1u << 29, kVmDiv = 1u << 30, kVmActive = 1u << 31;
+constexpr uint32_t kVmRowEor = 1u << 31, kVmRowNull = 1u << 30;   // on w1 (cur.y), same in all lanes of a row
 constexpr uint32_t kGsFirst = 1u << 16, kGsNop = 1u << 17;
 constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
 constexpr int kPrefetch = 3;   // records / groups a lane's table loads run ahead (schedule.cpp appends that much slack)
@@ -59,18 +60,18 @@ __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || 
 //      linear stream, table loads running kPrefetch records ahead of use
 template <int NT>
 __device__ __forceinline__ void vm_run(const VmDev& P, double* __restrict__ M, int wave, int lane) {
-  constexpr int NW = NT / 64;
   const uint4* __restrict__ rp = reinterpret_cast<const uint4*>(P.recs) + (size_t)P.wave_base[wave] * 64 + lane;
   uint4 q0 = rp[0], q1 = rp[64], q2 = rp[128];
   double acc = 0.0;
-  for (int r = 0; r < P.nrounds; r++) {
-    const int n = P.blk_n[r * NW + wave];
-    for (int i = 0; i < n; i++) {
-      const uint4 cur = q0;
-      q0 = q1;
-      q1 = q2;
-      q2 = rp[kPrefetch * 64];
-      rp += 64;
+  int rounds_left = P.nrounds;
+  while (rounds_left > 0) {
+    const uint4 cur = q0;
+    q0 = q1;
+    q1 = q2;
+    q2 = rp[kPrefetch * 64];
+    rp += 64;
+    const uint32_t row = __builtin_amdgcn_readfirstlane(cur.y);    // row marks are identical in all lanes
+    if (!(row & kVmRowNull)) {
       const uint32_t tgt = cur.x & kVmIdxMask;
       const double x0 = M[tgt], d = M[(cur.x >> kVmIdxBits) & kVmIdxMask];
       const double a1 = M[cur.y & kVmIdxMask], b1 = M[(cur.y >> kVmIdxBits) & kVmIdxMask];
@@ -89,7 +90,10 @@ __device__ __forceinline__ void vm_run(const VmDev& P, double* __restrict__ M, i
       }
       if (fin) M[tgt] = res;
     }
-    lds_barrier();
+    if (row & kVmRowEor) {
+      lds_barrier();
+      rounds_left--;
+    }
   }
 }
 

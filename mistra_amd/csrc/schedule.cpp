@@ -164,17 +164,25 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int zero_slo
       size_t n = 0;
       for (int l = 0; l < 64; l++) n = std::max(n, prog[(size_t)wv * 64 + l].size() / 4);
       if (n > 0xFFFF) throw std::logic_error("VM block too long");
-      P.blk_n[(size_t)ridx * P.nw + wv] = (uint16_t)n;
-      for (size_t r = 0; r < n; r++)
+      const size_t rows = std::max<size_t>(n, 1);       // a wave with no work still gets a null row carrying the round mark
+      P.blk_n[(size_t)ridx * P.nw + wv] = (uint16_t)rows;
+      for (size_t r = 0; r < rows; r++) {
+        const uint32_t row_flags = (r == rows - 1 ? VM_W1_EOR : 0u) | (n == 0 ? VM_W1_NULL : 0u);
         for (int l = 0; l < 64; l++) {
           const auto& w = prog[(size_t)wv * 64 + l];
           if (r * 4 < w.size()) {
-            for (int q = 0; q < 4; q++) stream[(size_t)wv].push_back(w[r * 4 + q]);
+            stream[(size_t)wv].push_back(w[r * 4]);
+            stream[(size_t)wv].push_back(w[r * 4 + 1] | row_flags);
+            stream[(size_t)wv].push_back(w[r * 4 + 2]);
+            stream[(size_t)wv].push_back(w[r * 4 + 3]);
           } else {   // idle record: loads the 0.0 cell, stores nothing
             stream[(size_t)wv].push_back(vm_word(zero_slot, zero_slot, VM_FIRST));
-            for (int q = 0; q < 3; q++) stream[(size_t)wv].push_back(pad_upd);
+            stream[(size_t)wv].push_back(pad_upd | row_flags);
+            stream[(size_t)wv].push_back(pad_upd);
+            stream[(size_t)wv].push_back(pad_upd);
           }
         }
+      }
       P.wave_rows += (int64_t)n;
       crit = std::max(crit, (int)n);
     }

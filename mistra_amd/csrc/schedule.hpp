@@ -10,8 +10,9 @@
 //        each update slot: acc = acc - M[i1]*M[i2]   (one multiply, one subtract, no contraction; an unused slot
 //                                                     points both indices at the 0.0 cell: acc - 0*0 = acc exactly)
 //        LAST  : M[tgt] = DIV ? acc / M[dv] : acc     (only if ACTIVE; idle padding records are not)
-//    A wave's records form one linear stream over all rounds, so the next record is always prefetched while the
-//    current one executes, whatever the round structure.
+//    A wave's records form one linear stream over all rounds (the last row of a round carries an end-of-round mark, a
+//    wave without work in a round gets one null row), so table loads run ahead of use whatever the round structure
+//    and nothing but the records themselves is read from memory.
 //    It expresses the sparse LU (KppDecomp_x, gas.f:6142: entry (k,c) receives  -L(k,j)*U(j,c)  for ascending j,
 //    L entries are divided by the pivot) and both triangular sweeps of KppSolve_x (gas.f:6206) with the reference's
 //    per-entry operation ORDER preserved where that is free: an entry's updates are cut into chunks, a chunk is
@@ -41,6 +42,8 @@ constexpr uint32_t VM_FIRST = 1u << 28;
 constexpr uint32_t VM_LAST = 1u << 29;
 constexpr uint32_t VM_DIV = 1u << 30;
 constexpr uint32_t VM_ACTIVE = 1u << 31;
+constexpr uint32_t VM_W1_EOR = 1u << 31;    // on w1 of every lane of a row: last row of this round for the wave -> barrier
+constexpr uint32_t VM_W1_NULL = 1u << 30;   // on w1: the row carries no work (a wave with nothing to do in a round)
 constexpr int VM_UPD_PER_REC = 3;
 constexpr int VM_LOOKAHEAD_ROWS = 4;     // >= the kernel's prefetch depth (ros3_kernel.hip: kPrefetch = 3)
 
@@ -61,7 +64,7 @@ struct VmEntry {
 struct VmProgram {
   int nt = 0, nw = 0, nrounds = 0, zero_slot = 0;
   std::vector<uint32_t> wave_base;              // [nw]  first record row of each wave's linear stream
-  std::vector<uint16_t> blk_n;                  // [nrounds*nw] record rows of (round, wave)
+  std::vector<uint16_t> blk_n;                  // [nrounds*nw] record rows of (round, wave), null rows included (census / emulator)
   std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*4 + k]   one uint4 per lane and row
   // census
   int64_t n_updates = 0, n_items = 0, n_records = 0, wave_rows = 0, crit_rows = 0;

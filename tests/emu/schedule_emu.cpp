@@ -41,6 +41,8 @@ static int run_vm(const VmProgram& P, std::vector<double>& M) {
         for (int ridx = 0; ridx < n; ridx++) {
           const uint32_t* rec = &P.recs[((base + ridx) * 64 + l) * 4];
           const uint32_t w0 = rec[0];
+          if ((rec[1] & VM_W1_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
+          if (rec[1] & VM_W1_NULL) continue;
           const int tgt = w0 & VM_IDX_MASK, dvi = (w0 >> VM_IDX_BITS) & VM_IDX_MASK;
           auto rd = [&](int i) {
             reads.emplace_back(i, lane);

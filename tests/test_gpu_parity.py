@@ -11,7 +11,8 @@ chemistry, not of the kernel: the REFERENCE ALGORITHM ITSELF, re-associated the 
 test_reference_sensitivity below and on the CPU in tests/test_oracle.py), moves by up to 1.9e-6 (aer), 2.4e-7 (tot),
 1e-16 (gas) in the worst species, which are trace species ~1e-9 of the largest concentration.
 Stated bound, every species of every cell:   |dc| / (|c| + 1e-12 * max|c| of the cell)  <=  2e-5   (10x that spread),
-species above 1e-6 of the cell maximum <= 1e-8, and identical step bookkeeping (COMMON /Statistics/).
+species above 1e-4 of the cell maximum <= 1e-12 (their spread under re-association is 1e-15), and identical step
+bookkeeping (COMMON /Statistics/).
 """
 import numpy as np
 import pytest
@@ -20,12 +21,12 @@ from conftest import MECHS, rel_diff
 
 pytestmark = pytest.mark.gpu
 RTOL = 2e-5          # all species, floor 1e-12 of the cell maximum
-RTOL_MAJOR = 1e-8    # species above 1e-6 of the cell maximum
+RTOL_MAJOR = 1e-12   # species above 1e-4 of the cell maximum
 
 
 def check(got, want, tag=""):
     d = rel_diff(got, want)
-    major = np.abs(want) >= 1e-6 * np.abs(want).max(axis=1, keepdims=True)
+    major = np.abs(want) >= 1e-4 * np.abs(want).max(axis=1, keepdims=True)
     dm = np.where(major, d, 0.0)
     print("%s max rel diff %.3e (all species), %.3e (major species), median of per-cell max %.3e"
           % (tag, d.max() if d.size else 0.0, dm.max() if d.size else 0.0, np.median(d.max(axis=1)) if d.size else 0.0))
