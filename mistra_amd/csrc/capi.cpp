@@ -189,7 +189,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* th) {
   KernelArgs a;
   a.var_in = var_in; a.fix = fix; a.rconst = rconst; a.var_out = var_out; a.ierr = ierr; a.stats = stats;
-  a.texit_hexit = th; a.tin = tin; a.tout = tout; a.ncell = ncell;
+  a.texit_hexit = th; a.prof = nullptr; a.tin = tin; a.tout = tout; a.ncell = ncell;
   a.consts = S.consts.p; a.fun_fac = S.fun_fac.p; a.jac_fac = S.jac_fac.p; a.jvs_pos = S.jvs_pos.p;
   a.zero_pos = S.zero_pos.p; a.diag_pos = S.diag_pos.p;
   a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev(); a.solve = S.solve.dev();
@@ -274,8 +274,27 @@ int mistra_chem_integrate(int mech, int ncell, const double* var_in, const doubl
   HIP_TRY(hipMemcpy(S.s_fix.p, fix, nc * nf * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(S.s_rct.p, rconst, nc * nr * sizeof(double), hipMemcpyHostToDevice));
   KernelArgs a = make_args(S, ncell, S.s_var.p, S.s_fix.p, S.s_rct.p, tin, tout, S.s_var.p, S.s_ierr.p, S.s_stats.p, nullptr);
+  // diagnostics: MISTRA_CHEM_PROFILE=1 prints where wave 0 of the workgroups spent its cycles (mean over the cells of the call)
+  DevBuf<unsigned long long> prof;
+  const bool profile = std::getenv("MISTRA_CHEM_PROFILE") != nullptr;
+  if (profile) {
+    HIP_TRY(prof.reserve(nc * 8));
+    a.prof = prof.p;
+  }
   if (int rc = launch(mech, a, nullptr)) return rc;
   HIP_TRY(hipDeviceSynchronize());
+  if (profile) {
+    std::vector<unsigned long long> h(nc * 8);
+    HIP_TRY(hipMemcpy(h.data(), prof.p, nc * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum[8] = {0};
+    for (size_t c = 0; c < nc; c++)
+      for (int k = 0; k < 8; k++) sum[k] += (double)h[c * 8 + k];
+    const char* names[8] = {"fun", "jac", "prepare", "lu", "solve", "norm", "other", "total"};
+    std::fprintf(stderr, "[mistra_chem profile] %s, %zu cells, mean shader-clock ticks per cell:", kMechName[mech], nc);
+    for (int k = 0; k < 8; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
+    std::fprintf(stderr, "\n");
+    prof.release();
+  }
   HIP_TRY(hipMemcpy(var_out, S.s_var.p, nc * nv * sizeof(double), hipMemcpyDeviceToHost));
   if (ierr) HIP_TRY(hipMemcpy(ierr, S.s_ierr.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (stats) HIP_TRY(hipMemcpy(stats, S.s_stats.p, nc * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));

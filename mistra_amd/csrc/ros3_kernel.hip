@@ -27,7 +27,8 @@ constexpr uint32_t kVmFirst = 1u << 28, kVmLast = 1u << 29, kVmDiv = 1u << 30, k
 constexpr uint32_t kVmRowEor = 1u << 31, kVmRowNull = 1u << 30;   // on w1 (cur.y), same in all lanes of a row
 constexpr uint32_t kGsFirst = 1u << 16, kGsNop = 1u << 17;
 constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
-constexpr int kPrefetch = 3;   // records / groups a lane's table loads run ahead (schedule.cpp appends that much slack)
+constexpr int kVmDepth = 8;    // VM records in flight per lane   (schedule.cpp appends 2*depth rows of slack per stream)
+constexpr int kGsDepth = 4;    // gather-sum rows in flight per lane
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. wait for the
 // schedule-table prefetches that are deliberately kept in flight across rounds.
@@ -59,45 +60,52 @@ __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || 
 // ---- the LDS VM (schedule.hpp): rounds separated by LDS barriers; each lane walks 16-byte records of its wave's
 //      linear stream, table loads running kPrefetch records ahead of use
 template <int NT>
-__device__ __forceinline__ void vm_run(const VmDev& P, double* __restrict__ M, int wave, int lane) {
+__device__ __attribute__((noinline)) void vm_run(const VmDev& P, double* __restrict__ M, int wave, int lane) {
+  // kVmDepth records are in flight per lane: the loop is unrolled over a register ring (static indices, no moves),
+  // each slot is refilled right after it is consumed, i.e. kVmDepth records ahead of its next use.
   const uint4* __restrict__ rp = reinterpret_cast<const uint4*>(P.recs) + (size_t)P.wave_base[wave] * 64 + lane;
-  uint4 q0 = rp[0], q1 = rp[64], q2 = rp[128];
+  uint4 q[kVmDepth];
+#pragma unroll
+  for (int k = 0; k < kVmDepth; k++) q[k] = rp[k * 64];
+  rp += kVmDepth * 64;
   double acc = 0.0;
   int rounds_left = P.nrounds;
   while (rounds_left > 0) {
-    const uint4 cur = q0;
-    q0 = q1;
-    q1 = q2;
-    q2 = rp[kPrefetch * 64];
-    rp += 64;
-    const uint32_t row = __builtin_amdgcn_readfirstlane(cur.y);    // row marks are identical in all lanes
-    if (!(row & kVmRowNull)) {
-      const uint32_t tgt = cur.x & kVmIdxMask;
-      const double x0 = M[tgt], d = M[(cur.x >> kVmIdxBits) & kVmIdxMask];
-      const double a1 = M[cur.y & kVmIdxMask], b1 = M[(cur.y >> kVmIdxBits) & kVmIdxMask];
-      const double a2 = M[cur.z & kVmIdxMask], b2 = M[(cur.z >> kVmIdxBits) & kVmIdxMask];
-      const double a3 = M[cur.w & kVmIdxMask], b3 = M[(cur.w >> kVmIdxBits) & kVmIdxMask];
-      acc = (cur.x & kVmFirst) ? x0 : acc;
-      acc = acc - a1 * b1;
-      acc = acc - a2 * b2;
-      acc = acc - a3 * b3;
-      const bool fin = (cur.x & (kVmLast | kVmActive)) == (kVmLast | kVmActive);
-      const bool dodiv = fin && (cur.x & kVmDiv);
-      double res = acc;
-      if (__any(dodiv)) {
-        const double qv = acc / d;
-        res = dodiv ? qv : acc;
+#pragma unroll
+    for (int k = 0; k < kVmDepth; k++) {
+      const uint4 cur = q[k];
+      q[k] = rp[k * 64];
+      const uint32_t row = __builtin_amdgcn_readfirstlane(cur.y);    // row marks are identical in all lanes
+      if (!(row & kVmRowNull)) {
+        const uint32_t tgt = cur.x & kVmIdxMask;
+        const double x0 = M[tgt], d = M[(cur.x >> kVmIdxBits) & kVmIdxMask];
+        const double a1 = M[cur.y & kVmIdxMask], b1 = M[(cur.y >> kVmIdxBits) & kVmIdxMask];
+        const double a2 = M[cur.z & kVmIdxMask], b2 = M[(cur.z >> kVmIdxBits) & kVmIdxMask];
+        const double a3 = M[cur.w & kVmIdxMask], b3 = M[(cur.w >> kVmIdxBits) & kVmIdxMask];
+        acc = (cur.x & kVmFirst) ? x0 : acc;
+        acc = acc - a1 * b1;
+        acc = acc - a2 * b2;
+        acc = acc - a3 * b3;
+        const bool fin = (cur.x & (kVmLast | kVmActive)) == (kVmLast | kVmActive);
+        const bool dodiv = fin && (cur.x & kVmDiv);
+        double res = acc;
+        if (__any(dodiv)) {
+          const double qv = acc / d;
+          res = dodiv ? qv : acc;
+        }
+        if (fin) M[tgt] = res;
       }
-      if (fin) M[tgt] = res;
+      if (row & kVmRowEor) {
+        lds_barrier();
+        if (--rounds_left == 0) break;
+      }
     }
-    if (row & kVmRowEor) {
-      lds_barrier();
-      rounds_left--;
-    }
+    rp += kVmDepth * 64;
   }
 }
 
-// ---- the gather-sum machine: out[q] = c0*src[i0] + c1*src[i1] + ...  (left to right), four terms per table row
+// ---- the gather-sum machine: out[q] = c0*src[i0] + c1*src[i1] + ...  (left to right), four terms per table row,
+//      table loads kGsDepth rows ahead (same register-ring scheme as the VM)
 template <int NT, int NQ>
 __device__ __forceinline__ void gsum_run(const GsDev& P, const double* __restrict__ src, double (&out)[NQ], int wave, int lane) {
   constexpr int NW = NT / 64;
@@ -107,22 +115,34 @@ __device__ __forceinline__ void gsum_run(const GsDev& P, const double* __restric
     const size_t off = (size_t)P.blk_base[q * NW + wave] * 64 + lane;
     const uint4* __restrict__ ip = reinterpret_cast<const uint4*>(P.idx) + off;
     const float4* __restrict__ cp = reinterpret_cast<const float4*>(P.coef) + off;
-    uint4 i0 = ip[0], i1 = ip[64], i2 = ip[128];
-    float4 c0 = cp[0], c1 = cp[64], c2 = cp[128];
+    uint4 iq[kGsDepth];
+    float4 cq[kGsDepth];
+#pragma unroll
+    for (int k = 0; k < kGsDepth; k++) {
+      iq[k] = ip[k * 64];
+      cq[k] = cp[k * 64];
+    }
+    ip += kGsDepth * 64;
+    cp += kGsDepth * 64;
     double acc = 0.0;
-    for (int g = 0; g < n; g++) {
-      const uint4 ci = i0;
-      const float4 cc = c0;
-      i0 = i1; i1 = i2; i2 = ip[kPrefetch * 64];
-      c0 = c1; c1 = c2; c2 = cp[kPrefetch * 64];
-      ip += 64;
-      cp += 64;
-      const double x0 = src[ci.x & 0xFFFFu], x1 = src[ci.y & 0xFFFFu], x2 = src[ci.z & 0xFFFFu], x3 = src[ci.w & 0xFFFFu];
-      const double t0 = (double)cc.x * x0, t1 = (double)cc.y * x1, t2 = (double)cc.z * x2, t3 = (double)cc.w * x3;
-      acc = (ci.x & kGsNop) ? acc : ((ci.x & kGsFirst) ? t0 : acc + t0);
-      acc = (ci.y & kGsNop) ? acc : acc + t1;
-      acc = (ci.z & kGsNop) ? acc : acc + t2;
-      acc = (ci.w & kGsNop) ? acc : acc + t3;
+    for (int g = 0; g < n; g += kGsDepth) {
+#pragma unroll
+      for (int k = 0; k < kGsDepth; k++) {
+        const uint4 ci = iq[k];
+        const float4 cc = cq[k];
+        iq[k] = ip[k * 64];
+        cq[k] = cp[k * 64];
+        if (g + k < n) {
+          const double x0 = src[ci.x & 0xFFFFu], x1 = src[ci.y & 0xFFFFu], x2 = src[ci.z & 0xFFFFu], x3 = src[ci.w & 0xFFFFu];
+          const double t0 = (double)cc.x * x0, t1 = (double)cc.y * x1, t2 = (double)cc.z * x2, t3 = (double)cc.w * x3;
+          acc = (ci.x & kGsNop) ? acc : ((ci.x & kGsFirst) ? t0 : acc + t0);
+          acc = (ci.y & kGsNop) ? acc : acc + t1;
+          acc = (ci.z & kGsNop) ? acc : acc + t2;
+          acc = (ci.w & kGsNop) ? acc : acc + t3;
+        }
+      }
+      ip += kGsDepth * 64;
+      cp += kGsDepth * 64;
     }
     out[q] = acc;
   }
@@ -295,18 +315,33 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
 
   double ynew[SPT], fcn0[SPT], fcn[SPT], k1[SPT], k2[SPT], k3[SPT], yerr[SPT];
 
+  // optional phase timing (diagnostics only): cycles of wave 0 between phase boundaries, summed per cell
+  const bool profiling = a.prof != nullptr;
+  unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = profiling ? clock64() : 0ull;
+  const unsigned long long t_begin = t_last;
+  auto lap = [&](int slot) {
+    if (profiling) {
+      const unsigned long long now = clock64();
+      pc[slot] += now - t_last;
+      t_last = now;
+    }
+  };
+
   while (fabs(Tend - T) >= Roundoff) {
     if (nstp > 100000) { ierr = -6; break; }
     if (((T + 0.1 * H) == T) || (H <= Roundoff)) { ierr = -7; break; }
     Hexit = H;
     H = fmin_f(H, fabs(Tend - T));
 
+    lap(6);
     fun(y, fcn0);
+    lap(0);
     // ros_FunTimeDerivative_x (gas.f:1375): Fun_x does not depend on T and RCONST is frozen, so
     // dFdT = (1/Delta)*(Fun - Fcn0) is an exact +0.0; the evaluation is skipped, its count and its "+ HG*0.0" are kept.
     nfun += 2;
     jac();
     njac += 1;
+    lap(1);
 
     bool accepted = false;
     while (!accepted) {
@@ -317,6 +352,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
           const double ghinv = 1.0 / (Direction * H * kRosGamma1);
           singular = prepare(ghinv);
           ndec += 1;
+          lap(2);
           if (singular) {
             lds_barrier();   // everyone has read flags[0] before the retry clears it
             nsng += 1;
@@ -325,6 +361,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
             else { ierr = -8; break; }
           } else {
             vm_run<NT>(a.lu, M, wave, lane);
+            lap(3);
           }
         }
         if (ierr == -8) break;
@@ -333,32 +370,42 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       // stage 1
 #pragma unroll
       for (int q = 0; q < SPT; q++) k1[q] = fcn0[q] + (dh * kRosGamma1) * 0.0;
+      lap(6);
       solve(k1);
+      lap(4);
       // stage 2: new function value at Y + A21*K1
 #pragma unroll
       for (int q = 0; q < SPT; q++) ynew[q] = y[q] + kRosA1 * k1[q];
+      lap(6);
       fun(ynew, fcn);
+      lap(0);
       nfun += 1;
       {
         const double hc = kRosC1 / dh;
 #pragma unroll
         for (int q = 0; q < SPT; q++) k2[q] = (fcn[q] + hc * k1[q]) + (dh * kRosGamma2) * 0.0;
       }
+      lap(6);
       solve(k2);
+      lap(4);
       // stage 3 reuses the stage-2 function value
       {
         const double hc1 = kRosC2 / dh, hc2 = kRosC3 / dh;
 #pragma unroll
         for (int q = 0; q < SPT; q++) k3[q] = ((fcn[q] + hc1 * k1[q]) + hc2 * k2[q]) + (dh * kRosGamma3) * 0.0;
       }
+      lap(6);
       solve(k3);
+      lap(4);
       nsol += 3;
 #pragma unroll
       for (int q = 0; q < SPT; q++) {
         ynew[q] = ((y[q] + kRosM1 * k1[q]) + kRosM2 * k2[q]) + kRosM3 * k3[q];
         yerr[q] = ((0.0 + kRosE1 * k1[q]) + kRosE2 * k2[q]) + kRosE3 * k3[q];
       }
+      lap(6);
       const double Err = error_norm(y, ynew, yerr);
+      lap(5);
       const double Fac = fmin_f(FacMax, fmax_f(FacMin, FacSafe / pow(Err, 1.0 / kRosElo)));
       double Hnew = H * Fac;
       nstp += 1;
@@ -394,6 +441,11 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     a.ierr[cell] = ierr;
     int32_t* st = a.stats + (size_t)cell * 8;
     st[0] = nfun; st[1] = njac; st[2] = nstp; st[3] = nacc; st[4] = nrej; st[5] = ndec; st[6] = nsol; st[7] = nsng;
+    if (profiling) {
+      lap(6);
+      pc[7] = clock64() - t_begin;
+      for (int k = 0; k < 8; k++) a.prof[(size_t)cell * 8 + k] = pc[k];
+    }
     if (a.texit_hexit) {
       a.texit_hexit[(size_t)cell * 2] = T;
       a.texit_hexit[(size_t)cell * 2 + 1] = Hexit;

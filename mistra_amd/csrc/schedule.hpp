@@ -45,7 +45,7 @@ constexpr uint32_t VM_ACTIVE = 1u << 31;
 constexpr uint32_t VM_W1_EOR = 1u << 31;    // on w1 of every lane of a row: last row of this round for the wave -> barrier
 constexpr uint32_t VM_W1_NULL = 1u << 30;   // on w1: the row carries no work (a wave with nothing to do in a round)
 constexpr int VM_UPD_PER_REC = 3;
-constexpr int VM_LOOKAHEAD_ROWS = 4;     // >= the kernel's prefetch depth (ros3_kernel.hip: kPrefetch = 3)
+constexpr int VM_LOOKAHEAD_ROWS = 16;    // >= 2x the kernel's table look-ahead depth (ros3_kernel.hip: kVmDepth = 8, kGsDepth = 4)
 
 constexpr uint32_t GS_FIRST = 1u << 16;
 constexpr uint32_t GS_NOP = 1u << 17;

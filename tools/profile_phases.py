@@ -1,0 +1,11 @@
+import os, sys, time, numpy as np
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','/root/repo'))
+import torch
+from mistra_amd import chem
+from mistra_amd.workload import make_batch
+chem.init(0)
+for mech,n in (('tot',512),('aer',512),('gas',4096)):
+    var,fix,rconst=make_batch(mech,0,n,'cpu')
+    os.environ['MISTRA_CHEM_PROFILE']='1'
+    t0=time.time(); res=chem.integrate(mech,var.numpy(),fix.numpy(),rconst.numpy()); dt=time.time()-t0
+    print(mech,n,'cells wall %.3fs'%dt,'steps/cell %.1f'%res.stats[:,2].mean(), chem.describe(mech), flush=True)
