@@ -30,6 +30,21 @@ constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
 constexpr int kVmDepth = 8;    // VM records in flight per lane   (schedule.cpp appends 2*depth rows of slack per stream)
 constexpr int kGsDepth = 4;    // gather-sum rows in flight per lane
 
+// Global-memory pointers with the address space spelled out.  Pointers that arrive inside the by-value KernelArgs
+// struct are generic to the compiler, which then emits flat_load: those tick lgkmcnt as well as vmcnt and return out
+// of order, so every LDS wait would also wait for the table loads that are meant to stay in flight.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain vector types load from any address space
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class T>
+using gptr = const T __attribute__((address_space(1)))*;
+template <class T>
+using gptr_mut = T __attribute__((address_space(1)))*;
+template <class T>
+__device__ __forceinline__ gptr<T> G_(const T* p) { return (gptr<T>)p; }
+template <class T>
+__device__ __forceinline__ gptr_mut<T> GM_(T* p) { return (gptr_mut<T>)p; }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. wait for the
 // schedule-table prefetches that are deliberately kept in flight across rounds.
 __device__ __forceinline__ void lds_barrier() {
@@ -59,49 +74,106 @@ __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || 
 
 // ---- the LDS VM (schedule.hpp): rounds separated by LDS barriers; each lane walks 16-byte records of its wave's
 //      linear stream, table loads running kPrefetch records ahead of use
+// Record ring in the accumulator registers a[0:31].  hipcc's own s_waitcnt placement falls back to vmcnt(0) inside the
+// VM loop (branches, barrier), which would serialise every record behind a full memory round trip, so the table loads
+// are issued from asm and counted by hand.  A VGPR destination would be unsafe (the compiler may copy an asm output
+// before the data lands, cdna_hip_programming.md §5.7 item 1); this kernel has no MFMA, so the AGPR half of the
+// register file is free: the loads land in a[4k:4k+3], which only the two statements below ever name, and the consume
+// statement waits and copies out in ONE asm (§5.7 form i).  Loads return in issue order, hence "at most kVmDepth-1
+// outstanding" means the oldest one — the slot about to be consumed — has landed.
+template <int K>
+__device__ __forceinline__ void vm_ring_load(gptr<u32x4> p) {
+#define MISTRA_RING_LOAD(A0, A1, A2, A3)                                                                              \
+  asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, off" : : "v"(p) : "memory", "a" #A0, "a" #A1, "a" #A2, "a" #A3)
+  if constexpr (K == 0) MISTRA_RING_LOAD(0, 1, 2, 3);
+  else if constexpr (K == 1) MISTRA_RING_LOAD(4, 5, 6, 7);
+  else if constexpr (K == 2) MISTRA_RING_LOAD(8, 9, 10, 11);
+  else if constexpr (K == 3) MISTRA_RING_LOAD(12, 13, 14, 15);
+  else if constexpr (K == 4) MISTRA_RING_LOAD(16, 17, 18, 19);
+  else if constexpr (K == 5) MISTRA_RING_LOAD(20, 21, 22, 23);
+  else if constexpr (K == 6) MISTRA_RING_LOAD(24, 25, 26, 27);
+  else MISTRA_RING_LOAD(28, 29, 30, 31);
+#undef MISTRA_RING_LOAD
+}
+
+template <int K>
+__device__ __forceinline__ u32x4 vm_ring_take() {
+  uint32_t x, y, z, w;
+#define MISTRA_RING_TAKE(A0, A1, A2, A3)                                                                              \
+  asm volatile("s_waitcnt vmcnt(7)\n\tv_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1                 \
+               "\n\tv_accvgpr_read_b32 %2, a" #A2 "\n\tv_accvgpr_read_b32 %3, a" #A3                                  \
+               : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : : "memory")
+  if constexpr (K == 0) MISTRA_RING_TAKE(0, 1, 2, 3);
+  else if constexpr (K == 1) MISTRA_RING_TAKE(4, 5, 6, 7);
+  else if constexpr (K == 2) MISTRA_RING_TAKE(8, 9, 10, 11);
+  else if constexpr (K == 3) MISTRA_RING_TAKE(12, 13, 14, 15);
+  else if constexpr (K == 4) MISTRA_RING_TAKE(16, 17, 18, 19);
+  else if constexpr (K == 5) MISTRA_RING_TAKE(20, 21, 22, 23);
+  else if constexpr (K == 6) MISTRA_RING_TAKE(24, 25, 26, 27);
+  else MISTRA_RING_TAKE(28, 29, 30, 31);
+#undef MISTRA_RING_TAKE
+  return u32x4{x, y, z, w};
+}
+static_assert(kVmDepth == 8, "the ring helpers above are written for 8 slots (vmcnt(7))");
+
+// One record of the LDS VM.  Returns true when the program's last round has been closed.
+__device__ __forceinline__ bool vm_step(const u32x4 cur, double* __restrict__ M, double& acc, int& rounds_left) {
+  const uint32_t row = __builtin_amdgcn_readfirstlane(cur.y);    // row marks are identical in all lanes
+  if (!(row & kVmRowNull)) {
+    const uint32_t tgt = cur.x & kVmIdxMask;
+    const double x0 = M[tgt], d = M[(cur.x >> kVmIdxBits) & kVmIdxMask];
+    const double a1 = M[cur.y & kVmIdxMask], b1 = M[(cur.y >> kVmIdxBits) & kVmIdxMask];
+    const double a2 = M[cur.z & kVmIdxMask], b2 = M[(cur.z >> kVmIdxBits) & kVmIdxMask];
+    const double a3 = M[cur.w & kVmIdxMask], b3 = M[(cur.w >> kVmIdxBits) & kVmIdxMask];
+    acc = (cur.x & kVmFirst) ? x0 : acc;
+    acc = acc - a1 * b1;
+    acc = acc - a2 * b2;
+    acc = acc - a3 * b3;
+    const bool fin = (cur.x & (kVmLast | kVmActive)) == (kVmLast | kVmActive);
+    const bool dodiv = fin && (cur.x & kVmDiv);
+    double res = acc;
+    if (__any(dodiv)) {
+      const double qv = acc / d;
+      res = dodiv ? qv : acc;
+    }
+    if (fin) M[tgt] = res;
+  }
+  if (row & kVmRowEor) {
+    lds_barrier();
+    return --rounds_left == 0;
+  }
+  return false;
+}
+
 template <int NT>
 __device__ __attribute__((noinline)) void vm_run(const VmDev& P, double* __restrict__ M, int wave, int lane) {
-  // kVmDepth records are in flight per lane: the loop is unrolled over a register ring (static indices, no moves),
-  // each slot is refilled right after it is consumed, i.e. kVmDepth records ahead of its next use.
-  const uint4* __restrict__ rp = reinterpret_cast<const uint4*>(P.recs) + (size_t)P.wave_base[wave] * 64 + lane;
-  uint4 q[kVmDepth];
-#pragma unroll
-  for (int k = 0; k < kVmDepth; k++) q[k] = rp[k * 64];
+  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + (size_t)G_(P.wave_base)[wave] * 64 + lane;
+  int rounds_left = P.nrounds;
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
+  vm_ring_load<0>(rp);
+  vm_ring_load<1>(rp + 64);
+  vm_ring_load<2>(rp + 128);
+  vm_ring_load<3>(rp + 192);
+  vm_ring_load<4>(rp + 256);
+  vm_ring_load<5>(rp + 320);
+  vm_ring_load<6>(rp + 384);
+  vm_ring_load<7>(rp + 448);
   rp += kVmDepth * 64;
   double acc = 0.0;
-  int rounds_left = P.nrounds;
   while (rounds_left > 0) {
-#pragma unroll
-    for (int k = 0; k < kVmDepth; k++) {
-      const uint4 cur = q[k];
-      q[k] = rp[k * 64];
-      const uint32_t row = __builtin_amdgcn_readfirstlane(cur.y);    // row marks are identical in all lanes
-      if (!(row & kVmRowNull)) {
-        const uint32_t tgt = cur.x & kVmIdxMask;
-        const double x0 = M[tgt], d = M[(cur.x >> kVmIdxBits) & kVmIdxMask];
-        const double a1 = M[cur.y & kVmIdxMask], b1 = M[(cur.y >> kVmIdxBits) & kVmIdxMask];
-        const double a2 = M[cur.z & kVmIdxMask], b2 = M[(cur.z >> kVmIdxBits) & kVmIdxMask];
-        const double a3 = M[cur.w & kVmIdxMask], b3 = M[(cur.w >> kVmIdxBits) & kVmIdxMask];
-        acc = (cur.x & kVmFirst) ? x0 : acc;
-        acc = acc - a1 * b1;
-        acc = acc - a2 * b2;
-        acc = acc - a3 * b3;
-        const bool fin = (cur.x & (kVmLast | kVmActive)) == (kVmLast | kVmActive);
-        const bool dodiv = fin && (cur.x & kVmDiv);
-        double res = acc;
-        if (__any(dodiv)) {
-          const double qv = acc / d;
-          res = dodiv ? qv : acc;
-        }
-        if (fin) M[tgt] = res;
-      }
-      if (row & kVmRowEor) {
-        lds_barrier();
-        if (--rounds_left == 0) break;
-      }
+#define MISTRA_VM_SLOT(K)                                  \
+    {                                                      \
+      const u32x4 cur = vm_ring_take<K>();                 \
+      vm_ring_load<K>(rp + K * 64);                        \
+      if (vm_step(cur, M, acc, rounds_left)) break;        \
     }
+    MISTRA_VM_SLOT(0) MISTRA_VM_SLOT(1) MISTRA_VM_SLOT(2) MISTRA_VM_SLOT(3)
+    MISTRA_VM_SLOT(4) MISTRA_VM_SLOT(5) MISTRA_VM_SLOT(6) MISTRA_VM_SLOT(7)
+#undef MISTRA_VM_SLOT
     rp += kVmDepth * 64;
   }
+  // drain: the look-ahead loads must have landed before this function returns
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 }
 
 // ---- the gather-sum machine: out[q] = c0*src[i0] + c1*src[i1] + ...  (left to right), four terms per table row,
@@ -111,12 +183,12 @@ __device__ __forceinline__ void gsum_run(const GsDev& P, const double* __restric
   constexpr int NW = NT / 64;
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
-    const int n = P.blk_n[q * NW + wave];
-    const size_t off = (size_t)P.blk_base[q * NW + wave] * 64 + lane;
-    const uint4* __restrict__ ip = reinterpret_cast<const uint4*>(P.idx) + off;
-    const float4* __restrict__ cp = reinterpret_cast<const float4*>(P.coef) + off;
-    uint4 iq[kGsDepth];
-    float4 cq[kGsDepth];
+    const int n = G_(P.blk_n)[q * NW + wave];
+    const size_t off = (size_t)G_(P.blk_base)[q * NW + wave] * 64 + lane;
+    gptr<u32x4> ip = G_(reinterpret_cast<const u32x4*>(P.idx)) + off;
+    gptr<f32x4> cp = G_(reinterpret_cast<const f32x4*>(P.coef)) + off;
+    u32x4 iq[kGsDepth];
+    f32x4 cq[kGsDepth];
 #pragma unroll
     for (int k = 0; k < kGsDepth; k++) {
       iq[k] = ip[k * 64];
@@ -128,8 +200,8 @@ __device__ __forceinline__ void gsum_run(const GsDev& P, const double* __restric
     for (int g = 0; g < n; g += kGsDepth) {
 #pragma unroll
       for (int k = 0; k < kGsDepth; k++) {
-        const uint4 ci = iq[k];
-        const float4 cc = cq[k];
+        const u32x4 ci = iq[k];
+        const f32x4 cc = cq[k];
         iq[k] = ip[k * 64];
         cq[k] = cp[k * 64];
         if (g + k < n) {
@@ -175,15 +247,15 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
 #pragma unroll
   for (int q = 0; q < SPT; q++) {
     const int s = q * NT + t;
-    y[q] = s < NVAR ? a.var_in[(size_t)cell * NVAR + s] : 0.0;
+    y[q] = s < NVAR ? G_(a.var_in)[(size_t)cell * NVAR + s] : 0.0;
   }
 #pragma unroll
   for (int q = 0; q < RPT; q++) {
     const int r = q * NT + t;
-    rct[q] = r < NREACT ? a.rconst[(size_t)cell * NREACT + r] : 0.0;
+    rct[q] = r < NREACT ? G_(a.rconst)[(size_t)cell * NREACT + r] : 0.0;
   }
-  if (t < NFIX) X[NVAR + t] = a.fix[(size_t)cell * NFIX + t];
-  if (t < NCONST) X[NVAR + NFIX + t] = a.consts[t];
+  if (t < NFIX) X[NVAR + t] = G_(a.fix)[(size_t)cell * NFIX + t];
+  if (t < NCONST) X[NVAR + NFIX + t] = G_(a.consts)[t];
   if (t == 0) M[NNZ + NVAR] = 0.0;   // the VM's 0.0 cell (operand of padding update slots)
 
   // ---- Fun_x (gas.f:2043): X <- v; A(r) = RCT(r)*X*X*X; Vdot = signed sums of A
@@ -196,7 +268,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     lds_barrier();
 #pragma unroll
     for (int q = 0; q < RPT; q++) {
-      const uint64_t w = a.fun_fac[q * NT + t];
+      const uint64_t w = G_(a.fun_fac)[q * NT + t];
       double p = rct[q] * X[w & 0xFFFFu];
       p = p * X[(w >> 16) & 0xFFFFu];
       p = p * X[(w >> 32) & 0xFFFFu];
@@ -214,7 +286,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     for (int q = 0; q < RPT; q++) {
 #pragma unroll
       for (int b = 0; b < 3; b++) {
-        const uint64_t w = a.jac_fac[(q * 3 + b) * NT + t];
+        const uint64_t w = G_(a.jac_fac)[(q * 3 + b) * NT + t];
         double p = rct[q] * X[w & 0xFFFFu];
         p = p * X[(w >> 16) & 0xFFFFu];
         p = p * X[(w >> 32) & 0xFFFFu];
@@ -234,7 +306,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     bool zero_diag = false;
 #pragma unroll
     for (int q = 0; q < JPT; q++) {
-      const uint16_t p = a.jvs_pos[q * NT + t];
+      const uint16_t p = G_(a.jvs_pos)[q * NT + t];
       if (p != kPosNone) {
         double v = -jac0[q];
         if (p & kPosDiag) {
@@ -246,7 +318,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     }
 #pragma unroll
     for (int q = 0; q < ZPT; q++) {
-      const uint16_t p = a.zero_pos[q * NT + t];
+      const uint16_t p = G_(a.zero_pos)[q * NT + t];
       if (p != kPosNone) {
         double v = -0.0;
         if (p & kPosDiag) {
@@ -435,20 +507,20 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
 #pragma unroll
   for (int q = 0; q < SPT; q++) {
     const int s = q * NT + t;
-    if (s < NVAR) a.var_out[(size_t)cell * NVAR + s] = y[q];
+    if (s < NVAR) GM_(a.var_out)[(size_t)cell * NVAR + s] = y[q];
   }
   if (t == 0) {
-    a.ierr[cell] = ierr;
-    int32_t* st = a.stats + (size_t)cell * 8;
+    GM_(a.ierr)[cell] = ierr;
+    gptr_mut<int32_t> st = GM_(a.stats) + (size_t)cell * 8;
     st[0] = nfun; st[1] = njac; st[2] = nstp; st[3] = nacc; st[4] = nrej; st[5] = ndec; st[6] = nsol; st[7] = nsng;
     if (profiling) {
       lap(6);
       pc[7] = clock64() - t_begin;
-      for (int k = 0; k < 8; k++) a.prof[(size_t)cell * 8 + k] = pc[k];
+      for (int k = 0; k < 8; k++) GM_(a.prof)[(size_t)cell * 8 + k] = pc[k];
     }
     if (a.texit_hexit) {
-      a.texit_hexit[(size_t)cell * 2] = T;
-      a.texit_hexit[(size_t)cell * 2 + 1] = Hexit;
+      GM_(a.texit_hexit)[(size_t)cell * 2] = T;
+      GM_(a.texit_hexit)[(size_t)cell * 2 + 1] = Hexit;
     }
   }
 }
