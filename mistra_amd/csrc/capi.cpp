@@ -100,13 +100,16 @@ struct MechState {
   DevBuf<uint64_t> fun_fac, jac_fac;
   DevBuf<uint16_t> jvs_pos, zero_pos, diag_pos;
   GsBufs vdot, jvs;
-  VmBufs lu, solve;
+  VmBufs lu, solve_head_fwd, solve_head_bwd;
+  DevBuf<uint32_t> tail_fwd, tail_bwd;
+  DevBuf<uint16_t> tail_diag;
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
   DevBuf<int32_t> s_ierr, s_stats;
   void release() {
     consts.release(); fun_fac.release(); jac_fac.release(); jvs_pos.release(); zero_pos.release(); diag_pos.release();
-    vdot.release(); jvs.release(); lu.release(); solve.release();
+    vdot.release(); jvs.release(); lu.release(); solve_head_fwd.release(); solve_head_bwd.release();
+    tail_fwd.release(); tail_bwd.release(); tail_diag.release();
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release();
     ready = false;
   }
@@ -136,8 +139,8 @@ int default_nt(int mech) {
 }
 
 template <class MT>
-bool traits_match(const MechTables& t, int n_jnz) {
-  return t.nvar == MT::NVAR && t.nfix == MT::NFIX && t.nreact == MT::NREACT && t.nnz == MT::NNZ && t.nb == MT::NB &&
+bool traits_match(const MechTables& t, int n_jnz, int tail_regs) {
+  return tail_regs == MT::TAIL_REGS && t.nvar == MT::NVAR && t.nfix == MT::NFIX && t.nreact == MT::NREACT && t.nnz == MT::NNZ && t.nb == MT::NB &&
          t.nconst == MT::NCONST && n_jnz == MT::NJNZ;
 }
 
@@ -155,9 +158,9 @@ int setup_mech(int mech) {
   } catch (const std::exception& ex) {
     return fail(std::string("schedule compiler: ") + ex.what());
   }
-  bool ok = mech == MISTRA_MECH_GAS   ? traits_match<GasTraits>(S.tab, K.n_jnz)
-            : mech == MISTRA_MECH_AER ? traits_match<AerTraits>(S.tab, K.n_jnz)
-                                      : traits_match<TotTraits>(S.tab, K.n_jnz);
+  bool ok = mech == MISTRA_MECH_GAS   ? traits_match<GasTraits>(S.tab, K.n_jnz, K.tail.regs)
+            : mech == MISTRA_MECH_AER ? traits_match<AerTraits>(S.tab, K.n_jnz, K.tail.regs)
+                                      : traits_match<TotTraits>(S.tab, K.n_jnz, K.tail.regs);
   if (!ok) return fail(std::string(kMechName[mech]) + ": mechanism table does not match the compiled kernel sizes");
   S.text = std::string(kMechName[mech]) + ": " + describe(K);
   HIP_TRY(S.consts.upload(S.tab.consts));
@@ -169,7 +172,11 @@ int setup_mech(int mech) {
   HIP_TRY(S.vdot.upload(K.vdot));
   HIP_TRY(S.jvs.upload(K.jvs));
   HIP_TRY(S.lu.upload(K.lu));
-  HIP_TRY(S.solve.upload(K.solve));
+  HIP_TRY(S.solve_head_fwd.upload(K.solve_head_fwd));
+  HIP_TRY(S.solve_head_bwd.upload(K.solve_head_bwd));
+  HIP_TRY(S.tail_fwd.upload(K.tail.fwd));
+  HIP_TRY(S.tail_bwd.upload(K.tail.bwd));
+  HIP_TRY(S.tail_diag.upload(K.tail.diag));
   S.ready = true;
   return 0;
 }
@@ -192,7 +199,8 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
   a.texit_hexit = th; a.prof = nullptr; a.tin = tin; a.tout = tout; a.ncell = ncell;
   a.consts = S.consts.p; a.fun_fac = S.fun_fac.p; a.jac_fac = S.jac_fac.p; a.jvs_pos = S.jvs_pos.p;
   a.zero_pos = S.zero_pos.p; a.diag_pos = S.diag_pos.p;
-  a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev(); a.solve = S.solve.dev();
+  a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev(); a.solve_head_fwd = S.solve_head_fwd.dev(); a.solve_head_bwd = S.solve_head_bwd.dev();
+  a.tail = TailDev{S.tail_fwd.p, S.tail_bwd.p, S.tail_diag.p};
   return a;
 }
 

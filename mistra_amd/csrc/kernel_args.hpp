@@ -18,6 +18,12 @@ struct GsDev {                 // gather-sum program in device memory
   const float* coef;
 };
 
+struct TailDev {               // tail chain of the triangular solves (schedule.hpp: TailSolve)
+  const uint32_t* fwd;         // u32x4 per lane and group of 4 columns, columns ascending
+  const uint32_t* bwd;         // same, columns descending
+  const uint16_t* diag;        // [regs*64]
+};
+
 struct KernelArgs {
   // per-cell data, cell-major (one cell's VAR / FIX / RCONST contiguous, as COMMON /GDATA_x/ holds them)
   const double* var_in;        // [ncell][NVAR]
@@ -38,7 +44,8 @@ struct KernelArgs {
   const uint16_t* zero_pos;
   const uint16_t* diag_pos;
   GsDev vdot, jvs;
-  VmDev lu, solve;
+  VmDev lu, solve_head_fwd, solve_head_bwd;
+  TailDev tail;
 };
 
 }  // namespace mistra

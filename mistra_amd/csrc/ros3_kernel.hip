@@ -176,6 +176,95 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev& P, double* __restr
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 }
 
+// ---- tail chain of the triangular solves (schedule.hpp: TailSolve), run by ONE wave: lane l holds rows h+l and
+//      h+64+l of the solution in registers, the pivot value travels by v_readlane, matrix entries are gathered from
+//      LDS through per-column index tables streamed with the same AGPR ring as the VM (one 16-byte slot = 4 columns).
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+  return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
+
+template <int R>
+__device__ __attribute__((noinline)) void tail_solve(const TailDev& T, const double* __restrict__ M, double* __restrict__ XT, int lane) {
+  double x[R], dg[R], rd[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    x[r] = XT[r * 64 + lane];
+    dg[r] = M[G_(T.diag)[r * 64 + lane]];
+    rd[r] = 1.0 / dg[r];
+  }
+  // ---- forward: for every tail column q ascending:  x(i) -= L(i,q) * x(q)  for the tail rows i > q
+  {
+    gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.fwd)) + lane;
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    vm_ring_load<0>(tp); vm_ring_load<1>(tp + 64); vm_ring_load<2>(tp + 128); vm_ring_load<3>(tp + 192);
+    vm_ring_load<4>(tp + 256); vm_ring_load<5>(tp + 320); vm_ring_load<6>(tp + 384); vm_ring_load<7>(tp + 448);
+    tp += kVmDepth * 64;
+#pragma unroll
+    for (int rq = 0; rq < R; rq++) {
+      for (int gb = 0; gb < 16; gb += kVmDepth) {
+#define MISTRA_TAIL_FWD(K)                                                              \
+        {                                                                               \
+          const u32x4 cur = vm_ring_take<K>();                                          \
+          vm_ring_load<K>(tp + K * 64);                                                 \
+          double l[4][R];                                                               \
+          _Pragma("unroll") for (int c = 0; c < 4; c++)                                 \
+            _Pragma("unroll") for (int r = rq; r < R; r++) l[c][r] = M[(cur[c] >> (16 * r)) & 0xFFFFu]; \
+          _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
+            const double xq = readlane_f64(x[rq], 4 * (gb + K) + c);                    \
+            _Pragma("unroll") for (int r = rq; r < R; r++) x[r] = x[r] - l[c][r] * xq;  \
+          }                                                                             \
+        }
+        MISTRA_TAIL_FWD(0) MISTRA_TAIL_FWD(1) MISTRA_TAIL_FWD(2) MISTRA_TAIL_FWD(3)
+        MISTRA_TAIL_FWD(4) MISTRA_TAIL_FWD(5) MISTRA_TAIL_FWD(6) MISTRA_TAIL_FWD(7)
+#undef MISTRA_TAIL_FWD
+        tp += kVmDepth * 64;
+      }
+    }
+  }
+  // ---- backward: for every tail column q descending:  x(q) = x(q)/U(q,q);  x(i) -= U(i,q) * x(q)  for tail rows i < q.
+  //      The quotient is formed with the reciprocal and one correction step (q0 = s*r; q0 + (s - q0*d)*r), which lands on
+  //      the correctly rounded s/d except in rare ties; the IEEE divide sequence would sit on the serial chain 128 times.
+  {
+    gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.bwd)) + lane;
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    vm_ring_load<0>(tp); vm_ring_load<1>(tp + 64); vm_ring_load<2>(tp + 128); vm_ring_load<3>(tp + 192);
+    vm_ring_load<4>(tp + 256); vm_ring_load<5>(tp + 320); vm_ring_load<6>(tp + 384); vm_ring_load<7>(tp + 448);
+    tp += kVmDepth * 64;
+#pragma unroll
+    for (int rq = R - 1; rq >= 0; rq--) {
+      for (int gb = 0; gb < 16; gb += kVmDepth) {
+#define MISTRA_TAIL_BWD(K)                                                              \
+        {                                                                               \
+          const u32x4 cur = vm_ring_take<K>();                                          \
+          vm_ring_load<K>(tp + K * 64);                                                 \
+          double u[4][R];                                                               \
+          _Pragma("unroll") for (int c = 0; c < 4; c++)                                 \
+            _Pragma("unroll") for (int r = 0; r <= rq; r++) u[c][r] = M[(cur[c] >> (16 * r)) & 0xFFFFu]; \
+          _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
+            const int lq = 63 - (4 * (gb + K) + c);                                     \
+            const double sv = readlane_f64(x[rq], lq), d = readlane_f64(dg[rq], lq), rr = readlane_f64(rd[rq], lq); \
+            const double q0 = sv * rr;                                                  \
+            const double e = __builtin_fma(-q0, d, sv);                                 \
+            const double xq = __builtin_fma(e, rr, q0);                                 \
+            x[rq] = (lane == lq) ? xq : x[rq];                                          \
+            _Pragma("unroll") for (int r = 0; r <= rq; r++) x[r] = x[r] - u[c][r] * xq; \
+          }                                                                             \
+        }
+        MISTRA_TAIL_BWD(0) MISTRA_TAIL_BWD(1) MISTRA_TAIL_BWD(2) MISTRA_TAIL_BWD(3)
+        MISTRA_TAIL_BWD(4) MISTRA_TAIL_BWD(5) MISTRA_TAIL_BWD(6) MISTRA_TAIL_BWD(7)
+#undef MISTRA_TAIL_BWD
+        tp += kVmDepth * 64;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+  for (int r = 0; r < R; r++) XT[r * 64 + lane] = x[r];
+}
+
 // ---- the gather-sum machine: out[q] = c0*src[i0] + c1*src[i1] + ...  (left to right), four terms per table row,
 //      table loads kGsDepth rows ahead (same register-ring scheme as the VM)
 template <int NT, int NQ>
@@ -341,7 +430,10 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       if (s < NVAR) XS[s] = k[q];
     }
     lds_barrier();
-    vm_run<NT>(a.solve, M, wave, lane);
+    vm_run<NT>(a.solve_head_fwd, M, wave, lane);                                          // head rows, all waves
+    if (wave == 0) tail_solve<MT::TAIL_REGS>(a.tail, M, XS + (NVAR - 64 * MT::TAIL_REGS), lane);   // tail chain, one wave
+    lds_barrier();
+    vm_run<NT>(a.solve_head_bwd, M, wave, lane);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
       const int s = q * NT + t;

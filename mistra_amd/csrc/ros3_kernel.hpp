@@ -1,7 +1,8 @@
 // Compile-time mechanism sizes and the LDS carve-up shared by the kernel and its launcher.
 // Sizes: gas_Parameters.h:28-49 | aer_Parameters.h:28-49 | tot_Parameters.h:28-49 (NVAR NFIX NREACT LU_NONZERO);
 // NB / NJNZ are counted from Jac_SP_x (number of B products / of JVS slots that are not `= 0`), NCONST from the
-// factor literals (1.0 padding + the 2 of squared reactants).  The host checks the loaded table against these.
+// factor literals (1.0 padding + the 2 of squared reactants); TAIL_REGS*64 = rows of the solve's tail chain
+// (schedule.cpp: build_tail_solve).  The host checks the loaded table against these.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -9,9 +10,9 @@
 
 namespace mistra {
 
-struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945; };
-struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831; };
-struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709; };
+struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1; };
+struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2; };
+struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2; };
 
 constexpr int round_up2(int x) { return (x + 1) & ~1; }
 constexpr int max_i(int a, int b) { return a > b ? a : b; }

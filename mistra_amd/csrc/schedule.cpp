@@ -258,6 +258,69 @@ std::vector<VmEntry> solve_entries(const MechTables& m) {
   return out;
 }
 
+// Forward sweep split at row h: head rows completely, tail rows only their head-column terms (the leading terms of the
+// reference's ascending-column order); the tail chain then subtracts the tail-column terms, again ascending.
+std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, int h) {
+  const int n = m.nvar, xo = m.nnz;
+  std::vector<VmEntry> out;
+  for (int i = 0; i < n; i++) {
+    VmEntry E;
+    E.tgt = xo + i;
+    E.phase = 0;
+    for (int p = m.crow[i]; p < m.diag[i]; p++)
+      if (m.icol[p] < h) E.upd.emplace_back(p, xo + m.icol[p]);
+    if (!E.upd.empty()) out.push_back(std::move(E));
+  }
+  return out;
+}
+
+// Backward sweep of the head rows, the tail part of X being final already.
+std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, int h) {
+  const int xo = m.nnz;
+  std::vector<VmEntry> out;
+  for (int i = h - 1; i >= 0; i--) {
+    VmEntry E;
+    E.tgt = xo + i;
+    E.phase = 0;
+    E.keep_order = false;
+    E.dv = m.diag[i];
+    for (int p = m.diag[i] + 1; p < m.crow[i + 1]; p++) E.upd.emplace_back(p, xo + m.icol[p]);
+    out.push_back(std::move(E));
+  }
+  return out;
+}
+
+TailSolve build_tail_solve(const MechTables& m, int zero_slot) {
+  TailSolve T;
+  const int n = m.nvar;
+  T.regs = n > 128 + 64 ? 2 : 1;           // 128-row tail where the mechanism is big enough to leave a head
+  T.m = 64 * T.regs;
+  if (T.m > n) throw std::invalid_argument("mechanism smaller than one wave");
+  T.h = n - T.m;
+  if (zero_slot > 0xFFFF) throw std::invalid_argument("tail tables need 16-bit Ghimj slots");
+  const uint32_t z = (uint32_t)zero_slot;
+  // + VM_LOOKAHEAD_ROWS groups of slack for the kernel's look-ahead loads
+  T.fwd.assign(((size_t)T.m / 4 + VM_LOOKAHEAD_ROWS) * 256, z | (z << 16));
+  T.bwd.assign(((size_t)T.m / 4 + VM_LOOKAHEAD_ROWS) * 256, z | (z << 16));
+  T.diag.assign((size_t)T.regs * 64, 0);
+  auto put = [&](std::vector<uint32_t>& tab, int group_pos, int lane, int r, int slot) {
+    uint32_t& w = tab[((size_t)(group_pos / 4) * 64 + lane) * 4 + group_pos % 4];
+    w = r == 0 ? ((w & 0xFFFF0000u) | (uint32_t)slot) : ((w & 0x0000FFFFu) | ((uint32_t)slot << 16));
+  };
+  for (int ti = 0; ti < T.m; ti++) {
+    const int i = T.h + ti, lane = ti % 64, r = ti / 64;
+    T.diag[(size_t)r * 64 + lane] = (uint16_t)m.diag[i];
+    for (int p = m.crow[i]; p < m.crow[i + 1]; p++) {
+      const int c = m.icol[p];
+      if (c < T.h || c == i) continue;
+      const int q = c - T.h;
+      if (c < i) put(T.fwd, q, lane, r, p);                 // L(i, c): used when the forward chain reaches column q
+      else put(T.bwd, T.m - 1 - q, lane, r, p);             // U(i, c): used when the backward chain reaches column q
+    }
+  }
+  return T;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,
                                const std::vector<int>& slot_of_output, int nq, int nt) {
@@ -391,20 +454,25 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt) {
   const int msize = m.nnz + m.nvar + 1, zero_slot = m.nnz + m.nvar;     // M = [Ghimj | XS | 0.0]
   S.lu = build_vm_program(lu_entries(m), msize, zero_slot, nt);
   S.solve = build_vm_program(solve_entries(m), msize, zero_slot, nt);
+  S.tail = build_tail_solve(m, zero_slot);
+  S.solve_head_fwd = build_vm_program(solve_head_fwd_entries(m, S.tail.h), msize, zero_slot, nt);
+  S.solve_head_bwd = build_vm_program(solve_head_bwd_entries(m, S.tail.h), msize, zero_slot, nt);
   return S;
 }
 
 std::string describe(const KernelSchedule& s) {
-  char buf[1024];
+  char buf[2048];
   std::snprintf(buf, sizeof buf,
                 "nt=%d spt=%d rpt=%d jpt=%d zpt=%d | vdot: %lld terms, %lld wave-rows | jvs: %lld terms, %lld wave-rows | "
                 "LU: %d rounds, %lld updates in %lld items / %lld records, %lld wave-rows, critical %lld | "
-                "solve: %d rounds, %lld updates in %lld items / %lld records, %lld wave-rows, critical %lld",
+                "solve: tail %d rows in registers of one wave; head fwd %d rounds / %lld rows critical, head bwd %d rounds / %lld rows "
+                "critical (whole solve as one VM program: %d rounds, %lld updates, %lld records, critical %lld)",
                 s.nt, s.spt, s.rpt, s.jpt, s.zpt, (long long)s.vdot.n_terms, (long long)s.vdot.wave_rows,
                 (long long)s.jvs.n_terms, (long long)s.jvs.wave_rows, s.lu.nrounds, (long long)s.lu.n_updates,
                 (long long)s.lu.n_items, (long long)s.lu.n_records, (long long)s.lu.wave_rows, (long long)s.lu.crit_rows,
-                s.solve.nrounds, (long long)s.solve.n_updates, (long long)s.solve.n_items, (long long)s.solve.n_records,
-                (long long)s.solve.wave_rows, (long long)s.solve.crit_rows);
+                s.tail.m, s.solve_head_fwd.nrounds, (long long)s.solve_head_fwd.crit_rows, s.solve_head_bwd.nrounds,
+                (long long)s.solve_head_bwd.crit_rows, s.solve.nrounds, (long long)s.solve.n_updates, (long long)s.solve.n_records,
+                (long long)s.solve.crit_rows);
   return buf;
 }
 

@@ -79,6 +79,18 @@ struct GsumProgram {
   int64_t n_terms = 0, wave_rows = 0;
 };
 
+// Triangular solves, tail part.  The last m rows of the LU pattern (the gas-phase block every other species couples
+// to) form a nearly dense triangle whose substitution is an inherently serial chain; it is run by ONE wave with the
+// tail of the solution vector in registers (lane l holds rows h+l, h+64+l), the pivot value passed lane-to-lane by
+// v_readlane, and only the matrix entries gathered from LDS through these per-column index tables:
+//   word (16 bit) for column q, lane l, register r  =  Ghimj slot of entry (row h+64r+l, column h+q), or the 0.0 cell
+struct TailSolve {
+  int m = 0, h = 0, regs = 0;                   // tail rows [h, h+m), m = 64*regs, regs in {1,2}
+  std::vector<uint32_t> fwd;                    // [((q/4)*64 + lane)*4 + q%4]  lo16: r=0, hi16: r=1; columns ascending
+  std::vector<uint32_t> bwd;                    // same, columns DEscending: group g, word c  <->  q = m-1-(4g+c)
+  std::vector<uint16_t> diag;                   // [regs*64] Ghimj slot of the diagonal of tail row r*64+lane
+};
+
 struct KernelSchedule {
   int nt = 0, nw = 0;
   int spt = 0;   // species per thread          s = q*nt + t
@@ -95,12 +107,17 @@ struct KernelSchedule {
   std::vector<uint16_t> jvs_pos;                // [jpt*nt] Ghimj slot (| POS_DIAG) of that output, POS_NONE = idle
   std::vector<uint16_t> zero_pos;               // [zpt*nt] Ghimj slots that Jac_SP_x sets to 0 (| POS_DIAG)
   std::vector<uint16_t> diag_pos;               // [spt*nt] Ghimj slot of (s,s), POS_NONE past nvar
-  VmProgram lu, solve;
+  VmProgram lu, solve;                          // solve = the whole of KppSolve_x as one VM program (kept for tests)
+  VmProgram solve_head_fwd, solve_head_bwd;     // head rows (+ head-column part of tail rows) around the tail chain
+  TailSolve tail;
 };
 
 VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int zero_slot, int nt, int merge_budget = 6);
 std::vector<VmEntry> lu_entries(const MechTables& m);
 std::vector<VmEntry> solve_entries(const MechTables& m);
+std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, int h);
+std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, int h);
+TailSolve build_tail_solve(const MechTables& m, int zero_slot);
 GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,
                                const std::vector<int>& slot_of_output, int nq, int nt);
 KernelSchedule build_kernel_schedule(const MechTables& m, int nt);

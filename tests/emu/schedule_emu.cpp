@@ -132,11 +132,64 @@ int emu_solve(void* h, const double* LU, double* X) {
   return rc;
 }
 
+// The kernel's solve: head forward (VM) -> tail chain forward/backward (one wave, registers) -> head backward (VM).
+// The tail loops below mirror tail_forward/tail_backward of ros3_kernel.hip statement by statement.
+static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, int nnz) {
+  int rc = run_vm(s.solve_head_fwd, M);
+  if (rc) return rc;
+  const TailSolve& T = s.tail;
+  const int R = T.regs, m = T.m;
+  std::vector<double> x((size_t)R * 64), dg((size_t)R * 64), rd((size_t)R * 64);
+  for (int i = 0; i < m; i++) {
+    x[(size_t)i] = M[(size_t)nnz + T.h + i];
+    dg[(size_t)i] = M[T.diag[(size_t)i]];
+    rd[(size_t)i] = 1.0 / dg[(size_t)i];
+  }
+  auto idx = [&](const std::vector<uint32_t>& tab, int pos, int lane, int r) {
+    uint32_t w = tab[((size_t)(pos / 4) * 64 + lane) * 4 + pos % 4];
+    return (int)(r == 0 ? (w & 0xFFFFu) : (w >> 16));
+  };
+  for (int q = 0; q < m; q++) {
+    const int rq = q / 64, lq = q % 64;
+    const double xq = x[(size_t)rq * 64 + lq];
+    for (int r = rq; r < R; r++)
+      for (int lane = 0; lane < 64; lane++) {
+        const double l = M[(size_t)idx(T.fwd, q, lane, r)];
+        x[(size_t)r * 64 + lane] = x[(size_t)r * 64 + lane] - l * xq;
+      }
+  }
+  for (int q = m - 1; q >= 0; q--) {
+    const int rq = q / 64, lq = q % 64;
+    const double sv = x[(size_t)rq * 64 + lq], d = dg[(size_t)rq * 64 + lq], rr = rd[(size_t)rq * 64 + lq];
+    const double q0 = sv * rr;
+    const double e = std::fma(-q0, d, sv);
+    const double xq = std::fma(e, rr, q0);
+    x[(size_t)rq * 64 + lq] = xq;
+    for (int r = 0; r <= rq; r++)
+      for (int lane = 0; lane < 64; lane++) {
+        const double u = M[(size_t)idx(T.bwd, m - 1 - q, lane, r)];
+        x[(size_t)r * 64 + lane] = x[(size_t)r * 64 + lane] - u * xq;
+      }
+  }
+  for (int i = 0; i < m; i++) M[(size_t)nnz + T.h + i] = x[(size_t)i];
+  return run_vm(s.solve_head_bwd, M);
+}
+
 static void make_x(const Emu* e, const double* V, const double* F, std::vector<double>& X) {
   X.resize((size_t)e->m.nx());
   std::memcpy(X.data(), V, sizeof(double) * e->m.nvar);
   std::memcpy(X.data() + e->m.nvar, F, sizeof(double) * e->m.nfix);
   std::memcpy(X.data() + e->m.nspec(), e->m.consts.data(), sizeof(double) * e->m.nconst);
+}
+
+int emu_solve_split(void* h, const double* LU, double* X) {
+  Emu* e = (Emu*)h;
+  std::vector<double> M((size_t)e->m.nnz + e->m.nvar + 1, 0.0);
+  std::memcpy(M.data(), LU, sizeof(double) * e->m.nnz);
+  std::memcpy(M.data() + e->m.nnz, X, sizeof(double) * e->m.nvar);
+  int rc = run_solve_split(e->s, M, e->m.nnz);
+  std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
+  return rc;
 }
 
 void emu_fun(void* h, const double* V, const double* F, const double* RCT, double* Vdot) {

@@ -27,6 +27,7 @@ def emu():
     lib.emu_describe.argtypes = [C.c_void_p]
     lib.emu_lu.argtypes = [C.c_void_p, dp]
     lib.emu_solve.argtypes = [C.c_void_p, dp, dp]
+    lib.emu_solve_split.argtypes = [C.c_void_p, dp, dp]
     lib.emu_fun.argtypes = [C.c_void_p, dp, dp, dp, dp]
     lib.emu_jac_prepare.argtypes = [C.c_void_p, dp, dp, dp, C.c_double, C.c_int, dp]
     lib.emu_round_profile.argtypes = [C.c_void_p, C.c_int, ip, ip, C.c_int]
@@ -70,6 +71,10 @@ def test_programs_match_oracle(emu, mech, nt, golden, oracles):
         assert emu.emu_solve(h, P(lu_ref), P(x)) == 0, "hazard inside a solve round"
         x_ref = o.solve(lu_ref, b)
         assert np.abs(x - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
+        # the form the kernel runs: head rows through the VM, the tail chain by one wave in registers
+        x2 = b.copy()
+        assert emu.emu_solve_split(h, P(lu_ref), P(x2)) == 0, "hazard inside a head round"
+        assert np.abs(x2 - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
 
 
 def test_round_structure_tot(emu):
