@@ -22,17 +22,16 @@ namespace mistra {
 
 namespace {
 
-constexpr uint32_t kVmIdxBits = 14, kVmIdxMask = (1u << 14) - 1;
-constexpr uint32_t kVmFirst = 1u << 28, kVmLast = 1u << 29, kVmDiv = 1u << 30, kVmActive = 1u << 31;
-constexpr uint32_t kVmRowEor = 1u << 31, kVmRowNull = 1u << 30;   // on w1 (cur.y), same in all lanes of a row
+// LDS VM record fields (schedule.hpp): LDS byte offsets with flags in the three alignment bits
+constexpr uint32_t kD0First = 1u, kD0Last = 2u, kD0Active = 4u;
+constexpr uint32_t kD1MulR = 1u, kD1Rcp = 2u;
+constexpr uint32_t kD2Eor = 1u, kD2Null = 2u, kD2Rcp = 4u;
+constexpr uint32_t kOffMask = ~7u;
 constexpr uint32_t kGsFirst = 1u << 16, kGsNop = 1u << 17;
 constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
-constexpr int kVmDepth = 8;    // VM records in flight per lane   (schedule.cpp appends 2*depth rows of slack per stream)
+constexpr int kRingSlots = 8;  // 16-byte table loads in flight per lane (schedule.cpp appends 2x that many rows of slack)
 constexpr int kGsDepth = 4;    // gather-sum rows in flight per lane
 
-// Global-memory pointers with the address space spelled out.  Pointers that arrive inside the by-value KernelArgs
-// struct are generic to the compiler, which then emits flat_load: those tick lgkmcnt as well as vmcnt and return out
-// of order, so every LDS wait would also wait for the table loads that are meant to stay in flight.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain vector types load from any address space
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -44,6 +43,15 @@ template <class T>
 __device__ __forceinline__ gptr<T> G_(const T* p) { return (gptr<T>)p; }
 template <class T>
 __device__ __forceinline__ gptr_mut<T> GM_(T* p) { return (gptr_mut<T>)p; }
+
+// LDS accesses by 32-bit LDS address.  A `double*` that crosses a (non-inlined) function boundary is a generic pointer:
+// every access through it pays a generic->LDS conversion with a null check (4 VALU + a scalar load per operand).
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ double lds_ld(uint32_t addr) { return *(const lds_f64*)(uintptr_t)addr; }
+__device__ __forceinline__ void lds_st(uint32_t addr, double v) { *(lds_f64*)(uintptr_t)addr = v; }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. wait for the
 // schedule-table prefetches that are deliberately kept in flight across rounds.
@@ -96,13 +104,13 @@ __device__ __forceinline__ void vm_ring_load(gptr<u32x4> p) {
 #undef MISTRA_RING_LOAD
 }
 
-template <int K>
+template <int K, int PENDING = 7>
 __device__ __forceinline__ u32x4 vm_ring_take() {
   uint32_t x, y, z, w;
 #define MISTRA_RING_TAKE(A0, A1, A2, A3)                                                                              \
-  asm volatile("s_waitcnt vmcnt(7)\n\tv_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1                 \
+  asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1                 \
                "\n\tv_accvgpr_read_b32 %2, a" #A2 "\n\tv_accvgpr_read_b32 %3, a" #A3                                  \
-               : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : : "memory")
+               : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : "n"(PENDING) : "memory")
   if constexpr (K == 0) MISTRA_RING_TAKE(0, 1, 2, 3);
   else if constexpr (K == 1) MISTRA_RING_TAKE(4, 5, 6, 7);
   else if constexpr (K == 2) MISTRA_RING_TAKE(8, 9, 10, 11);
@@ -114,31 +122,27 @@ __device__ __forceinline__ u32x4 vm_ring_take() {
 #undef MISTRA_RING_TAKE
   return u32x4{x, y, z, w};
 }
-static_assert(kVmDepth == 8, "the ring helpers above are written for 8 slots (vmcnt(7))");
+static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots");
 
-// One record of the LDS VM.  Returns true when the program's last round has been closed.
-__device__ __forceinline__ bool vm_step(const u32x4 cur, double* __restrict__ M, double& acc, int& rounds_left) {
-  const uint32_t row = __builtin_amdgcn_readfirstlane(cur.y);    // row marks are identical in all lanes
-  if (!(row & kVmRowNull)) {
-    const uint32_t tgt = cur.x & kVmIdxMask;
-    const double x0 = M[tgt], d = M[(cur.x >> kVmIdxBits) & kVmIdxMask];
-    const double a1 = M[cur.y & kVmIdxMask], b1 = M[(cur.y >> kVmIdxBits) & kVmIdxMask];
-    const double a2 = M[cur.z & kVmIdxMask], b2 = M[(cur.z >> kVmIdxBits) & kVmIdxMask];
-    const double a3 = M[cur.w & kVmIdxMask], b3 = M[(cur.w >> kVmIdxBits) & kVmIdxMask];
-    acc = (cur.x & kVmFirst) ? x0 : acc;
-    acc = acc - a1 * b1;
-    acc = acc - a2 * b2;
-    acc = acc - a3 * b3;
-    const bool fin = (cur.x & (kVmLast | kVmActive)) == (kVmLast | kVmActive);
-    const bool dodiv = fin && (cur.x & kVmDiv);
-    double res = acc;
-    if (__any(dodiv)) {
-      const double qv = acc / d;
-      res = dodiv ? qv : acc;
+// One record of the LDS VM (schedule.hpp); mb = LDS address of M.  Returns true when the last round has been closed.
+__device__ __forceinline__ bool vm_step(const u32x4 lo, const u32x4 hi, uint32_t mb, double& acc, int& rounds_left) {
+  const uint32_t row = __builtin_amdgcn_readfirstlane(lo.z);       // row marks are identical in all lanes
+  if (!(row & kD2Null)) {
+    const uint32_t tgt = mb + (lo.x & kOffMask), aux = mb + (lo.y & kOffMask);
+    const double x0 = lds_ld(tgt), ax = lds_ld(aux);
+    const double a1 = lds_ld(mb + (lo.z & kOffMask)), r1 = lds_ld(mb + lo.w), u1 = lds_ld(mb + hi.x);
+    const double a2 = lds_ld(mb + hi.y), r2 = lds_ld(mb + hi.z), u2 = lds_ld(mb + hi.w);
+    acc = (lo.x & kD0First) ? x0 : acc;
+    acc = acc - (a1 * r1) * u1;
+    acc = acc - (a2 * r2) * u2;
+    const bool fin = (lo.x & (kD0Last | kD0Active)) == (kD0Last | kD0Active);
+    const double res = (lo.y & kD1MulR) ? acc * ax : acc;
+    if (fin) lds_st(tgt, res);
+    if (row & kD2Rcp) {                                            // some lane of this row finalises a pivot
+      if (fin && (lo.y & kD1Rcp)) lds_st(aux, 1.0 / res);
     }
-    if (fin) M[tgt] = res;
   }
-  if (row & kVmRowEor) {
+  if (row & kD2Eor) {
     lds_barrier();
     return --rounds_left == 0;
   }
@@ -147,30 +151,29 @@ __device__ __forceinline__ bool vm_step(const u32x4 cur, double* __restrict__ M,
 
 template <int NT>
 __device__ __attribute__((noinline)) void vm_run(const VmDev& P, double* __restrict__ M, int wave, int lane) {
-  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + (size_t)G_(P.wave_base)[wave] * 64 + lane;
+  // a record is two 16-byte halves: 4 records (8 loads) in flight per lane
+  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)G_(P.wave_base)[wave] * 64 + lane) * 2;
+  const uint32_t Mb = lds_addr(M);
   int rounds_left = P.nrounds;
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
-  vm_ring_load<0>(rp);
-  vm_ring_load<1>(rp + 64);
-  vm_ring_load<2>(rp + 128);
-  vm_ring_load<3>(rp + 192);
-  vm_ring_load<4>(rp + 256);
-  vm_ring_load<5>(rp + 320);
-  vm_ring_load<6>(rp + 384);
-  vm_ring_load<7>(rp + 448);
-  rp += kVmDepth * 64;
+  vm_ring_load<0>(rp);       vm_ring_load<1>(rp + 1);
+  vm_ring_load<2>(rp + 128); vm_ring_load<3>(rp + 129);
+  vm_ring_load<4>(rp + 256); vm_ring_load<5>(rp + 257);
+  vm_ring_load<6>(rp + 384); vm_ring_load<7>(rp + 385);
+  rp += 4 * 128;
   double acc = 0.0;
   while (rounds_left > 0) {
-#define MISTRA_VM_SLOT(K)                                  \
-    {                                                      \
-      const u32x4 cur = vm_ring_take<K>();                 \
-      vm_ring_load<K>(rp + K * 64);                        \
-      if (vm_step(cur, M, acc, rounds_left)) break;        \
+#define MISTRA_VM_SLOT(K)                                                \
+    {                                                                    \
+      const u32x4 lo = vm_ring_take<2 * K, 6>();      /* the two oldest of 8 loads have landed */ \
+      const u32x4 hi = vm_ring_take<2 * K + 1, 6>();                      \
+      vm_ring_load<2 * K>(rp + K * 128);                                 \
+      vm_ring_load<2 * K + 1>(rp + K * 128 + 1);                         \
+      if (vm_step(lo, hi, Mb, acc, rounds_left)) break;                  \
     }
     MISTRA_VM_SLOT(0) MISTRA_VM_SLOT(1) MISTRA_VM_SLOT(2) MISTRA_VM_SLOT(3)
-    MISTRA_VM_SLOT(4) MISTRA_VM_SLOT(5) MISTRA_VM_SLOT(6) MISTRA_VM_SLOT(7)
 #undef MISTRA_VM_SLOT
-    rp += kVmDepth * 64;
+    rp += 4 * 128;
   }
   // drain: the look-ahead loads must have landed before this function returns
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
@@ -187,13 +190,15 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 
 template <int R>
-__device__ __attribute__((noinline)) void tail_solve(const TailDev& T, const double* __restrict__ M, double* __restrict__ XT, int lane) {
+__device__ __attribute__((noinline)) void tail_solve(const TailDev& T, const double* __restrict__ M, double* __restrict__ XT,
+                                                     const double* __restrict__ RT, int lane) {
+  const uint32_t mb = lds_addr(M), xb = lds_addr(XT), rb = lds_addr(RT);
   double x[R], dg[R], rd[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    x[r] = XT[r * 64 + lane];
-    dg[r] = M[G_(T.diag)[r * 64 + lane]];
-    rd[r] = 1.0 / dg[r];
+    x[r] = lds_ld(xb + 8 * (r * 64 + lane));
+    dg[r] = lds_ld(mb + 8 * (uint32_t)G_(T.diag)[r * 64 + lane]);
+    rd[r] = lds_ld(rb + 8 * (r * 64 + lane));          // R(k) = 1/U(k,k), published by the LU program
   }
   // ---- forward: for every tail column q ascending:  x(i) -= L(i,q) * x(q)  for the tail rows i > q
   {
@@ -201,17 +206,17 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, const dou
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     vm_ring_load<0>(tp); vm_ring_load<1>(tp + 64); vm_ring_load<2>(tp + 128); vm_ring_load<3>(tp + 192);
     vm_ring_load<4>(tp + 256); vm_ring_load<5>(tp + 320); vm_ring_load<6>(tp + 384); vm_ring_load<7>(tp + 448);
-    tp += kVmDepth * 64;
+    tp += kRingSlots * 64;
 #pragma unroll
     for (int rq = 0; rq < R; rq++) {
-      for (int gb = 0; gb < 16; gb += kVmDepth) {
+      for (int gb = 0; gb < 16; gb += kRingSlots) {
 #define MISTRA_TAIL_FWD(K)                                                              \
         {                                                                               \
           const u32x4 cur = vm_ring_take<K>();                                          \
           vm_ring_load<K>(tp + K * 64);                                                 \
           double l[4][R];                                                               \
           _Pragma("unroll") for (int c = 0; c < 4; c++)                                 \
-            _Pragma("unroll") for (int r = rq; r < R; r++) l[c][r] = M[(cur[c] >> (16 * r)) & 0xFFFFu]; \
+            _Pragma("unroll") for (int r = rq; r < R; r++) l[c][r] = lds_ld(mb + 8 * ((cur[c] >> (16 * r)) & 0xFFFFu)); \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const double xq = readlane_f64(x[rq], 4 * (gb + K) + c);                    \
             _Pragma("unroll") for (int r = rq; r < R; r++) x[r] = x[r] - l[c][r] * xq;  \
@@ -220,7 +225,7 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, const dou
         MISTRA_TAIL_FWD(0) MISTRA_TAIL_FWD(1) MISTRA_TAIL_FWD(2) MISTRA_TAIL_FWD(3)
         MISTRA_TAIL_FWD(4) MISTRA_TAIL_FWD(5) MISTRA_TAIL_FWD(6) MISTRA_TAIL_FWD(7)
 #undef MISTRA_TAIL_FWD
-        tp += kVmDepth * 64;
+        tp += kRingSlots * 64;
       }
     }
   }
@@ -232,17 +237,17 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, const dou
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     vm_ring_load<0>(tp); vm_ring_load<1>(tp + 64); vm_ring_load<2>(tp + 128); vm_ring_load<3>(tp + 192);
     vm_ring_load<4>(tp + 256); vm_ring_load<5>(tp + 320); vm_ring_load<6>(tp + 384); vm_ring_load<7>(tp + 448);
-    tp += kVmDepth * 64;
+    tp += kRingSlots * 64;
 #pragma unroll
     for (int rq = R - 1; rq >= 0; rq--) {
-      for (int gb = 0; gb < 16; gb += kVmDepth) {
+      for (int gb = 0; gb < 16; gb += kRingSlots) {
 #define MISTRA_TAIL_BWD(K)                                                              \
         {                                                                               \
           const u32x4 cur = vm_ring_take<K>();                                          \
           vm_ring_load<K>(tp + K * 64);                                                 \
           double u[4][R];                                                               \
           _Pragma("unroll") for (int c = 0; c < 4; c++)                                 \
-            _Pragma("unroll") for (int r = 0; r <= rq; r++) u[c][r] = M[(cur[c] >> (16 * r)) & 0xFFFFu]; \
+            _Pragma("unroll") for (int r = 0; r <= rq; r++) u[c][r] = lds_ld(mb + 8 * ((cur[c] >> (16 * r)) & 0xFFFFu)); \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const int lq = 63 - (4 * (gb + K) + c);                                     \
             const double sv = readlane_f64(x[rq], lq), d = readlane_f64(dg[rq], lq), rr = readlane_f64(rd[rq], lq); \
@@ -256,13 +261,13 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, const dou
         MISTRA_TAIL_BWD(0) MISTRA_TAIL_BWD(1) MISTRA_TAIL_BWD(2) MISTRA_TAIL_BWD(3)
         MISTRA_TAIL_BWD(4) MISTRA_TAIL_BWD(5) MISTRA_TAIL_BWD(6) MISTRA_TAIL_BWD(7)
 #undef MISTRA_TAIL_BWD
-        tp += kVmDepth * 64;
+        tp += kRingSlots * 64;
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
-  for (int r = 0; r < R; r++) XT[r * 64 + lane] = x[r];
+  for (int r = 0; r < R; r++) lds_st(xb + 8 * (r * 64 + lane), x[r]);
 }
 
 // ---- the gather-sum machine: out[q] = c0*src[i0] + c1*src[i1] + ...  (left to right), four terms per table row,
@@ -345,7 +350,10 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
   }
   if (t < NFIX) X[NVAR + t] = G_(a.fix)[(size_t)cell * NFIX + t];
   if (t < NCONST) X[NVAR + NFIX + t] = G_(a.consts)[t];
-  if (t == 0) M[NNZ + NVAR] = 0.0;   // the VM's 0.0 cell (operand of padding update slots)
+  if (t == 0) {   // the VM's constant cells: 0.0 (padding update slots) and 1.0 (neutral pivot factor)
+    M[NNZ + NVAR] = 0.0;
+    M[NNZ + NVAR + 1] = 1.0;
+  }
 
   // ---- Fun_x (gas.f:2043): X <- v; A(r) = RCT(r)*X*X*X; Vdot = signed sums of A
   auto fun = [&](const double (&v)[SPT], double (&out)[SPT]) {
@@ -431,7 +439,8 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     }
     lds_barrier();
     vm_run<NT>(a.solve_head_fwd, M, wave, lane);                                          // head rows, all waves
-    if (wave == 0) tail_solve<MT::TAIL_REGS>(a.tail, M, XS + (NVAR - 64 * MT::TAIL_REGS), lane);   // tail chain, one wave
+    if (wave == 0)                                                                         // tail chain, one wave
+      tail_solve<MT::TAIL_REGS>(a.tail, M, XS + (NVAR - 64 * MT::TAIL_REGS), M + NNZ + NVAR + 2 + (NVAR - 64 * MT::TAIL_REGS), lane);
     lds_barrier();
     vm_run<NT>(a.solve_head_bwd, M, wave, lane);
 #pragma unroll

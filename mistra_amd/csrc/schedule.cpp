@@ -14,14 +14,12 @@ namespace {
 struct Item {            // one chunk of one entry inside one round
   int entry;
   int first, count;      // range of entry.upd
-  bool div;              // divide by M[dv] before the store
-  int cost() const { return 1 + count; }
+  bool final;            // completes the entry: apply MULR / RCP
 };
 
-uint32_t vm_word(int i1, int i2, uint32_t flags) {
-  if (i1 < 0 || i2 < 0 || (uint32_t)i1 > VM_IDX_MASK || (uint32_t)i2 > VM_IDX_MASK)
-    throw std::logic_error("VM index out of range");
-  return (uint32_t)i1 | ((uint32_t)i2 << VM_IDX_BITS) | flags;
+uint32_t vm_off(int idx, uint32_t flags) {
+  if (idx < 0 || idx >= (1 << 20)) throw std::logic_error("VM index out of range");
+  return ((uint32_t)idx << 3) | flags;
 }
 
 // Snake-deal n work items (already sorted by decreasing cost) over lanes; small sets are packed into few waves.
@@ -41,10 +39,9 @@ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
-VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int zero_slot, int nt, int merge_budget) {
+VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget) {
   if (nt % 64 != 0 || nt <= 0) throw std::invalid_argument("nt must be a positive multiple of 64");
-  if ((uint32_t)msize > VM_IDX_MASK + 1 || zero_slot < 0 || zero_slot >= msize)
-    throw std::invalid_argument("VM memory exceeds the 14-bit index space");
+  const int msize = lay.size(), zero_slot = lay.zero();
   VmProgram P;
   P.nt = nt;
   P.nw = nt / 64;
@@ -63,12 +60,13 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int zero_slo
       base = std::max(base, phase_max);     // the next phase starts after every round of the previous one
     }
     const int n = (int)E.upd.size();
-    if (n == 0 && E.dv < 0) continue;       // nothing to do, value stays as it is
+    const bool has_final_op = E.mulr >= 0 || E.rcp >= 0;
+    if (n == 0 && !has_final_op) continue;  // nothing to do, value stays as it is
     std::vector<int> ru((size_t)n);
     for (int i = 0; i < n; i++) {
-      int a = E.upd[i].first, b = E.upd[i].second;
-      if (a == E.tgt || b == E.tgt) throw std::invalid_argument("VM entry reads its own target");
-      ru[i] = std::max({base + 1, fin[a] + 1, fin[b] + 1});      // operands must be final
+      const VmUpd& u = E.upd[(size_t)i];
+      if (u.a == E.tgt || u.r == E.tgt || u.u == E.tgt) throw std::invalid_argument("VM entry reads its own target");
+      ru[i] = std::max({base + 1, fin[u.a] + 1, fin[u.r] + 1, fin[u.u] + 1});      // operands must be final
     }
     if (E.keep_order) {
       for (int i = 1; i < n; i++) ru[i] = std::max(ru[i], ru[i - 1]);   // chunks keep the given order
@@ -76,15 +74,16 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int zero_slo
       std::vector<int> perm((size_t)n);
       std::iota(perm.begin(), perm.end(), 0);
       std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return ru[x] < ru[y]; });
-      std::vector<std::pair<int, int>> u2((size_t)n);
+      std::vector<VmUpd> u2((size_t)n);
       std::vector<int> r2((size_t)n);
       for (int i = 0; i < n; i++) { u2[i] = E.upd[(size_t)perm[i]]; r2[i] = ru[(size_t)perm[i]]; }
       E.upd.swap(u2);
       ru.swap(r2);
     }
     const int last = n ? ru[n - 1] : base;
-    int rdiv = -1;
-    if (E.dv >= 0) rdiv = std::max({last, fin[E.dv] + 1, base + 1});
+    int rfinal = last;                      // round in which the entry becomes final
+    if (E.mulr >= 0) rfinal = std::max({last, fin[E.mulr] + 1, base + 1});
+    if (n == 0) rfinal = std::max(rfinal, base + 1);
     // eager chunks: maximal runs of equal readiness round
     struct Chunk { int round, first, count; };
     std::vector<Chunk> chunks;
@@ -110,48 +109,67 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int zero_slo
       }
       merged.push_back(chunks[(size_t)k]);
     }
+    bool final_placed = false;
     for (int k = (int)merged.size() - 1; k >= 0; k--) {
       const Chunk& c = merged[(size_t)k];
-      bool div = (k == 0) && E.dv >= 0 && rdiv == c.round;
-      rounds[c.round].push_back({(int)e, c.first, c.count, div});
+      bool fin_here = (k == 0) && (rfinal == c.round);
+      rounds[c.round].push_back({(int)e, c.first, c.count, fin_here});
+      final_placed |= fin_here;
     }
-    if (E.dv >= 0 && (n == 0 || rdiv != last)) rounds[rdiv].push_back({(int)e, n, 0, true});
-    int f = E.dv >= 0 ? rdiv : last;
+    if (!final_placed && has_final_op) rounds[rfinal].push_back({(int)e, n, 0, true});
+    const int f = has_final_op ? rfinal : last;
     fin[E.tgt] = f;
+    if (E.rcp >= 0) fin[E.rcp] = f;
     phase_max = std::max(phase_max, f);
   }
 
   P.nrounds = (int)rounds.size();
   P.blk_n.assign((size_t)P.nrounds * P.nw, 0);
-  // per-wave linear record streams: stream[w] = rows of 64 uint4
+  // per-wave linear record streams: stream[w] = rows of 64 records of VM_REC_WORDS words
   std::vector<std::vector<uint32_t>> stream((size_t)P.nw);
-  const uint32_t z = (uint32_t)zero_slot;
-  const uint32_t pad_upd = z | (z << VM_IDX_BITS);
+  const uint32_t zoff = vm_off(zero_slot, 0);
+  auto idle_record = [&](std::vector<uint32_t>& out, uint32_t row_flags) {
+    out.push_back(zoff | VM_D0_FIRST);
+    out.push_back(zoff);
+    out.push_back(zoff | row_flags);
+    for (int q = 3; q < VM_REC_WORDS; q++) out.push_back(zoff);
+  };
   int ridx = 0;
   for (auto& kv : rounds) {
     std::vector<Item>& items = kv.second;
     auto nrec = [](const Item& it) { return std::max(1, (it.count + VM_UPD_PER_REC - 1) / VM_UPD_PER_REC); };
     std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return nrec(a) > nrec(b); });
     std::vector<int> lane = deal((int)items.size(), nt);
-    std::vector<std::vector<uint32_t>> prog((size_t)nt);     // 4 words per record
+    std::vector<std::vector<uint32_t>> prog((size_t)nt);     // VM_REC_WORDS words per record
     for (size_t k = 0; k < items.size(); k++) {
       const Item& it = items[k];
       const VmEntry& E = entries[(size_t)it.entry];
       std::vector<uint32_t>& w = prog[(size_t)lane[k]];
       const int nr = nrec(it);
       for (int r = 0; r < nr; r++) {
-        uint32_t flags = VM_ACTIVE;
-        if (r == 0) flags |= VM_FIRST;
-        if (r == nr - 1) flags |= VM_LAST | (it.div ? VM_DIV : 0u);
-        // the divisor operand is only meaningful in the record that divides; otherwise a harmless re-read of tgt
-        w.push_back(vm_word(E.tgt, (r == nr - 1 && it.div) ? E.dv : E.tgt, flags));
+        const bool last_rec = r == nr - 1;
+        uint32_t f0 = VM_D0_ACTIVE | (r == 0 ? VM_D0_FIRST : 0u) | (last_rec ? VM_D0_LAST : 0u);
+        uint32_t f1 = 0;
+        int aux = zero_slot;
+        if (last_rec && it.final) {
+          if (E.mulr >= 0) { f1 |= VM_D1_MULR; aux = E.mulr; }
+          if (E.rcp >= 0) {
+            if (E.mulr >= 0) throw std::logic_error("an entry cannot both scale and publish a reciprocal");
+            f1 |= VM_D1_RCP;
+            aux = E.rcp;
+          }
+        }
+        w.push_back(vm_off(E.tgt, f0));
+        w.push_back(vm_off(aux, f1));
         for (int u = 0; u < VM_UPD_PER_REC; u++) {
           int i = r * VM_UPD_PER_REC + u;
           if (i < it.count) {
-            const auto& up = E.upd[(size_t)(it.first + i)];
-            w.push_back(vm_word(up.first, up.second, 0));
+            const VmUpd& up = E.upd[(size_t)(it.first + i)];
+            w.push_back(vm_off(up.a, 0));
+            w.push_back(vm_off(up.r, 0));
+            w.push_back(vm_off(up.u, 0));
           } else {
-            w.push_back(pad_upd);
+            w.push_back(zoff); w.push_back(zoff); w.push_back(zoff);
           }
         }
       }
@@ -162,53 +180,50 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int zero_slo
     int crit = 0;
     for (int wv = 0; wv < P.nw; wv++) {
       size_t n = 0;
-      for (int l = 0; l < 64; l++) n = std::max(n, prog[(size_t)wv * 64 + l].size() / 4);
+      for (int l = 0; l < 64; l++) n = std::max(n, prog[(size_t)wv * 64 + l].size() / VM_REC_WORDS);
       if (n > 0xFFFF) throw std::logic_error("VM block too long");
       const size_t rows = std::max<size_t>(n, 1);       // a wave with no work still gets a null row carrying the round mark
       P.blk_n[(size_t)ridx * P.nw + wv] = (uint16_t)rows;
       for (size_t r = 0; r < rows; r++) {
-        const uint32_t row_flags = (r == rows - 1 ? VM_W1_EOR : 0u) | (n == 0 ? VM_W1_NULL : 0u);
+        uint32_t row_flags = (r == rows - 1 ? VM_D2_EOR : 0u) | (n == 0 ? VM_D2_NULL : 0u);
         for (int l = 0; l < 64; l++) {
           const auto& w = prog[(size_t)wv * 64 + l];
-          if (r * 4 < w.size()) {
-            stream[(size_t)wv].push_back(w[r * 4]);
-            stream[(size_t)wv].push_back(w[r * 4 + 1] | row_flags);
-            stream[(size_t)wv].push_back(w[r * 4 + 2]);
-            stream[(size_t)wv].push_back(w[r * 4 + 3]);
-          } else {   // idle record: loads the 0.0 cell, stores nothing
-            stream[(size_t)wv].push_back(vm_word(zero_slot, zero_slot, VM_FIRST));
-            stream[(size_t)wv].push_back(pad_upd | row_flags);
-            stream[(size_t)wv].push_back(pad_upd);
-            stream[(size_t)wv].push_back(pad_upd);
+          if (r * VM_REC_WORDS < w.size() && (w[r * VM_REC_WORDS + 1] & VM_D1_RCP)) row_flags |= VM_D2_RCP;
+        }
+        for (int l = 0; l < 64; l++) {
+          const auto& w = prog[(size_t)wv * 64 + l];
+          if (r * VM_REC_WORDS < w.size()) {
+            for (int q = 0; q < VM_REC_WORDS; q++) stream[(size_t)wv].push_back(w[r * VM_REC_WORDS + q] | (q == 2 ? row_flags : 0u));
+          } else {
+            idle_record(stream[(size_t)wv], row_flags);      // loads the 0.0 cell, stores nothing
           }
         }
       }
-      P.wave_rows += (int64_t)n;
-      crit = std::max(crit, (int)n);
+      P.wave_rows += (int64_t)rows;
+      crit = std::max(crit, (int)rows);
     }
     P.crit_rows += crit;
     ridx++;
   }
   P.wave_base.assign((size_t)P.nw, 0);
   for (int wv = 0; wv < P.nw; wv++) {
-    P.wave_base[(size_t)wv] = (uint32_t)(P.recs.size() / 256);
+    P.wave_base[(size_t)wv] = (uint32_t)(P.recs.size() / (64 * VM_REC_WORDS));
     P.recs.insert(P.recs.end(), stream[(size_t)wv].begin(), stream[(size_t)wv].end());
     // idle rows of slack so that the executor's look-ahead loads past the last record stay in bounds
     for (int rr = 0; rr < VM_LOOKAHEAD_ROWS; rr++)
-      for (int l = 0; l < 64; l++) {
-        P.recs.push_back(vm_word(zero_slot, zero_slot, VM_FIRST));
-        for (int q = 0; q < 3; q++) P.recs.push_back(pad_upd);
-      }
+      for (int l = 0; l < 64; l++) idle_record(P.recs, 0);
   }
   return P;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // KppDecomp_x (gas.f:6142-6176), entry view: slot p=(k,c) of row k gets  - L(k,j)*U(j,c)  for every j < min(k,c) with
-// both factors present, ascending j (the order in which the reference's kk/jj loops touch W(c)); entries left of
-// the diagonal are then divided by the pivot U(c,c) (reference: a = -W(j)/JVS(LU_DIAG(j)); W(j) = -a).
+// both factors present, ascending j (the order in which the reference's kk/jj loops touch W(c)).  The multiplier is
+// taken as W(k,j)*R(j) from the unscaled slot (see schedule.hpp); pivots publish R(k) = 1/U(k,k) when final; phase 1
+// scales the L slots in place so that the solves find L(k,j) where the reference leaves it.
 std::vector<VmEntry> lu_entries(const MechTables& m) {
   const int n = m.nvar;
+  const VmLayout lay{m.nnz, m.nvar};
   std::vector<VmEntry> out((size_t)m.nnz);
   std::vector<int> where((size_t)n, -1);    // column -> slot in the current row
   for (int k = 0; k < n; k++) {
@@ -217,42 +232,50 @@ std::vector<VmEntry> lu_entries(const MechTables& m) {
       VmEntry& E = out[(size_t)p];
       E.tgt = p;
       E.phase = 0;
-      int c = m.icol[p];
-      E.dv = c < k ? m.diag[(size_t)c] : -1;
+      if (m.icol[p] == k) E.rcp = lay.rdiag(k);
     }
     for (int pl = m.crow[k]; pl < m.diag[k]; pl++) {
       int j = m.icol[pl];
       for (int pu = m.diag[j] + 1; pu < m.crow[j + 1]; pu++) {
         int t = where[(size_t)m.icol[pu]];
         if (t < 0) throw std::logic_error("LU pattern is not closed under fill-in");
-        out[(size_t)t].upd.emplace_back(pl, pu);
+        out[(size_t)t].upd.push_back({pl, lay.rdiag(j), pu});
       }
     }
     for (int p = m.crow[k]; p < m.crow[k + 1]; p++) where[(size_t)m.icol[p]] = -1;
   }
+  for (int k = 0; k < n; k++)
+    for (int p = m.crow[k]; p < m.diag[k]; p++) {
+      VmEntry E;
+      E.tgt = p;
+      E.phase = 1;
+      E.mulr = lay.rdiag(m.icol[p]);
+      out.push_back(std::move(E));
+    }
   return out;
 }
 
-// KppSolve_x (gas.f:6206-6608): phase 0 forward sweep with unit L, phase 1 backward sweep with division by U(i,i).
-// X lives behind Ghimj in VM memory: M[nnz + i].
+// KppSolve_x (gas.f:6206-6608) as one program: phase 0 forward sweep with unit L, phase 1 backward sweep.
+// X lives behind Ghimj in VM memory.  (Kept for tests; the kernel runs the head/tail split below.)
 std::vector<VmEntry> solve_entries(const MechTables& m) {
-  const int n = m.nvar, xo = m.nnz;
+  const int n = m.nvar;
+  const VmLayout lay{m.nnz, m.nvar};
   std::vector<VmEntry> out;
   for (int i = 0; i < n; i++) {
     if (m.diag[i] == m.crow[i]) continue;
     VmEntry E;
-    E.tgt = xo + i;
+    E.tgt = lay.xs(i);
     E.phase = 0;
-    for (int p = m.crow[i]; p < m.diag[i]; p++) E.upd.emplace_back(p, xo + m.icol[p]);
+    for (int p = m.crow[i]; p < m.diag[i]; p++) E.upd.push_back({p, lay.one(), lay.xs(m.icol[p])});
     out.push_back(std::move(E));
   }
   for (int i = n - 1; i >= 0; i--) {
     VmEntry E;
-    E.tgt = xo + i;
+    E.tgt = lay.xs(i);
     E.phase = 1;
     E.keep_order = false;        // see schedule.hpp: readiness order instead of the reference's ascending columns
-    E.dv = m.diag[i];
-    for (int p = m.diag[i] + 1; p < m.crow[i + 1]; p++) E.upd.emplace_back(p, xo + m.icol[p]);
+    E.mulr = lay.rdiag(i);
+    for (int p = m.diag[i] + 1; p < m.crow[i + 1]; p++) E.upd.push_back({p, lay.one(), lay.xs(m.icol[p])});
     out.push_back(std::move(E));
   }
   return out;
@@ -261,14 +284,15 @@ std::vector<VmEntry> solve_entries(const MechTables& m) {
 // Forward sweep split at row h: head rows completely, tail rows only their head-column terms (the leading terms of the
 // reference's ascending-column order); the tail chain then subtracts the tail-column terms, again ascending.
 std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, int h) {
-  const int n = m.nvar, xo = m.nnz;
+  const int n = m.nvar;
+  const VmLayout lay{m.nnz, m.nvar};
   std::vector<VmEntry> out;
   for (int i = 0; i < n; i++) {
     VmEntry E;
-    E.tgt = xo + i;
+    E.tgt = lay.xs(i);
     E.phase = 0;
     for (int p = m.crow[i]; p < m.diag[i]; p++)
-      if (m.icol[p] < h) E.upd.emplace_back(p, xo + m.icol[p]);
+      if (m.icol[p] < h) E.upd.push_back({p, lay.one(), lay.xs(m.icol[p])});
     if (!E.upd.empty()) out.push_back(std::move(E));
   }
   return out;
@@ -276,23 +300,23 @@ std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, int h) {
 
 // Backward sweep of the head rows, the tail part of X being final already.
 std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, int h) {
-  const int xo = m.nnz;
+  const VmLayout lay{m.nnz, m.nvar};
   std::vector<VmEntry> out;
   for (int i = h - 1; i >= 0; i--) {
     VmEntry E;
-    E.tgt = xo + i;
+    E.tgt = lay.xs(i);
     E.phase = 0;
     E.keep_order = false;
-    E.dv = m.diag[i];
-    for (int p = m.diag[i] + 1; p < m.crow[i + 1]; p++) E.upd.emplace_back(p, xo + m.icol[p]);
+    E.mulr = lay.rdiag(i);
+    for (int p = m.diag[i] + 1; p < m.crow[i + 1]; p++) E.upd.push_back({p, lay.one(), lay.xs(m.icol[p])});
     out.push_back(std::move(E));
   }
   return out;
 }
 
-TailSolve build_tail_solve(const MechTables& m, int zero_slot) {
+TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay) {
   TailSolve T;
-  const int n = m.nvar;
+  const int n = m.nvar, zero_slot = lay.zero();
   T.regs = n > 128 + 64 ? 2 : 1;           // 128-row tail where the mechanism is big enough to leave a head
   T.m = 64 * T.regs;
   if (T.m > n) throw std::invalid_argument("mechanism smaller than one wave");
@@ -376,7 +400,7 @@ GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, doub
 // ---------------------------------------------------------------------------------------------------------------
 KernelSchedule build_kernel_schedule(const MechTables& m, int nt) {
   if (nt % 64 != 0 || nt <= 0 || nt > 1024) throw std::invalid_argument("nt must be a multiple of 64 in (0,1024]");
-  if (m.nnz + m.nvar + 1 > (int)VM_IDX_MASK + 1) throw std::invalid_argument("mechanism too large for the LDS VM index space");
+  if ((m.nnz + 2 * m.nvar + 2) * 8 > 160 * 1024) throw std::invalid_argument("mechanism too large for the LDS VM");
   if (m.nx() > 0xFFFF || m.nb >= 0xFFFF || m.nreact > 0xFFFF) throw std::invalid_argument("mechanism too large");
   KernelSchedule S;
   S.nt = nt;
@@ -451,12 +475,12 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt) {
   S.diag_pos.assign((size_t)S.spt * nt, POS_NONE);
   for (int s = 0; s < m.nvar; s++) S.diag_pos[(size_t)s] = (uint16_t)m.diag[(size_t)s];
 
-  const int msize = m.nnz + m.nvar + 1, zero_slot = m.nnz + m.nvar;     // M = [Ghimj | XS | 0.0]
-  S.lu = build_vm_program(lu_entries(m), msize, zero_slot, nt);
-  S.solve = build_vm_program(solve_entries(m), msize, zero_slot, nt);
-  S.tail = build_tail_solve(m, zero_slot);
-  S.solve_head_fwd = build_vm_program(solve_head_fwd_entries(m, S.tail.h), msize, zero_slot, nt);
-  S.solve_head_bwd = build_vm_program(solve_head_bwd_entries(m, S.tail.h), msize, zero_slot, nt);
+  const VmLayout lay{m.nnz, m.nvar};                                    // M = [Ghimj | XS | 0.0 | 1.0 | R]
+  S.lu = build_vm_program(lu_entries(m), lay, nt);
+  S.solve = build_vm_program(solve_entries(m), lay, nt);
+  S.tail = build_tail_solve(m, lay);
+  S.solve_head_fwd = build_vm_program(solve_head_fwd_entries(m, S.tail.h), lay, nt);
+  S.solve_head_bwd = build_vm_program(solve_head_bwd_entries(m, S.tail.h), lay, nt);
   return S;
 }
 

@@ -3,25 +3,30 @@
 //
 // Two tiny "machines" run inside the kernel, both over LDS-resident data:
 //
-//  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) | 0.0 ].  A program is a list of rounds separated
-//    by workgroup barriers; inside a round every lane walks its own list of fixed 16-byte RECORDS:
-//        w0 = tgt | dv<<14 | FIRST | LAST | DIV | ACTIVE        w1..w3 = i1 | i2<<14   (three update slots)
-//        FIRST : acc = M[tgt]                 (else the lane's acc carries over from its previous record)
-//        each update slot: acc = acc - M[i1]*M[i2]   (one multiply, one subtract, no contraction; an unused slot
-//                                                     points both indices at the 0.0 cell: acc - 0*0 = acc exactly)
-//        LAST  : M[tgt] = DIV ? acc / M[dv] : acc     (only if ACTIVE; idle padding records are not)
-//    A wave's records form one linear stream over all rounds (the last row of a round carries an end-of-round mark, a
-//    wave without work in a round gets one null row), so table loads run ahead of use whatever the round structure
-//    and nothing but the records themselves is read from memory.
-//    It expresses the sparse LU (KppDecomp_x, gas.f:6142: entry (k,c) receives  -L(k,j)*U(j,c)  for ascending j,
-//    L entries are divided by the pivot) and both triangular sweeps of KppSolve_x (gas.f:6206) with the reference's
-//    per-entry operation ORDER preserved where that is free: an entry's updates are cut into chunks, a chunk is
-//    issued no earlier than the first round in which its operands are final, chunks of one entry stay in ascending-j
-//    order.  That cuts the LU's dependency depth from ~9600 serial updates (tot) to ~165 rounds.  Chunks that are not
-//    on the critical path are merged forward (issued later, together with the entry's next chunk) to save record
-//    headers.  The backward sweep is the exception to order-keeping: the reference subtracts U(i,c)*X(c) for ASCENDING
-//    c while the X(c) become known in DESCENDING c, which would serialise whole dot products; there the updates are
-//    applied in readiness order (keep_order = false) — same terms, different summation order, round-off level.
+//  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) | 0.0 | 1.0 | R (nvar) ], R(k) = 1/U(k,k).  A program
+//    is a list of rounds separated by workgroup barriers; inside a round every lane walks its own list of fixed
+//    32-byte RECORDS whose fields are LDS byte offsets (flags ride in the three alignment bits):
+//        d0 = tgt | FIRST | LAST | ACTIVE      d1 = aux | MULR | RCP      d2..d4 = a1,r1,u1   d5..d7 = a2,r2,u2
+//        FIRST : acc = M[tgt]                  (else the lane's acc carries over from its previous record)
+//        each update slot: acc = acc - (M[a]*M[r])*M[u]     (three roundings, no contraction; an unused slot points all
+//                                                           three at the 0.0 cell: acc - (0*0)*0 = acc exactly)
+//        LAST  : res = MULR ? acc*M[aux] : acc;  M[tgt] = res;  RCP: M[aux] = 1/res      (only if ACTIVE)
+//    d2 also carries the row marks (end-of-round, null row).  A wave's records form one linear stream over all rounds,
+//    so table loads run ahead of use whatever the round structure and nothing else is read from memory.
+//
+//    Sparse LU (KppDecomp_x, gas.f:6142): entry (k,c) receives  -L(k,j)*U(j,c)  for ascending j.  The reference forms
+//    the multiplier L(k,j) = W(j)/U(j,j) first; here an update reads the UNSCALED W(j), the pivot's reciprocal R(j) and
+//    U(j,c) and forms (W(j)*R(j))*U(j,c): one round per pivot instead of two (no separate multiplier round on the
+//    dependency chain), at the price of a multiplier that can differ from the quotient in the last bit.  Pivots store
+//    their reciprocal when they become final (RCP, one IEEE division per pivot); the L entries are scaled in place by
+//    one last round.  Per-entry update ORDER is the reference's (ascending j): an entry's updates are cut into
+//    chunks, a chunk is issued no earlier than the first round in which its operands are final, chunks of one entry
+//    stay in order; chunks off the critical path are merged forward to save record headers.  That cuts the LU's
+//    dependency depth from ~9600 serial updates (tot) to ~100 rounds.
+//    Triangular sweeps of KppSolve_x (gas.f:6206): updates are (L(i,j), 1.0, X(j)); the backward sweep multiplies by
+//    R(i) instead of dividing and applies its terms in readiness order (keep_order = false: the reference subtracts
+//    U(i,c)*X(c) for ASCENDING c while the X(c) become known in DESCENDING c).  Same terms, round-off level changes;
+//    the CPU test-suite measures what such re-associations do to the reference algorithm itself.
 //
 //  * the gather-sum machine ("gsum"): out = c0*src[i0] + c1*src[i1] + ... left to right, coefficient as float
 //    (every stoichiometric coefficient in the reference is a default-REAL literal or a small integer),
@@ -36,16 +41,26 @@
 
 namespace mistra {
 
-constexpr uint32_t VM_IDX_BITS = 14;
-constexpr uint32_t VM_IDX_MASK = (1u << VM_IDX_BITS) - 1;
-constexpr uint32_t VM_FIRST = 1u << 28;
-constexpr uint32_t VM_LAST = 1u << 29;
-constexpr uint32_t VM_DIV = 1u << 30;
-constexpr uint32_t VM_ACTIVE = 1u << 31;
-constexpr uint32_t VM_W1_EOR = 1u << 31;    // on w1 of every lane of a row: last row of this round for the wave -> barrier
-constexpr uint32_t VM_W1_NULL = 1u << 30;   // on w1: the row carries no work (a wave with nothing to do in a round)
-constexpr int VM_UPD_PER_REC = 3;
-constexpr int VM_LOOKAHEAD_ROWS = 16;    // >= 2x the kernel's table look-ahead depth (ros3_kernel.hip: kVmDepth = 8, kGsDepth = 4)
+// record flags (low three bits of an 8-byte-aligned LDS byte offset)
+constexpr uint32_t VM_D0_FIRST = 1u, VM_D0_LAST = 2u, VM_D0_ACTIVE = 4u;
+constexpr uint32_t VM_D1_MULR = 1u, VM_D1_RCP = 2u;
+constexpr uint32_t VM_D2_EOR = 1u;     // on d2 of every lane of a row: last row of this round for the wave -> barrier
+constexpr uint32_t VM_D2_NULL = 2u;    // on d2: the row carries no work (a wave with nothing to do in a round)
+constexpr uint32_t VM_D2_RCP = 4u;     // on d2 of every lane of a row: some lane of the row publishes a reciprocal
+constexpr uint32_t VM_OFF_MASK = ~7u;
+constexpr int VM_REC_WORDS = 8;
+constexpr int VM_UPD_PER_REC = 2;
+constexpr int VM_LOOKAHEAD_ROWS = 16;    // >= 2x the kernel's table look-ahead depth (ros3_kernel.hip)
+
+// VM memory map for a mechanism with nnz LU slots and nvar species
+struct VmLayout {
+  int nnz = 0, nvar = 0;
+  int xs(int i = 0) const { return nnz + i; }
+  int zero() const { return nnz + nvar; }
+  int one() const { return nnz + nvar + 1; }
+  int rdiag(int k = 0) const { return nnz + nvar + 2 + k; }
+  int size() const { return nnz + 2 * nvar + 2; }
+};
 
 constexpr uint32_t GS_FIRST = 1u << 16;
 constexpr uint32_t GS_NOP = 1u << 17;
@@ -53,19 +68,22 @@ constexpr uint32_t GS_NOP = 1u << 17;
 constexpr uint16_t POS_DIAG = 0x8000;   // flag on a Ghimj slot number: the slot is a diagonal
 constexpr uint16_t POS_NONE = 0xFFFF;
 
+struct VmUpd { int a, r, u; };                  // acc -= (M[a]*M[r])*M[u]
+
 struct VmEntry {
   int tgt = 0;                                  // M index updated
-  int dv = -1;                                  // M index of the divisor applied after the last update, -1 = none
+  int mulr = -1;                                // M index of a factor applied after the last update, -1 = none
+  int rcp = -1;                                 // M index that receives 1/result when the entry is final, -1 = none
   int phase = 0;                                // phases run strictly one after the other
   bool keep_order = true;                       // false: updates may be applied in the order their operands get ready
-  std::vector<std::pair<int, int>> upd;         // (i1, i2) pairs, applied in this order (if keep_order)
+  std::vector<VmUpd> upd;                       // applied in this order (if keep_order)
 };
 
 struct VmProgram {
   int nt = 0, nw = 0, nrounds = 0, zero_slot = 0;
   std::vector<uint32_t> wave_base;              // [nw]  first record row of each wave's linear stream
   std::vector<uint16_t> blk_n;                  // [nrounds*nw] record rows of (round, wave), null rows included (census / emulator)
-  std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*4 + k]   one uint4 per lane and row
+  std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*8 + k]   two uint4 per lane and row
   // census
   int64_t n_updates = 0, n_items = 0, n_records = 0, wave_rows = 0, crit_rows = 0;
 };
@@ -112,12 +130,12 @@ struct KernelSchedule {
   TailSolve tail;
 };
 
-VmProgram build_vm_program(std::vector<VmEntry> entries, int msize, int zero_slot, int nt, int merge_budget = 6);
+VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 4);
 std::vector<VmEntry> lu_entries(const MechTables& m);
 std::vector<VmEntry> solve_entries(const MechTables& m);
 std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, int h);
 std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, int h);
-TailSolve build_tail_solve(const MechTables& m, int zero_slot);
+TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay);
 GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,
                                const std::vector<int>& slot_of_output, int nq, int nt);
 KernelSchedule build_kernel_schedule(const MechTables& m, int nt);

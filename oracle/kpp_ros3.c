@@ -87,6 +87,7 @@ int kpp_mech_dim(const kpp_mech *m, int which) {
  * under legal re-associations (what a different compiler or summation order does to the reference itself):
  *   bit 0: backward sweep of KppSolve subtracts its terms in DESCENDING column order (the kernel's readiness order)
  *   bit 1: a*b+c contracted to fma() in KppDecomp, KppSolve and the stoichiometric sums (-ffp-contract=fast on FMA hardware)
+ *   bit 2: quotients by a pivot formed as a product with its reciprocal (KppDecomp multipliers, KppSolve backward sweep)
  * Default 0 = the pinned, bit-exact restatement. */
 static int kpp_variant = 0;
 void kpp_set_variant(int v) { kpp_variant = v; }
@@ -142,7 +143,7 @@ int kpp_decomp(const kpp_mech *m, double *JVS, double *W) {
     for (int kk = crow[k]; kk < crow[k + 1]; kk++) W[icol[kk]] = JVS[kk];
     for (int kk = crow[k]; kk < diag[k]; kk++) {
       int j = icol[kk];
-      double a = -W[j] / JVS[diag[j]];
+      double a = (kpp_variant & 4) ? -(W[j] * (1.0 / JVS[diag[j]])) : -W[j] / JVS[diag[j]];
       W[j] = -a;
       if (kpp_variant & 2)
         for (int jj = diag[j] + 1; jj < crow[j + 1]; jj++) W[icol[jj]] = fma(a, JVS[jj], W[icol[jj]]);
@@ -168,7 +169,7 @@ void kpp_solve(const kpp_mech *m, const double *JVS, double *X) {
       double acc = X[i];
       if (desc) for (int k = crow[i + 1] - 1; k > diag[i]; k--) acc = use_fma ? fma(-JVS[k], X[icol[k]], acc) : acc - JVS[k] * X[icol[k]];
       else for (int k = diag[i] + 1; k < crow[i + 1]; k++) acc = use_fma ? fma(-JVS[k], X[icol[k]], acc) : acc - JVS[k] * X[icol[k]];
-      X[i] = acc / JVS[diag[i]];
+      X[i] = (kpp_variant & 4) ? acc * (1.0 / JVS[diag[i]]) : acc / JVS[diag[i]];
     }
     return;
   }

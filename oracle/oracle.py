@@ -60,7 +60,8 @@ def _oracle_lib():
 
 
 def set_variant(v):
-    """0 = pinned restatement; 1 = descending backward sweep; 2 = fma-contracted (sensitivity studies only)"""
+    """0 = pinned restatement; bit 0 descending backward sweep; bit 1 fma-contracted; bit 2 reciprocal instead of
+    division by pivots (sensitivity studies only)"""
     _oracle_lib().kpp_set_variant(int(v))
 
 

@@ -18,6 +18,12 @@ struct Emu {
   MechTables m;
   KernelSchedule s;
   std::string text;
+  VmLayout lay() const { return VmLayout{m.nnz, m.nvar}; }
+  std::vector<double> fresh_m() const {
+    std::vector<double> M((size_t)lay().size(), 0.0);
+    M[(size_t)lay().one()] = 1.0;
+    return M;
+  }
 };
 
 static int run_vm(const VmProgram& P, std::vector<double>& M) {
@@ -25,7 +31,6 @@ static int run_vm(const VmProgram& P, std::vector<double>& M) {
   std::vector<int> writer(M.size());
   std::vector<uint32_t> row_of_wave((size_t)P.nw, 0);
   std::vector<double> acc_of_lane((size_t)nt, 0.0);
-  M[(size_t)P.zero_slot] = 0.0;
   for (int r = 0; r < P.nrounds; r++) {
     std::fill(writer.begin(), writer.end(), -1);
     std::vector<std::pair<int, int>> reads;   // (slot, lane)
@@ -39,26 +44,35 @@ static int run_vm(const VmProgram& P, std::vector<double>& M) {
         if (lane >= nt) break;
         double acc = acc_of_lane[(size_t)lane];
         for (int ridx = 0; ridx < n; ridx++) {
-          const uint32_t* rec = &P.recs[((base + ridx) * 64 + l) * 4];
-          const uint32_t w0 = rec[0];
-          if ((rec[1] & VM_W1_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
-          if (rec[1] & VM_W1_NULL) continue;
-          const int tgt = w0 & VM_IDX_MASK, dvi = (w0 >> VM_IDX_BITS) & VM_IDX_MASK;
-          auto rd = [&](int i) {
+          const uint32_t* rec = &P.recs[((base + ridx) * 64 + l) * VM_REC_WORDS];
+          if ((rec[2] & VM_D2_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
+          if (rec[2] & VM_D2_NULL) continue;
+          auto rd = [&](uint32_t off) {
+            const int i = (int)((off & VM_OFF_MASK) >> 3);
             reads.emplace_back(i, lane);
-            return (writer[i] == lane) ? M[i] : snapshot[i];
+            return (writer[i] == lane) ? M[(size_t)i] : snapshot[(size_t)i];
           };
-          const double x0 = rd(tgt), d = rd(dvi);
-          if (w0 & VM_FIRST) acc = x0;
-          for (int u = 1; u <= VM_UPD_PER_REC; u++) {
-            const int i1 = rec[u] & VM_IDX_MASK, i2 = (rec[u] >> VM_IDX_BITS) & VM_IDX_MASK;
-            const double p = rd(i1) * rd(i2);
+          const int tgt = (int)((rec[0] & VM_OFF_MASK) >> 3), aux = (int)((rec[1] & VM_OFF_MASK) >> 3);
+          const double x0 = rd(rec[0]);
+          if (rec[0] & VM_D0_FIRST) acc = x0;
+          for (int u = 0; u < VM_UPD_PER_REC; u++) {
+            const double av = rd(rec[2 + 3 * u]), rv = rd(rec[3 + 3 * u]), uv = rd(rec[4 + 3 * u]);
+            const double mlt = av * rv;
+            const double p = mlt * uv;
             acc = acc - p;
           }
-          if ((w0 & VM_LAST) && (w0 & VM_ACTIVE)) {
-            M[tgt] = (w0 & VM_DIV) ? acc / d : acc;
+          if ((rec[0] & VM_D0_LAST) && (rec[0] & VM_D0_ACTIVE)) {
+            double res = acc;
+            if (rec[1] & VM_D1_MULR) res = acc * rd(rec[1]);
+            M[(size_t)tgt] = res;
             if (writer[tgt] >= 0 && writer[tgt] != lane) return -2;   // two lanes write one slot in a round
             writer[tgt] = lane;
+            if (rec[1] & VM_D1_RCP) {
+              if (!(rec[2] & VM_D2_RCP)) return -6;   // row mark missing
+              M[(size_t)aux] = 1.0 / res;
+              if (writer[aux] >= 0 && writer[aux] != lane) return -2;
+              writer[aux] = lane;
+            }
           }
         }
         acc_of_lane[(size_t)lane] = acc;
@@ -66,7 +80,6 @@ static int run_vm(const VmProgram& P, std::vector<double>& M) {
     }
     for (auto& rd : reads)
       if (writer[rd.first] >= 0 && writer[rd.first] != rd.second) return -3;   // read of a slot another lane writes this round
-    if (M[(size_t)P.zero_slot] != 0.0) return -4;
   }
   return 0;
 }
@@ -93,48 +106,10 @@ static void run_gsum(const GsumProgram& P, const std::vector<double>& src, std::
     }
 }
 
-extern "C" {
-
-void* emu_create(const char* mech_path, int nt) {
-  Emu* e = new Emu;
-  std::string err;
-  if (!e->m.load(mech_path, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); delete e; return nullptr; }
-  try {
-    e->s = build_kernel_schedule(e->m, nt);
-  } catch (const std::exception& ex) {
-    std::fprintf(stderr, "schedule: %s\n", ex.what());
-    delete e;
-    return nullptr;
-  }
-  e->text = describe(e->s);
-  return e;
-}
-void emu_destroy(void* h) { delete (Emu*)h; }
-const char* emu_describe(void* h) { return ((Emu*)h)->text.c_str(); }
-
-// KppDecomp on G (nnz doubles, in place) through the LU program.  Returns 0 or a negative hazard code.
-int emu_lu(void* h, double* G) {
-  Emu* e = (Emu*)h;
-  std::vector<double> M((size_t)e->m.nnz + e->m.nvar + 1, 0.0);
-  std::memcpy(M.data(), G, sizeof(double) * e->m.nnz);
-  int rc = run_vm(e->s.lu, M);
-  std::memcpy(G, M.data(), sizeof(double) * e->m.nnz);
-  return rc;
-}
-
-int emu_solve(void* h, const double* LU, double* X) {
-  Emu* e = (Emu*)h;
-  std::vector<double> M((size_t)e->m.nnz + e->m.nvar + 1, 0.0);
-  std::memcpy(M.data(), LU, sizeof(double) * e->m.nnz);
-  std::memcpy(M.data() + e->m.nnz, X, sizeof(double) * e->m.nvar);
-  int rc = run_vm(e->s.solve, M);
-  std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
-  return rc;
-}
-
 // The kernel's solve: head forward (VM) -> tail chain forward/backward (one wave, registers) -> head backward (VM).
-// The tail loops below mirror tail_forward/tail_backward of ros3_kernel.hip statement by statement.
-static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, int nnz) {
+// The tail loops below mirror tail_solve of ros3_kernel.hip statement by statement.
+static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, const VmLayout& lay) {
+  const int nnz = lay.nnz;
   int rc = run_vm(s.solve_head_fwd, M);
   if (rc) return rc;
   const TailSolve& T = s.tail;
@@ -143,7 +118,7 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, int 
   for (int i = 0; i < m; i++) {
     x[(size_t)i] = M[(size_t)nnz + T.h + i];
     dg[(size_t)i] = M[T.diag[(size_t)i]];
-    rd[(size_t)i] = 1.0 / dg[(size_t)i];
+    rd[(size_t)i] = M[(size_t)lay.rdiag(T.h + i)];        // R(k) = 1/U(k,k), published by the LU program
   }
   auto idx = [&](const std::vector<uint32_t>& tab, int pos, int lane, int r) {
     uint32_t w = tab[((size_t)(pos / 4) * 64 + lane) * 4 + pos % 4];
@@ -175,21 +150,66 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, int 
   return run_vm(s.solve_head_bwd, M);
 }
 
+extern "C" {
+
+void* emu_create(const char* mech_path, int nt) {
+  Emu* e = new Emu;
+  std::string err;
+  if (!e->m.load(mech_path, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); delete e; return nullptr; }
+  try {
+    e->s = build_kernel_schedule(e->m, nt);
+  } catch (const std::exception& ex) {
+    std::fprintf(stderr, "schedule: %s\n", ex.what());
+    delete e;
+    return nullptr;
+  }
+  e->text = describe(e->s);
+  return e;
+}
+void emu_destroy(void* h) { delete (Emu*)h; }
+const char* emu_describe(void* h) { return ((Emu*)h)->text.c_str(); }
+
+// KppDecomp on G (nnz doubles, in place) through the LU program; R (nvar) receives the pivot reciprocals the program
+// publishes.  Returns 0 or a negative hazard code.
+int emu_lu(void* h, double* G, double* R) {
+  Emu* e = (Emu*)h;
+  std::vector<double> M = e->fresh_m();
+  std::memcpy(M.data(), G, sizeof(double) * e->m.nnz);
+  int rc = run_vm(e->s.lu, M);
+  std::memcpy(G, M.data(), sizeof(double) * e->m.nnz);
+  if (R) std::memcpy(R, M.data() + e->lay().rdiag(), sizeof(double) * e->m.nvar);
+  return rc;
+}
+
+static std::vector<double> solve_memory(const Emu* e, const double* LU, const double* X) {
+  std::vector<double> M = e->fresh_m();
+  std::memcpy(M.data(), LU, sizeof(double) * e->m.nnz);
+  std::memcpy(M.data() + e->m.nnz, X, sizeof(double) * e->m.nvar);
+  for (int k = 0; k < e->m.nvar; k++) M[(size_t)e->lay().rdiag(k)] = 1.0 / LU[e->m.diag[(size_t)k]];
+  return M;
+}
+
+int emu_solve(void* h, const double* LU, double* X) {
+  Emu* e = (Emu*)h;
+  std::vector<double> M = solve_memory(e, LU, X);
+  int rc = run_vm(e->s.solve, M);
+  std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
+  return rc;
+}
+
+int emu_solve_split(void* h, const double* LU, double* X) {
+  Emu* e = (Emu*)h;
+  std::vector<double> M = solve_memory(e, LU, X);
+  int rc = run_solve_split(e->s, M, e->lay());
+  std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
+  return rc;
+}
+
 static void make_x(const Emu* e, const double* V, const double* F, std::vector<double>& X) {
   X.resize((size_t)e->m.nx());
   std::memcpy(X.data(), V, sizeof(double) * e->m.nvar);
   std::memcpy(X.data() + e->m.nvar, F, sizeof(double) * e->m.nfix);
   std::memcpy(X.data() + e->m.nspec(), e->m.consts.data(), sizeof(double) * e->m.nconst);
-}
-
-int emu_solve_split(void* h, const double* LU, double* X) {
-  Emu* e = (Emu*)h;
-  std::vector<double> M((size_t)e->m.nnz + e->m.nvar + 1, 0.0);
-  std::memcpy(M.data(), LU, sizeof(double) * e->m.nnz);
-  std::memcpy(M.data() + e->m.nnz, X, sizeof(double) * e->m.nvar);
-  int rc = run_solve_split(e->s, M, e->m.nnz);
-  std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
-  return rc;
 }
 
 void emu_fun(void* h, const double* V, const double* F, const double* RCT, double* Vdot) {

@@ -1,7 +1,7 @@
 """Host logic: the schedule compiler (mistra_amd/csrc/schedule.cpp) run through the TEST-ONLY emulator
-(tests/emu/schedule_emu.cpp) against the oracle.  Fun, Jac, matrix preparation and the LU keep the reference's
-operation order, so they must be bit-exact; the solve applies the backward-sweep updates in readiness order and is
-checked to round-off."""
+(tests/emu/schedule_emu.cpp) against the oracle.  Fun, Jac and the matrix preparation keep the reference's operation
+order and must be bit-exact; the LU forms its multipliers with the pivot's reciprocal and the solve applies the
+backward-sweep terms in readiness order: both are checked to round-off."""
 import ctypes as C
 import os
 import subprocess
@@ -25,7 +25,7 @@ def emu():
     lib.emu_create.argtypes = [C.c_char_p, C.c_int]
     lib.emu_describe.restype = C.c_char_p
     lib.emu_describe.argtypes = [C.c_void_p]
-    lib.emu_lu.argtypes = [C.c_void_p, dp]
+    lib.emu_lu.argtypes = [C.c_void_p, dp, dp]
     lib.emu_solve.argtypes = [C.c_void_p, dp, dp]
     lib.emu_solve_split.argtypes = [C.c_void_p, dp, dp]
     lib.emu_fun.argtypes = [C.c_void_p, dp, dp, dp, dp]
@@ -64,17 +64,24 @@ def test_programs_match_oracle(emu, mech, nt, golden, oracles):
         assert np.array_equal(G, G_ref) and np.array_equal(np.signbit(G), np.signbit(G_ref))
         lu_ref, ier = o.decomp(G_ref)
         assert ier == 0
-        assert emu.emu_lu(h, P(G)) == 0, "hazard inside an LU round"
-        assert np.array_equal(G, lu_ref)
+        R = np.empty(o.nvar)
+        assert emu.emu_lu(h, P(G), P(R)) == 0, "hazard inside an LU round"
+        # multipliers are formed as W*R(j) instead of W/U(j,j) (schedule.hpp): last-bit differences that the elimination
+        # carries along; entries are compared against the scale of their row
+        rowmax = np.array([np.abs(lu_ref[t.crow[k]:t.crow[k + 1]]).max() for k in range(o.nvar)])
+        scale = np.repeat(rowmax, np.diff(t.crow))
+        print(mech, nt, "LU max |diff|/rowmax %.2e" % (np.abs(G - lu_ref) / scale).max())
+        assert (np.abs(G - lu_ref) / scale).max() <= 1e-10
+        assert np.allclose(R, 1.0 / lu_ref[t.diag], rtol=1e-9, atol=0)
         b = rng.normal(size=o.nvar) * np.abs(o.fun(V, F, K)).max()
         x = b.copy()
         assert emu.emu_solve(h, P(lu_ref), P(x)) == 0, "hazard inside a solve round"
         x_ref = o.solve(lu_ref, b)
-        assert np.abs(x - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
+        assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
         # the form the kernel runs: head rows through the VM, the tail chain by one wave in registers
         x2 = b.copy()
         assert emu.emu_solve_split(h, P(lu_ref), P(x2)) == 0, "hazard inside a head round"
-        assert np.abs(x2 - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
+        assert np.abs(x2 - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
 
 
 def test_round_structure_tot(emu):
@@ -83,6 +90,6 @@ def test_round_structure_tot(emu):
     crit = np.zeros(512, np.int32)
     tot = np.zeros(512, np.int32)
     n_lu = emu.emu_round_profile(h, 0, crit.ctypes.data_as(ip), tot.ctypes.data_as(ip), 512)
-    assert 100 < n_lu < 200 and crit[:n_lu].sum() < 1500
+    assert 60 < n_lu < 140 and crit[:n_lu].sum() < 1500
     n_sv = emu.emu_round_profile(h, 1, crit.ctypes.data_as(ip), tot.ctypes.data_as(ip), 512)
     assert 100 < n_sv < 200 and crit[:n_sv].sum() < 800
