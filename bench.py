@@ -46,7 +46,18 @@ def _cpu_worker(job):
     return time.perf_counter() - t0, nstp
 
 
-def cpu_baseline(mech, budget_s=12.0):
+def measured_traffic(mech, ncell):
+    """HBM bytes per launch from the most recent committed PMC pass (profiles/rNN_traffic.json), scaled to this launch's
+    cell count; None when no pass exists for the mechanism.  bench.py cannot collect PMC counters itself."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")), reverse=True):
+        d = json.load(open(path))
+        if d.get("mech") == mech:
+            return d["bytes_per_launch"] * ncell / d["cells"], os.path.basename(path)
+    return None, None
+
+
+def cpu_baseline(mech, budget_s=15.0):
     import multiprocessing as mp
     import numpy as np
     import torch
@@ -60,7 +71,7 @@ def cpu_baseline(mech, budget_s=12.0):
     var, fix, rconst = (x.numpy() for x in make_batch(mech, 0, 4, "cpu"))
     dt, _ = _cpu_worker((kind, mech, var, fix, rconst))
     per_cell = dt / 4
-    ncell = int(max(cores, min(4096, budget_s * cores / max(per_cell, 1e-6))))
+    ncell = int(max(cores, min(32768, budget_s * cores / max(per_cell, 1e-6))))
     ncell -= ncell % cores
     var, fix, rconst = (x.numpy() for x in make_batch(mech, 0, ncell, "cpu"))
     share = ncell // cores
@@ -154,6 +165,7 @@ def main():
         steps_per_cell = nstp_total / cells_done
         achieved = ncell * ALG_BYTES[args.mech] / (kernel_ms * 1e-3) / 1e9
         flops = ncell * steps_per_cell * FLOP_PER_STEP[args.mech] / (kernel_ms * 1e-3)
+        traffic, traffic_src = measured_traffic(args.mech, ncell)
         line = {
             "metric": "chemistry-timesteps/sec (%s mechanism)" % args.mech, "value": value, "unit": "chemistry-timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
@@ -163,7 +175,7 @@ def main():
                        "cells_per_gpu": args.cells_per_gpu, "mean_internal_steps_per_cell": steps_per_cell,
                        "failed_cells": int(nfail), "parallelism": "cells sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "ros3_integrate_kernel", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "ros3_integrate_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_cell": ALG_BYTES[args.mech],
                          "fp64_tflops": flops / 1e12, "fp64_frac_of_vector_peak": flops / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
         }
