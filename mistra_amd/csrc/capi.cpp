@@ -310,6 +310,10 @@ int mistra_chem_integrate(int mech, int ncell, const double* var_in, const doubl
 }
 
 int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tout) {
+  if (!g_inited) {   // the Fortran caller has no init hook: first use selects the device (env MISTRA_CHEM_DEVICE, default 0)
+    const char* dev = std::getenv("MISTRA_CHEM_DEVICE");
+    if (int rc = mistra_chem_init(dev ? std::atoi(dev) : 0)) return rc;
+  }
   if (int rc = check_call(mech, 1)) return rc;
   if (!gdata || !tin || !tout) return fail("null pointer");
   const int nv = kDims[mech][0], nf = kDims[mech][1], nr = kDims[mech][2];
