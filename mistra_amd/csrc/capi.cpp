@@ -286,20 +286,20 @@ int mistra_chem_integrate(int mech, int ncell, const double* var_in, const doubl
   DevBuf<unsigned long long> prof;
   const bool profile = std::getenv("MISTRA_CHEM_PROFILE") != nullptr;
   if (profile) {
-    HIP_TRY(prof.reserve(nc * 8));
+    HIP_TRY(prof.reserve(nc * 12));
     a.prof = prof.p;
   }
   if (int rc = launch(mech, a, nullptr)) return rc;
   HIP_TRY(hipDeviceSynchronize());
   if (profile) {
-    std::vector<unsigned long long> h(nc * 8);
-    HIP_TRY(hipMemcpy(h.data(), prof.p, nc * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum[8] = {0};
+    std::vector<unsigned long long> h(nc * 12);
+    HIP_TRY(hipMemcpy(h.data(), prof.p, nc * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum[12] = {0};
     for (size_t c = 0; c < nc; c++)
-      for (int k = 0; k < 8; k++) sum[k] += (double)h[c * 8 + k];
-    const char* names[8] = {"fun", "jac", "prepare", "lu", "solve", "norm", "other", "total"};
+      for (int k = 0; k < 12; k++) sum[k] += (double)h[c * 12 + k];
+    const char* names[12] = {"fun", "jac", "prepare", "lu", "solve(rest)", "norm", "other", "total", "solve_head_fwd", "solve_tail", "solve_head_bwd", "-"};
     std::fprintf(stderr, "[mistra_chem profile] %s, %zu cells, mean shader-clock ticks per cell:", kMechName[mech], nc);
-    for (int k = 0; k < 8; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
+    for (int k = 0; k < 11; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
     std::fprintf(stderr, "\n");
     prof.release();
   }

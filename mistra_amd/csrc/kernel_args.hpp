@@ -33,7 +33,7 @@ struct KernelArgs {
   int32_t* ierr;               // [ncell]         1 = success, <0 = ros_ErrorMsg code (gas.f:1474)
   int32_t* stats;              // [ncell][8]      Nfun,Njac,Nstp,Nacc,Nrej,Ndec,Nsol,Nsng  (COMMON /Statistics/)
   double* texit_hexit;         // [ncell][2] or null: what INTEGRATE_x leaves in TIN and STEPMIN
-  unsigned long long* prof;    // [ncell][8] or null: shader-clock cycles per phase (diagnostics, see capi.cpp)
+  unsigned long long* prof;    // [ncell][12] or null: shader-clock cycles per phase (diagnostics, see capi.cpp)
   double tin, tout;
   int32_t ncell;
   // mechanism schedule

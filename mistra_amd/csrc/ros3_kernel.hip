@@ -23,8 +23,7 @@ namespace mistra {
 namespace {
 
 // LDS VM record fields (schedule.hpp): LDS byte offsets with flags in the three alignment bits
-constexpr uint32_t kD0First = 1u, kD0Last = 2u, kD0Active = 4u;
-constexpr uint32_t kD1MulR = 1u, kD1Rcp = 2u;
+constexpr uint32_t kD1Rcp = 1u;
 constexpr uint32_t kD2Eor = 1u, kD2Null = 2u, kD2Rcp = 4u;
 constexpr uint32_t kOffMask = ~7u;
 constexpr uint32_t kGsFirst = 1u << 16, kGsNop = 1u << 17;
@@ -89,10 +88,11 @@ __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || 
 // register file is free: the loads land in a[4k:4k+3], which only the two statements below ever name, and the consume
 // statement waits and copies out in ONE asm (§5.7 form i).  Loads return in issue order, hence "at most kVmDepth-1
 // outstanding" means the oldest one — the slot about to be consumed — has landed.
-template <int K>
+template <int K, int BYTE_OFFSET = 0>
 __device__ __forceinline__ void vm_ring_load(gptr<u32x4> p) {
 #define MISTRA_RING_LOAD(A0, A1, A2, A3)                                                                              \
-  asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, off" : : "v"(p) : "memory", "a" #A0, "a" #A1, "a" #A2, "a" #A3)
+  asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, off offset:%1" : : "v"(p), "n"(BYTE_OFFSET)             \
+               : "memory", "a" #A0, "a" #A1, "a" #A2, "a" #A3)
   if constexpr (K == 0) MISTRA_RING_LOAD(0, 1, 2, 3);
   else if constexpr (K == 1) MISTRA_RING_LOAD(4, 5, 6, 7);
   else if constexpr (K == 2) MISTRA_RING_LOAD(8, 9, 10, 11);
@@ -124,22 +124,23 @@ __device__ __forceinline__ u32x4 vm_ring_take() {
 }
 static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots");
 
-// One record of the LDS VM (schedule.hpp); mb = LDS address of M.  Returns true when the last round has been closed.
-__device__ __forceinline__ bool vm_step(const u32x4 lo, const u32x4 hi, uint32_t mb, double& acc, int& rounds_left) {
+// One record of the LDS VM (schedule.hpp).  M starts at LDS address 0 (checked at kernel entry), so the record's byte
+// offsets are LDS addresses as they stand.  Returns true when the program's last round has been closed.
+__device__ __forceinline__ bool vm_step(const u32x4 lo, const u32x4 hi, int& rounds_left) {
   const uint32_t row = __builtin_amdgcn_readfirstlane(lo.z);       // row marks are identical in all lanes
   if (!(row & kD2Null)) {
-    const uint32_t tgt = mb + (lo.x & kOffMask), aux = mb + (lo.y & kOffMask);
-    const double x0 = lds_ld(tgt), ax = lds_ld(aux);
-    const double a1 = lds_ld(mb + (lo.z & kOffMask)), r1 = lds_ld(mb + lo.w), u1 = lds_ld(mb + hi.x);
-    const double a2 = lds_ld(mb + hi.y), r2 = lds_ld(mb + hi.z), u2 = lds_ld(mb + hi.w);
-    acc = (lo.x & kD0First) ? x0 : acc;
+    double acc = lds_ld(lo.x);
+    const double a1 = lds_ld(lo.z & kOffMask), r1 = lds_ld(lo.w), u1 = lds_ld(hi.x);
+    const double a2 = lds_ld(hi.y), r2 = lds_ld(hi.z), u2 = lds_ld(hi.w);
+    const double sc = lds_ld(lo.y & kOffMask);
     acc = acc - (a1 * r1) * u1;
     acc = acc - (a2 * r2) * u2;
-    const bool fin = (lo.x & (kD0Last | kD0Active)) == (kD0Last | kD0Active);
-    const double res = (lo.y & kD1MulR) ? acc * ax : acc;
-    if (fin) lds_st(tgt, res);
     if (row & kD2Rcp) {                                            // some lane of this row finalises a pivot
-      if (fin && (lo.y & kD1Rcp)) lds_st(aux, 1.0 / res);
+      const bool rcp = lo.y & kD1Rcp;
+      lds_st(lo.x, rcp ? acc : acc * sc);
+      if (rcp) lds_st(lo.y & kOffMask, 1.0 / acc);
+    } else {
+      lds_st(lo.x, acc * sc);
     }
   }
   if (row & kD2Eor) {
@@ -150,26 +151,24 @@ __device__ __forceinline__ bool vm_step(const u32x4 lo, const u32x4 hi, uint32_t
 }
 
 template <int NT>
-__device__ __attribute__((noinline)) void vm_run(const VmDev& P, double* __restrict__ M, int wave, int lane) {
+__device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int lane) {
   // a record is two 16-byte halves: 4 records (8 loads) in flight per lane
   gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)G_(P.wave_base)[wave] * 64 + lane) * 2;
-  const uint32_t Mb = lds_addr(M);
   int rounds_left = P.nrounds;
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
-  vm_ring_load<0>(rp);       vm_ring_load<1>(rp + 1);
-  vm_ring_load<2>(rp + 128); vm_ring_load<3>(rp + 129);
-  vm_ring_load<4>(rp + 256); vm_ring_load<5>(rp + 257);
-  vm_ring_load<6>(rp + 384); vm_ring_load<7>(rp + 385);
+  vm_ring_load<0>(rp);       vm_ring_load<1, 16>(rp);
+  vm_ring_load<2>(rp + 128); vm_ring_load<3, 16>(rp + 128);
+  vm_ring_load<4>(rp + 256); vm_ring_load<5, 16>(rp + 256);
+  vm_ring_load<6>(rp + 384); vm_ring_load<7, 16>(rp + 384);
   rp += 4 * 128;
-  double acc = 0.0;
   while (rounds_left > 0) {
 #define MISTRA_VM_SLOT(K)                                                \
     {                                                                    \
       const u32x4 lo = vm_ring_take<2 * K, 6>();      /* the two oldest of 8 loads have landed */ \
       const u32x4 hi = vm_ring_take<2 * K + 1, 6>();                      \
       vm_ring_load<2 * K>(rp + K * 128);                                 \
-      vm_ring_load<2 * K + 1>(rp + K * 128 + 1);                         \
-      if (vm_step(lo, hi, Mb, acc, rounds_left)) break;                  \
+      vm_ring_load<2 * K + 1, 16>(rp + K * 128);                         \
+      if (vm_step(lo, hi, rounds_left)) break;                           \
     }
     MISTRA_VM_SLOT(0) MISTRA_VM_SLOT(1) MISTRA_VM_SLOT(2) MISTRA_VM_SLOT(3)
 #undef MISTRA_VM_SLOT
@@ -190,9 +189,8 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 
 template <int R>
-__device__ __attribute__((noinline)) void tail_solve(const TailDev& T, const double* __restrict__ M, double* __restrict__ XT,
-                                                     const double* __restrict__ RT, int lane) {
-  const uint32_t mb = lds_addr(M), xb = lds_addr(XT), rb = lds_addr(RT);
+__device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t xb, uint32_t rb, int lane) {
+  constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
   double x[R], dg[R], rd[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
@@ -335,6 +333,10 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int cell = blockIdx.x;
   if (cell >= a.ncell) return;
+  if (lds_addr(lds) != 0u) {      // the VM and the tail chain address M by absolute LDS offsets
+    if (t == 0) GM_(a.ierr)[cell] = -99;
+    return;
+  }
 
   // ---- per-cell inputs: coalesced cell-major reads, once
   double y[SPT], rct[RPT];
@@ -354,6 +356,18 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     M[NNZ + NVAR] = 0.0;
     M[NNZ + NVAR + 1] = 1.0;
   }
+
+  // optional phase timing (diagnostics only): cycles of wave 0 between phase boundaries, summed per cell
+  const bool profiling = a.prof != nullptr;
+  unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = profiling ? clock64() : 0ull;
+  const unsigned long long t_begin = t_last;
+  auto lap = [&](int slot) {
+    if (profiling) {
+      const unsigned long long now = clock64();
+      pc[slot] += now - t_last;
+      t_last = now;
+    }
+  };
 
   // ---- Fun_x (gas.f:2043): X <- v; A(r) = RCT(r)*X*X*X; Vdot = signed sums of A
   auto fun = [&](const double (&v)[SPT], double (&out)[SPT]) {
@@ -438,11 +452,15 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       if (s < NVAR) XS[s] = k[q];
     }
     lds_barrier();
-    vm_run<NT>(a.solve_head_fwd, M, wave, lane);                                          // head rows, all waves
+    lap(6);
+    vm_run<NT>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
+    lap(8);
     if (wave == 0)                                                                         // tail chain, one wave
-      tail_solve<MT::TAIL_REGS>(a.tail, M, XS + (NVAR - 64 * MT::TAIL_REGS), M + NNZ + NVAR + 2 + (NVAR - 64 * MT::TAIL_REGS), lane);
+      tail_solve<MT::TAIL_REGS>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 3 + NVAR - 64 * MT::TAIL_REGS), lane);
     lds_barrier();
-    vm_run<NT>(a.solve_head_bwd, M, wave, lane);
+    lap(9);
+    vm_run<NT>(a.solve_head_bwd, wave, lane);
+    lap(10);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
       const int s = q * NT + t;
@@ -488,18 +506,6 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
 
   double ynew[SPT], fcn0[SPT], fcn[SPT], k1[SPT], k2[SPT], k3[SPT], yerr[SPT];
 
-  // optional phase timing (diagnostics only): cycles of wave 0 between phase boundaries, summed per cell
-  const bool profiling = a.prof != nullptr;
-  unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = profiling ? clock64() : 0ull;
-  const unsigned long long t_begin = t_last;
-  auto lap = [&](int slot) {
-    if (profiling) {
-      const unsigned long long now = clock64();
-      pc[slot] += now - t_last;
-      t_last = now;
-    }
-  };
-
   while (fabs(Tend - T) >= Roundoff) {
     if (nstp > 100000) { ierr = -6; break; }
     if (((T + 0.1 * H) == T) || (H <= Roundoff)) { ierr = -7; break; }
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
             if (nconsecutive <= 5) H = H * 0.5;
             else { ierr = -8; break; }
           } else {
-            vm_run<NT>(a.lu, M, wave, lane);
+            vm_run<NT>(a.lu, wave, lane);
             lap(3);
           }
         }
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     if (profiling) {
       lap(6);
       pc[7] = clock64() - t_begin;
-      for (int k = 0; k < 8; k++) GM_(a.prof)[(size_t)cell * 8 + k] = pc[k];
+      for (int k = 0; k < 12; k++) GM_(a.prof)[(size_t)cell * 12 + k] = pc[k];
     }
     if (a.texit_hexit) {
       GM_(a.texit_hexit)[(size_t)cell * 2] = T;

@@ -20,8 +20,8 @@ constexpr int max_i(int a, int b) { return a > b ? a : b; }
 // offsets in doubles into the dynamic LDS block
 template <class MT, int NT>
 struct LdsLayout {
-  static constexpr int M = 0;                                                          // Ghimj | XS | 0.0 | 1.0 | R
-  static constexpr int X = M + round_up2(MT::NNZ + 2 * MT::NVAR + 2);                  // V | F | consts
+  static constexpr int M = 0;                                                          // Ghimj | XS | 0.0 | 1.0 | trash | R
+  static constexpr int X = M + round_up2(MT::NNZ + 2 * MT::NVAR + 3);                  // V | F | consts
   static constexpr int AB = X + round_up2(MT::NVAR + MT::NFIX + MT::NCONST);           // A or B products
   static constexpr int RED = AB + round_up2(max_i(MT::NREACT, MT::NB));                // per-wave partial sums
   static constexpr int FLAGS = RED + 32;

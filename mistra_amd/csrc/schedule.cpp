@@ -128,9 +128,10 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
   // per-wave linear record streams: stream[w] = rows of 64 records of VM_REC_WORDS words
   std::vector<std::vector<uint32_t>> stream((size_t)P.nw);
   const uint32_t zoff = vm_off(zero_slot, 0);
+  const uint32_t one_off = vm_off(lay.one(), 0), trash_off = vm_off(lay.trash(), 0);
   auto idle_record = [&](std::vector<uint32_t>& out, uint32_t row_flags) {
-    out.push_back(zoff | VM_D0_FIRST);
-    out.push_back(zoff);
+    out.push_back(trash_off);
+    out.push_back(one_off);
     out.push_back(zoff | row_flags);
     for (int q = 3; q < VM_REC_WORDS; q++) out.push_back(zoff);
   };
@@ -148,18 +149,17 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
       const int nr = nrec(it);
       for (int r = 0; r < nr; r++) {
         const bool last_rec = r == nr - 1;
-        uint32_t f0 = VM_D0_ACTIVE | (r == 0 ? VM_D0_FIRST : 0u) | (last_rec ? VM_D0_LAST : 0u);
         uint32_t f1 = 0;
-        int aux = zero_slot;
+        int aux = lay.one();
         if (last_rec && it.final) {
-          if (E.mulr >= 0) { f1 |= VM_D1_MULR; aux = E.mulr; }
+          if (E.mulr >= 0) aux = E.mulr;
           if (E.rcp >= 0) {
             if (E.mulr >= 0) throw std::logic_error("an entry cannot both scale and publish a reciprocal");
-            f1 |= VM_D1_RCP;
+            f1 = VM_D1_RCP;
             aux = E.rcp;
           }
         }
-        w.push_back(vm_off(E.tgt, f0));
+        w.push_back(vm_off(E.tgt, 0));
         w.push_back(vm_off(aux, f1));
         for (int u = 0; u < VM_UPD_PER_REC; u++) {
           int i = r * VM_UPD_PER_REC + u;
@@ -400,7 +400,7 @@ GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, doub
 // ---------------------------------------------------------------------------------------------------------------
 KernelSchedule build_kernel_schedule(const MechTables& m, int nt) {
   if (nt % 64 != 0 || nt <= 0 || nt > 1024) throw std::invalid_argument("nt must be a multiple of 64 in (0,1024]");
-  if ((m.nnz + 2 * m.nvar + 2) * 8 > 160 * 1024) throw std::invalid_argument("mechanism too large for the LDS VM");
+  if ((m.nnz + 2 * m.nvar + 3) * 8 > 160 * 1024) throw std::invalid_argument("mechanism too large for the LDS VM");
   if (m.nx() > 0xFFFF || m.nb >= 0xFFFF || m.nreact > 0xFFFF) throw std::invalid_argument("mechanism too large");
   KernelSchedule S;
   S.nt = nt;

@@ -3,16 +3,20 @@
 //
 // Two tiny "machines" run inside the kernel, both over LDS-resident data:
 //
-//  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) | 0.0 | 1.0 | R (nvar) ], R(k) = 1/U(k,k).  A program
-//    is a list of rounds separated by workgroup barriers; inside a round every lane walks its own list of fixed
-//    32-byte RECORDS whose fields are LDS byte offsets (flags ride in the three alignment bits):
-//        d0 = tgt | FIRST | LAST | ACTIVE      d1 = aux | MULR | RCP      d2..d4 = a1,r1,u1   d5..d7 = a2,r2,u2
-//        FIRST : acc = M[tgt]                  (else the lane's acc carries over from its previous record)
-//        each update slot: acc = acc - (M[a]*M[r])*M[u]     (three roundings, no contraction; an unused slot points all
-//                                                           three at the 0.0 cell: acc - (0*0)*0 = acc exactly)
-//        LAST  : res = MULR ? acc*M[aux] : acc;  M[tgt] = res;  RCP: M[aux] = 1/res      (only if ACTIVE)
-//    d2 also carries the row marks (end-of-round, null row).  A wave's records form one linear stream over all rounds,
-//    so table loads run ahead of use whatever the round structure and nothing else is read from memory.
+//  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) | 0.0 | 1.0 | trash | R (nvar) ], R(k) = 1/U(k,k).
+//    A program is a list of rounds separated by workgroup barriers; inside a round every lane walks its own list of
+//    fixed 32-byte RECORDS whose fields are LDS byte offsets.  Records are self-contained (no state carried from one
+//    to the next, no per-lane flags to decode):
+//        d0 = tgt     d1 = aux (| RCP)     d2..d4 = a1,r1,u1     d5..d7 = a2,r2,u2      (d2 also carries the row marks)
+//        acc = M[tgt];   acc -= (M[a1]*M[r1])*M[u1];   acc -= (M[a2]*M[r2])*M[u2];      (three roundings per update, no
+//                                                                                        contraction)
+//        M[tgt] = acc * M[aux]            aux = the 1.0 cell unless the entry is scaled by a pivot reciprocal
+//        RCP:  M[tgt] = acc;  M[aux] = 1/acc           (a pivot publishes its reciprocal; rows with such lanes are marked)
+//    An unused update slot points all three operands at the 0.0 cell (acc - (0*0)*0 = acc exactly); an idle lane
+//    targets the trash cell.  An entry with more than two updates in a round takes consecutive records of one lane
+//    (store, reload: LDS is in-order within a wave).  A wave's records form one linear stream over all rounds (the
+//    last row of a round carries an end-of-round mark, a wave without work gets one null row), so table loads run
+//    ahead of use whatever the round structure and nothing but the records themselves is read from memory.
 //
 //    Sparse LU (KppDecomp_x, gas.f:6142): entry (k,c) receives  -L(k,j)*U(j,c)  for ascending j.  The reference forms
 //    the multiplier L(k,j) = W(j)/U(j,j) first; here an update reads the UNSCALED W(j), the pivot's reciprocal R(j) and
@@ -41,9 +45,8 @@
 
 namespace mistra {
 
-// record flags (low three bits of an 8-byte-aligned LDS byte offset)
-constexpr uint32_t VM_D0_FIRST = 1u, VM_D0_LAST = 2u, VM_D0_ACTIVE = 4u;
-constexpr uint32_t VM_D1_MULR = 1u, VM_D1_RCP = 2u;
+// record marks (low three bits of an 8-byte-aligned LDS byte offset)
+constexpr uint32_t VM_D1_RCP = 1u;     // on d1: publish 1/result to aux instead of scaling by M[aux]
 constexpr uint32_t VM_D2_EOR = 1u;     // on d2 of every lane of a row: last row of this round for the wave -> barrier
 constexpr uint32_t VM_D2_NULL = 2u;    // on d2: the row carries no work (a wave with nothing to do in a round)
 constexpr uint32_t VM_D2_RCP = 4u;     // on d2 of every lane of a row: some lane of the row publishes a reciprocal
@@ -58,8 +61,9 @@ struct VmLayout {
   int xs(int i = 0) const { return nnz + i; }
   int zero() const { return nnz + nvar; }
   int one() const { return nnz + nvar + 1; }
-  int rdiag(int k = 0) const { return nnz + nvar + 2 + k; }
-  int size() const { return nnz + 2 * nvar + 2; }
+  int trash() const { return nnz + nvar + 2; }
+  int rdiag(int k = 0) const { return nnz + nvar + 3 + k; }
+  int size() const { return nnz + 2 * nvar + 3; }
 };
 
 constexpr uint32_t GS_FIRST = 1u << 16;

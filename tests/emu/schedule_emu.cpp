@@ -26,11 +26,10 @@ struct Emu {
   }
 };
 
-static int run_vm(const VmProgram& P, std::vector<double>& M) {
+static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
   const int nt = P.nt;
   std::vector<int> writer(M.size());
   std::vector<uint32_t> row_of_wave((size_t)P.nw, 0);
-  std::vector<double> acc_of_lane((size_t)nt, 0.0);
   for (int r = 0; r < P.nrounds; r++) {
     std::fill(writer.begin(), writer.end(), -1);
     std::vector<std::pair<int, int>> reads;   // (slot, lane)
@@ -42,40 +41,39 @@ static int run_vm(const VmProgram& P, std::vector<double>& M) {
       for (int l = 0; l < 64; l++) {
         const int lane = w * 64 + l;
         if (lane >= nt) break;
-        double acc = acc_of_lane[(size_t)lane];
         for (int ridx = 0; ridx < n; ridx++) {
           const uint32_t* rec = &P.recs[((base + ridx) * 64 + l) * VM_REC_WORDS];
           if ((rec[2] & VM_D2_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
           if (rec[2] & VM_D2_NULL) continue;
           auto rd = [&](uint32_t off) {
             const int i = (int)((off & VM_OFF_MASK) >> 3);
-            reads.emplace_back(i, lane);
+            if (i != trash) reads.emplace_back(i, lane);
             return (writer[i] == lane) ? M[(size_t)i] : snapshot[(size_t)i];
           };
+          auto wr = [&](int i, double v) {
+            M[(size_t)i] = v;
+            if (i == trash) return 0;
+            if (writer[i] >= 0 && writer[i] != lane) return -2;   // two lanes write one slot in a round
+            writer[i] = lane;
+            return 0;
+          };
           const int tgt = (int)((rec[0] & VM_OFF_MASK) >> 3), aux = (int)((rec[1] & VM_OFF_MASK) >> 3);
-          const double x0 = rd(rec[0]);
-          if (rec[0] & VM_D0_FIRST) acc = x0;
+          double acc = rd(rec[0]);
           for (int u = 0; u < VM_UPD_PER_REC; u++) {
             const double av = rd(rec[2 + 3 * u]), rv = rd(rec[3 + 3 * u]), uv = rd(rec[4 + 3 * u]);
             const double mlt = av * rv;
             const double p = mlt * uv;
             acc = acc - p;
           }
-          if ((rec[0] & VM_D0_LAST) && (rec[0] & VM_D0_ACTIVE)) {
-            double res = acc;
-            if (rec[1] & VM_D1_MULR) res = acc * rd(rec[1]);
-            M[(size_t)tgt] = res;
-            if (writer[tgt] >= 0 && writer[tgt] != lane) return -2;   // two lanes write one slot in a round
-            writer[tgt] = lane;
-            if (rec[1] & VM_D1_RCP) {
-              if (!(rec[2] & VM_D2_RCP)) return -6;   // row mark missing
-              M[(size_t)aux] = 1.0 / res;
-              if (writer[aux] >= 0 && writer[aux] != lane) return -2;
-              writer[aux] = lane;
-            }
+          if (rec[1] & VM_D1_RCP) {
+            if (!(rec[2] & VM_D2_RCP)) return -6;   // row mark missing
+            if (wr(tgt, acc)) return -2;
+            if (wr(aux, 1.0 / acc)) return -2;
+          } else {
+            const double sc = rd(rec[1]);
+            if (wr(tgt, acc * sc)) return -2;
           }
         }
-        acc_of_lane[(size_t)lane] = acc;
       }
     }
     for (auto& rd : reads)
@@ -110,7 +108,7 @@ static void run_gsum(const GsumProgram& P, const std::vector<double>& src, std::
 // The tail loops below mirror tail_solve of ros3_kernel.hip statement by statement.
 static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, const VmLayout& lay) {
   const int nnz = lay.nnz;
-  int rc = run_vm(s.solve_head_fwd, M);
+  int rc = run_vm(s.solve_head_fwd, M, lay.trash());
   if (rc) return rc;
   const TailSolve& T = s.tail;
   const int R = T.regs, m = T.m;
@@ -147,7 +145,7 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
       }
   }
   for (int i = 0; i < m; i++) M[(size_t)nnz + T.h + i] = x[(size_t)i];
-  return run_vm(s.solve_head_bwd, M);
+  return run_vm(s.solve_head_bwd, M, lay.trash());
 }
 
 extern "C" {
@@ -175,7 +173,7 @@ int emu_lu(void* h, double* G, double* R) {
   Emu* e = (Emu*)h;
   std::vector<double> M = e->fresh_m();
   std::memcpy(M.data(), G, sizeof(double) * e->m.nnz);
-  int rc = run_vm(e->s.lu, M);
+  int rc = run_vm(e->s.lu, M, e->lay().trash());
   std::memcpy(G, M.data(), sizeof(double) * e->m.nnz);
   if (R) std::memcpy(R, M.data() + e->lay().rdiag(), sizeof(double) * e->m.nvar);
   return rc;
@@ -192,7 +190,7 @@ static std::vector<double> solve_memory(const Emu* e, const double* LU, const do
 int emu_solve(void* h, const double* LU, double* X) {
   Emu* e = (Emu*)h;
   std::vector<double> M = solve_memory(e, LU, X);
-  int rc = run_vm(e->s.solve, M);
+  int rc = run_vm(e->s.solve, M, e->lay().trash());
   std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
   return rc;
 }

@@ -4,7 +4,8 @@ import torch
 from mistra_amd import chem
 from mistra_amd.workload import make_batch
 chem.init(0)
-for mech,n in (('tot',512),('aer',512),('gas',4096)):
+import sys
+for mech,n in ((('tot',512),) if len(sys.argv)>1 else (('tot',512),('aer',512),('gas',4096))):
     var,fix,rconst=make_batch(mech,0,n,'cpu')
     os.environ['MISTRA_CHEM_PROFILE']='1'
     t0=time.time(); res=chem.integrate(mech,var.numpy(),fix.numpy(),rconst.numpy()); dt=time.time()-t0
