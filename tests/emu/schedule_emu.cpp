@@ -133,10 +133,7 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
   }
   for (int q = m - 1; q >= 0; q--) {
     const int rq = q / 64, lq = q % 64;
-    const double sv = x[(size_t)rq * 64 + lq], d = dg[(size_t)rq * 64 + lq], rr = rd[(size_t)rq * 64 + lq];
-    const double q0 = sv * rr;
-    const double e = std::fma(-q0, d, sv);
-    const double xq = std::fma(e, rr, q0);
+    const double xq = x[(size_t)rq * 64 + lq] * rd[(size_t)rq * 64 + lq];
     x[(size_t)rq * 64 + lq] = xq;
     for (int r = 0; r <= rq; r++)
       for (int lane = 0; lane < 64; lane++) {
