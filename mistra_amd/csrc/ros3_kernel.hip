@@ -23,6 +23,7 @@ namespace mistra {
 namespace {
 
 // LDS VM record fields (schedule.hpp): LDS byte offsets with flags in the three alignment bits
+constexpr uint32_t kD0Cont = 1u;
 constexpr uint32_t kD1Rcp = 1u;
 constexpr uint32_t kD2Eor = 1u, kD2Null = 2u, kD2Rcp = 4u;
 constexpr uint32_t kOffMask = ~7u;
@@ -133,7 +134,7 @@ struct VmOperands {
 };
 __device__ __forceinline__ VmOperands vm_fetch(const u32x4 lo, const u32x4 hi) {
   VmOperands o;
-  o.acc = lds_ld(lo.x);
+  o.acc = lds_ld(lo.x & kOffMask);   // ignored by a continuation record (its previous record's store may still be pending)
   o.a1 = lds_ld(lo.z & kOffMask);
   o.r1 = lds_ld(lo.w);
   o.u1 = lds_ld(hi.x);
@@ -143,15 +144,20 @@ __device__ __forceinline__ VmOperands vm_fetch(const u32x4 lo, const u32x4 hi) {
   o.sc = lds_ld(lo.y & kOffMask);
   return o;
 }
-__device__ __forceinline__ void vm_finish(const VmOperands& o, const u32x4 lo, uint32_t row) {
-  double acc = o.acc - (o.a1 * o.r1) * o.u1;
+// `carry`: what this lane's previous record stored; a continuation record starts from it instead of its (prefetched) M[tgt]
+__device__ __forceinline__ void vm_finish(const VmOperands& o, const u32x4 lo, uint32_t row, double& carry) {
+  double acc = (lo.x & kD0Cont) ? carry : o.acc;
+  acc = acc - (o.a1 * o.r1) * o.u1;
   acc = acc - (o.a2 * o.r2) * o.u2;
+  const uint32_t tgt = lo.x & kOffMask;
   if (row & kD2Rcp) {                                            // some lane of this row finalises a pivot
     const bool rcp = lo.y & kD1Rcp;
-    lds_st(lo.x, rcp ? acc : acc * o.sc);
+    carry = rcp ? acc : acc * o.sc;
+    lds_st(tgt, carry);
     if (rcp) lds_st(lo.y & kOffMask, 1.0 / acc);
   } else {
-    lds_st(lo.x, acc * o.sc);
+    carry = acc * o.sc;
+    lds_st(tgt, carry);
   }
 }
 
@@ -172,6 +178,7 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int l
   vm_ring_load<0>(rp);
   vm_ring_load<1, 16>(rp);
   VmOperands op_a = vm_fetch(lo_a, hi_a), op_b;
+  double carry = 0.0;
   for (;;) {
 #define MISTRA_VM_SLOT(KN, CUR, NXT)   /* KN = ring slot of the record AFTER the current one */                 \
     {                                                                                                          \
@@ -182,7 +189,7 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int l
       const uint32_t row = __builtin_amdgcn_readfirstlane(lo_##CUR.z);   /* row marks are identical in all lanes */ \
       const bool eor = row & kD2Eor;                                                                           \
       if (!eor) op_##NXT = vm_fetch(lo_##NXT, hi_##NXT);   /* same round: reads may run ahead of the current stores */ \
-      vm_finish(op_##CUR, lo_##CUR, row);                                                                      \
+      vm_finish(op_##CUR, lo_##CUR, row, carry);                                                               \
       if (eor) {                                                                                               \
         lds_barrier();                                                                                         \
         if (--rounds_left == 0) break;                                                                         \

@@ -159,7 +159,7 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
             aux = E.rcp;
           }
         }
-        w.push_back(vm_off(E.tgt, 0));
+        w.push_back(vm_off(E.tgt, r > 0 ? VM_D0_CONT : 0u));
         w.push_back(vm_off(aux, f1));
         for (int u = 0; u < VM_UPD_PER_REC; u++) {
           int i = r * VM_UPD_PER_REC + u;

@@ -8,7 +8,8 @@
 //    fixed 32-byte RECORDS whose fields are LDS byte offsets.  Records are self-contained (no state carried from one
 //    to the next, no per-lane flags to decode):
 //        d0 = tgt     d1 = aux (| RCP)     d2..d4 = a1,r1,u1     d5..d7 = a2,r2,u2      (d2 also carries the row marks)
-//        acc = M[tgt];   acc -= (M[a1]*M[r1])*M[u1];   acc -= (M[a2]*M[r2])*M[u2];      (three roundings per update, no
+//        acc = CONT ? (what this lane's previous record stored) : M[tgt];
+//        acc -= (M[a1]*M[r1])*M[u1];   acc -= (M[a2]*M[r2])*M[u2];      (three roundings per update, no
 //                                                                                        contraction)
 //        M[tgt] = acc * M[aux]            aux = the 1.0 cell unless the entry is scaled by a pivot reciprocal
 //        RCP:  M[tgt] = acc;  M[aux] = 1/acc           (a pivot publishes its reciprocal; rows with such lanes are marked)
@@ -46,6 +47,9 @@
 namespace mistra {
 
 // record marks (low three bits of an 8-byte-aligned LDS byte offset)
+constexpr uint32_t VM_D0_CONT = 1u;    // on d0: continuation record of the lane's previous record (same target): the
+                                       // accumulator is carried in a register (the kernel prefetches operands, so a reload of
+                                       // the target could overtake the previous record's store)
 constexpr uint32_t VM_D1_RCP = 1u;     // on d1: publish 1/result to aux instead of scaling by M[aux]
 constexpr uint32_t VM_D2_EOR = 1u;     // on d2 of every lane of a row: last row of this round for the wave -> barrier
 constexpr uint32_t VM_D2_NULL = 2u;    // on d2: the row carries no work (a wave with nothing to do in a round)

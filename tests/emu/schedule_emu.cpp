@@ -41,6 +41,7 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
       for (int l = 0; l < 64; l++) {
         const int lane = w * 64 + l;
         if (lane >= nt) break;
+        double carry = 0.0;
         for (int ridx = 0; ridx < n; ridx++) {
           const uint32_t* rec = &P.recs[((base + ridx) * 64 + l) * VM_REC_WORDS];
           if ((rec[2] & VM_D2_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
@@ -58,7 +59,8 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
             return 0;
           };
           const int tgt = (int)((rec[0] & VM_OFF_MASK) >> 3), aux = (int)((rec[1] & VM_OFF_MASK) >> 3);
-          double acc = rd(rec[0]);
+          double acc = (rec[0] & VM_D0_CONT) ? carry : rd(rec[0]);
+          if ((rec[0] & VM_D0_CONT) && ridx == 0) return -7;   // a continuation cannot open a round
           for (int u = 0; u < VM_UPD_PER_REC; u++) {
             const double av = rd(rec[2 + 3 * u]), rv = rd(rec[3 + 3 * u]), uv = rd(rec[4 + 3 * u]);
             const double mlt = av * rv;
@@ -69,15 +71,18 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
             if (!(rec[2] & VM_D2_RCP)) return -6;   // row mark missing
             if (wr(tgt, acc)) return -2;
             if (wr(aux, 1.0 / acc)) return -2;
+            carry = acc;
           } else {
             const double sc = rd(rec[1]);
             if (wr(tgt, acc * sc)) return -2;
+            carry = acc * sc;
           }
         }
       }
     }
     for (auto& rd : reads)
-      if (writer[rd.first] >= 0 && writer[rd.first] != rd.second) return -3;   // read of a slot another lane writes this round
+      if (writer[rd.first] >= 0) return -3;   // read of a slot that is written in this round (the kernel prefetches operands,
+                                              // so not even the writing lane itself may read it back before the barrier)
   }
   return 0;
 }
