@@ -19,7 +19,7 @@ import numpy as np
 from .mechtab import MECH_IDS, MECH_NAMES
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmistra_chem.so")
+LIB_PATH = os.environ.get("MISTRA_CHEM_LIB", os.path.join(_PKG, "lib", "libmistra_chem.so"))   # override: diagnostic builds
 
 DIMS = {"gas": (102, 3, 331, 1110), "aer": (257, 5, 979, 6579), "tot": (417, 7, 1627, 13503)}
 STAT_NAMES = ("Nfun", "Njac", "Nstp", "Nacc", "Nrej", "Ndec", "Nsol", "Nsng")   # COMMON /Statistics/, gas.f:913

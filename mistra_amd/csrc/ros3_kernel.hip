@@ -31,6 +31,11 @@ constexpr uint32_t kGsFirst = 1u << 16, kGsNop = 1u << 17;
 constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
 constexpr int kRingSlots = 8;  // 16-byte table loads in flight per lane (schedule.cpp appends 2x that many rows of slack)
 constexpr int kGsDepth = 4;    // gather-sum rows in flight per lane
+#ifdef MISTRA_VM_NO_PREFETCH
+constexpr bool kVmPrefetchOperands = false;   // diagnostic build: operand reads strictly after the previous record's stores
+#else
+constexpr bool kVmPrefetchOperands = true;
+#endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain vector types load from any address space
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -188,11 +193,13 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int l
       vm_ring_load<2 * KN + 1, 16>(rp + KN * 128);                                                             \
       const uint32_t row = __builtin_amdgcn_readfirstlane(lo_##CUR.z);   /* row marks are identical in all lanes */ \
       const bool eor = row & kD2Eor;                                                                           \
-      if (!eor) op_##NXT = vm_fetch(lo_##NXT, hi_##NXT);   /* same round: reads may run ahead of the current stores */ \
+      if (!eor && kVmPrefetchOperands) op_##NXT = vm_fetch(lo_##NXT, hi_##NXT);   /* same round: reads may run ahead of the current stores */ \
       vm_finish(op_##CUR, lo_##CUR, row, carry);                                                               \
       if (eor) {                                                                                               \
         lds_barrier();                                                                                         \
         if (--rounds_left == 0) break;                                                                         \
+        op_##NXT = vm_fetch(lo_##NXT, hi_##NXT);                                                               \
+      } else if (!kVmPrefetchOperands) {                                                                       \
         op_##NXT = vm_fetch(lo_##NXT, hi_##NXT);                                                               \
       }                                                                                                        \
     }
@@ -220,11 +227,12 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 template <int R>
 __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t xb, uint32_t rb, int lane) {
   constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
-  double x[R], rd[R];
+  double x[R], rd[R], dg[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
     x[r] = lds_ld(xb + 8 * (r * 64 + lane));
     rd[r] = lds_ld(rb + 8 * (r * 64 + lane));          // R(k) = 1/U(k,k), published by the LU program
+    dg[r] = lds_ld(mb + 8 * (uint32_t)G_(T.diag)[r * 64 + lane]);
   }
   // ---- forward: for every tail column q ascending:  x(i) -= L(i,q) * x(q)  for the tail rows i > q
   {
@@ -255,9 +263,10 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t 
       }
     }
   }
-  // ---- backward: for every tail column q descending:  x(q) = x(q)*R(q);  x(i) -= U(i,q) * x(q)  for tail rows i < q.
-  //      R(q) = 1/U(q,q) as published by the LU (the head rows scale the same way); an IEEE divide sequence would sit on
-  //      the serial chain 128 times.
+  // ---- backward: for every tail column q descending:  x(q) = x(q)/U(q,q);  x(i) -= U(i,q) * x(q)  for tail rows i < q.
+  //      The quotient is formed with the published reciprocal R(q) and one correction step (q0 = s*r; q0 + (s - q0*d)*r),
+  //      which lands on the correctly rounded s/d except in rare ties; an IEEE divide sequence would sit on the serial
+  //      chain 128 times.
   {
     gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.bwd)) + lane;
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
@@ -276,7 +285,10 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t 
             _Pragma("unroll") for (int r = 0; r <= rq; r++) u[c][r] = lds_ld(mb + 8 * ((cur[c] >> (16 * r)) & 0xFFFFu)); \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const int lq = 63 - (4 * (gb + K) + c);                                     \
-            const double xq = readlane_f64(x[rq], lq) * readlane_f64(rd[rq], lq);        \
+            const double sv = readlane_f64(x[rq], lq), d = readlane_f64(dg[rq], lq), rr = readlane_f64(rd[rq], lq); \
+            const double q0 = sv * rr;                                                  \
+            const double e = __builtin_fma(-q0, d, sv);                                 \
+            const double xq = __builtin_fma(e, rr, q0);                                 \
             x[rq] = (lane == lq) ? xq : x[rq];                                          \
             _Pragma("unroll") for (int r = 0; r <= rq; r++) x[r] = x[r] - u[c][r] * xq; \
           }                                                                             \

@@ -4,6 +4,7 @@
 // lane reads an M slot another lane writes in the same round.  It is NOT part of the product library and is never
 // a fallback: mistra_amd/ does not link it.
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -42,13 +43,17 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
         const int lane = w * 64 + l;
         if (lane >= nt) break;
         double carry = 0.0;
+        bool own_raw = false;
         for (int ridx = 0; ridx < n; ridx++) {
           const uint32_t* rec = &P.recs[((base + ridx) * 64 + l) * VM_REC_WORDS];
           if ((rec[2] & VM_D2_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
           if (rec[2] & VM_D2_NULL) continue;
           auto rd = [&](uint32_t off) {
             const int i = (int)((off & VM_OFF_MASK) >> 3);
-            if (i != trash) reads.emplace_back(i, lane);
+            if (i != trash) {
+              reads.emplace_back(i, lane);
+              if (writer[i] == lane) own_raw = true;   // the kernel prefetches operands: a lane may not read back its own store
+            }
             return (writer[i] == lane) ? M[(size_t)i] : snapshot[(size_t)i];
           };
           auto wr = [&](int i, double v) {
@@ -78,10 +83,11 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
             carry = acc * sc;
           }
         }
+        if (own_raw) return -8;
       }
     }
     for (auto& rd : reads)
-      if (writer[rd.first] >= 0) return -3;   // read of a slot that is written in this round (the kernel prefetches operands,
+      if (writer[rd.first] >= 0 && writer[rd.first] != rd.second) return -3;   // read of a slot another lane writes this round   // read of a slot that is written in this round (the kernel prefetches operands,
                                               // so not even the writing lane itself may read it back before the barrier)
   }
   return 0;
@@ -138,7 +144,10 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
   }
   for (int q = m - 1; q >= 0; q--) {
     const int rq = q / 64, lq = q % 64;
-    const double xq = x[(size_t)rq * 64 + lq] * rd[(size_t)rq * 64 + lq];
+    const double sv = x[(size_t)rq * 64 + lq], d = dg[(size_t)rq * 64 + lq], rr = rd[(size_t)rq * 64 + lq];
+    const double q0 = sv * rr;
+    const double e = std::fma(-q0, d, sv);
+    const double xq = std::fma(e, rr, q0);
     x[(size_t)rq * 64 + lq] = xq;
     for (int r = 0; r <= rq; r++)
       for (int lane = 0; lane < 64; lane++) {
