@@ -31,11 +31,6 @@ constexpr uint32_t kGsFirst = 1u << 16, kGsNop = 1u << 17;
 constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
 constexpr int kRingSlots = 8;  // 16-byte table loads in flight per lane (schedule.cpp appends 2x that many rows of slack)
 constexpr int kGsDepth = 4;    // gather-sum rows in flight per lane
-#ifdef MISTRA_VM_NO_PREFETCH
-constexpr bool kVmPrefetchOperands = false;   // diagnostic build: operand reads strictly after the previous record's stores
-#else
-constexpr bool kVmPrefetchOperands = true;
-#endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain vector types load from any address space
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -130,85 +125,56 @@ __device__ __forceinline__ u32x4 vm_ring_take() {
 }
 static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots");
 
-// One record of the LDS VM (schedule.hpp), split in two halves so that the operand reads of the NEXT record of the same
-// round can be issued before the arithmetic of the current one (records of one round never read what the round
-// writes, except a lane's own target, and LDS is in-order within a wave).  M starts at LDS address 0 (checked at kernel
-// entry), so the record's byte offsets are LDS addresses as they stand.
-struct VmOperands {
-  double acc, a1, r1, u1, a2, r2, u2, sc;
-};
-__device__ __forceinline__ VmOperands vm_fetch(const u32x4 lo, const u32x4 hi) {
-  VmOperands o;
-  o.acc = lds_ld(lo.x & kOffMask);   // ignored by a continuation record (its previous record's store may still be pending)
-  o.a1 = lds_ld(lo.z & kOffMask);
-  o.r1 = lds_ld(lo.w);
-  o.u1 = lds_ld(hi.x);
-  o.a2 = lds_ld(hi.y);
-  o.r2 = lds_ld(hi.z);
-  o.u2 = lds_ld(hi.w);
-  o.sc = lds_ld(lo.y & kOffMask);
-  return o;
-}
-// `carry`: what this lane's previous record stored; a continuation record starts from it instead of its (prefetched) M[tgt]
-__device__ __forceinline__ void vm_finish(const VmOperands& o, const u32x4 lo, uint32_t row, double& carry) {
-  double acc = (lo.x & kD0Cont) ? carry : o.acc;
-  acc = acc - (o.a1 * o.r1) * o.u1;
-  acc = acc - (o.a2 * o.r2) * o.u2;
-  const uint32_t tgt = lo.x & kOffMask;
-  if (row & kD2Rcp) {                                            // some lane of this row finalises a pivot
-    const bool rcp = lo.y & kD1Rcp;
-    carry = rcp ? acc : acc * o.sc;
-    lds_st(tgt, carry);
-    if (rcp) lds_st(lo.y & kOffMask, 1.0 / acc);
-  } else {
-    carry = acc * o.sc;
-    lds_st(tgt, carry);
+// One record of the LDS VM (schedule.hpp).  M starts at LDS address 0 (checked at kernel entry), so the record's byte
+// offsets are LDS addresses as they stand.  Returns true when the program's last round has been closed.
+__device__ __forceinline__ bool vm_step(const u32x4 lo, const u32x4 hi, int& rounds_left) {
+  const uint32_t row = __builtin_amdgcn_readfirstlane(lo.z);       // row marks are identical in all lanes
+  if (!(row & kD2Null)) {
+    const uint32_t tgt = lo.x & kOffMask;     // bit 0 marks a continuation record: here the reload simply follows the
+    double acc = lds_ld(tgt);                 // lane's own store (LDS is in-order within a wave), nothing to carry
+    const double a1 = lds_ld(lo.z & kOffMask), r1 = lds_ld(lo.w), u1 = lds_ld(hi.x);
+    const double a2 = lds_ld(hi.y), r2 = lds_ld(hi.z), u2 = lds_ld(hi.w);
+    const double sc = lds_ld(lo.y & kOffMask);
+    acc = acc - (a1 * r1) * u1;
+    acc = acc - (a2 * r2) * u2;
+    if (row & kD2Rcp) {                                            // some lane of this row finalises a pivot
+      const bool rcp = lo.y & kD1Rcp;
+      lds_st(tgt, rcp ? acc : acc * sc);
+      if (rcp) lds_st(lo.y & kOffMask, 1.0 / acc);
+    } else {
+      lds_st(tgt, acc * sc);
+    }
   }
+  if (row & kD2Eor) {
+    lds_barrier();
+    return --rounds_left == 0;
+  }
+  return false;
 }
 
 template <int NT>
 __device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int lane) {
   // a record is two 16-byte halves: 4 records (8 loads) in flight per lane
   gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)G_(P.wave_base)[wave] * 64 + lane) * 2;
-  int rounds_left = __builtin_amdgcn_readfirstlane(P.nrounds);
+  int rounds_left = P.nrounds;
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
   vm_ring_load<0>(rp);       vm_ring_load<1, 16>(rp);
   vm_ring_load<2>(rp + 128); vm_ring_load<3, 16>(rp + 128);
   vm_ring_load<4>(rp + 256); vm_ring_load<5, 16>(rp + 256);
   vm_ring_load<6>(rp + 384); vm_ring_load<7, 16>(rp + 384);
   rp += 4 * 128;
-  // software pipeline over records with two statically named register sets (A, B) that swap roles every record:
-  // the set in the CUR role has its LDS reads in flight or done, the other one receives the following record
-  u32x4 lo_a = vm_ring_take<0, 6>(), hi_a = vm_ring_take<1, 6>(), lo_b, hi_b;
-  vm_ring_load<0>(rp);
-  vm_ring_load<1, 16>(rp);
-  VmOperands op_a = vm_fetch(lo_a, hi_a), op_b;
-  double carry = 0.0;
-  for (;;) {
-#define MISTRA_VM_SLOT(KN, CUR, NXT)   /* KN = ring slot of the record AFTER the current one */                 \
-    {                                                                                                          \
-      lo_##NXT = vm_ring_take<2 * KN, 6>();                                                                    \
-      hi_##NXT = vm_ring_take<2 * KN + 1, 6>();                                                                \
-      vm_ring_load<2 * KN>(rp + KN * 128);                                                                     \
-      vm_ring_load<2 * KN + 1, 16>(rp + KN * 128);                                                             \
-      const uint32_t row = __builtin_amdgcn_readfirstlane(lo_##CUR.z);   /* row marks are identical in all lanes */ \
-      const bool eor = row & kD2Eor;                                                                           \
-      if (!eor && kVmPrefetchOperands) op_##NXT = vm_fetch(lo_##NXT, hi_##NXT);   /* same round: reads may run ahead of the current stores */ \
-      vm_finish(op_##CUR, lo_##CUR, row, carry);                                                               \
-      if (eor) {                                                                                               \
-        lds_barrier();                                                                                         \
-        if (--rounds_left == 0) break;                                                                         \
-        op_##NXT = vm_fetch(lo_##NXT, hi_##NXT);                                                               \
-      } else if (!kVmPrefetchOperands) {                                                                       \
-        op_##NXT = vm_fetch(lo_##NXT, hi_##NXT);                                                               \
-      }                                                                                                        \
+  while (rounds_left > 0) {
+#define MISTRA_VM_SLOT(K)                                                \
+    {                                                                    \
+      const u32x4 lo = vm_ring_take<2 * K, 6>();      /* the two oldest of 8 loads have landed */ \
+      const u32x4 hi = vm_ring_take<2 * K + 1, 6>();                      \
+      vm_ring_load<2 * K>(rp + K * 128);                                 \
+      vm_ring_load<2 * K + 1, 16>(rp + K * 128);                         \
+      if (vm_step(lo, hi, rounds_left)) break;                           \
     }
-    MISTRA_VM_SLOT(1, a, b)
-    MISTRA_VM_SLOT(2, b, a)
-    MISTRA_VM_SLOT(3, a, b)
-    rp += 4 * 128;
-    MISTRA_VM_SLOT(0, b, a)
+    MISTRA_VM_SLOT(0) MISTRA_VM_SLOT(1) MISTRA_VM_SLOT(2) MISTRA_VM_SLOT(3)
 #undef MISTRA_VM_SLOT
+    rp += 4 * 128;
   }
   // drain: the look-ahead loads must have landed before this function returns
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");

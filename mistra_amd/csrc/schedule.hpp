@@ -47,9 +47,9 @@
 namespace mistra {
 
 // record marks (low three bits of an 8-byte-aligned LDS byte offset)
-constexpr uint32_t VM_D0_CONT = 1u;    // on d0: continuation record of the lane's previous record (same target): the
-                                       // accumulator is carried in a register (the kernel prefetches operands, so a reload of
-                                       // the target could overtake the previous record's store)
+constexpr uint32_t VM_D0_CONT = 1u;    // on d0: continuation record of the lane's previous record (same target); an executor
+                                       // that prefetches operands must carry the accumulator instead of reloading the target
+                                       // (the shipped one does not prefetch: measured no gain, the loop is issue-bound)
 constexpr uint32_t VM_D1_RCP = 1u;     // on d1: publish 1/result to aux instead of scaling by M[aux]
 constexpr uint32_t VM_D2_EOR = 1u;     // on d2 of every lane of a row: last row of this round for the wave -> barrier
 constexpr uint32_t VM_D2_NULL = 2u;    // on d2: the row carries no work (a wave with nothing to do in a round)
