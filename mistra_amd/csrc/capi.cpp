@@ -77,18 +77,16 @@ struct VmBufs {
 };
 
 struct GsBufs {
-  DevBuf<uint32_t> blk_base, idx;
+  DevBuf<uint32_t> wave_base, recs;
   DevBuf<uint16_t> blk_n;
-  DevBuf<float> coef;
   hipError_t upload(const GsumProgram& P) {
     hipError_t e;
-    if ((e = blk_base.upload(P.blk_base)) != hipSuccess) return e;
+    if ((e = wave_base.upload(P.wave_base)) != hipSuccess) return e;
     if ((e = blk_n.upload(P.blk_n)) != hipSuccess) return e;
-    if ((e = idx.upload(P.idx)) != hipSuccess) return e;
-    return coef.upload(P.coef);
+    return recs.upload(P.recs);
   }
-  GsDev dev() const { return GsDev{blk_base.p, blk_n.p, idx.p, coef.p}; }
-  void release() { blk_base.release(); idx.release(); blk_n.release(); coef.release(); }
+  GsDev dev() const { return GsDev{wave_base.p, blk_n.p, recs.p}; }
+  void release() { wave_base.release(); recs.release(); blk_n.release(); }
 };
 
 struct MechState {
@@ -152,9 +150,14 @@ int setup_mech(int mech) {
   const bool nt_ok = (mech == MISTRA_MECH_GAS && S.nt == 128) || (mech == MISTRA_MECH_AER && S.nt == 512) ||
                      (mech == MISTRA_MECH_TOT && (S.nt == 512 || S.nt == 1024));
   if (!nt_ok) return fail(std::string("no kernel instantiated for workgroup size ") + std::to_string(S.nt) + " of " + kMechName[mech]);
+  // LDS byte address of the A/B product array for this <mechanism, workgroup size> (the gather-sum tables hold addresses)
+  const uint32_t ab_base = 8u * (uint32_t)(mech == MISTRA_MECH_GAS   ? LdsLayout<GasTraits, 128>::AB
+                                           : mech == MISTRA_MECH_AER ? LdsLayout<AerTraits, 512>::AB
+                                           : S.nt == 1024           ? LdsLayout<TotTraits, 1024>::AB
+                                                                    : LdsLayout<TotTraits, 512>::AB);
   KernelSchedule K;
   try {
-    K = build_kernel_schedule(S.tab, S.nt);
+    K = build_kernel_schedule(S.tab, S.nt, ab_base);
   } catch (const std::exception& ex) {
     return fail(std::string("schedule compiler: ") + ex.what());
   }

@@ -11,11 +11,10 @@ struct VmDev {                 // LDS VM program in device memory (see schedule.
   int nrounds;
 };
 
-struct GsDev {                 // gather-sum program in device memory
-  const uint32_t* blk_base;
-  const uint16_t* blk_n;
-  const uint32_t* idx;
-  const float* coef;
+struct GsDev {                 // gather-sum program in device memory (see schedule.hpp)
+  const uint32_t* wave_base;   // [NW]     first row of each wave's stream
+  const uint16_t* blk_n;       // [NW*NQ]  rows per (wave, output block), multiples of 4
+  const uint32_t* recs;        // two uint4 per lane and row: 4 LDS byte addresses, 4 float coefficients
 };
 
 struct TailDev {               // tail chain of the triangular solves (schedule.hpp: TailSolve)

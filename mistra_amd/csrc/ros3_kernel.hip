@@ -27,10 +27,8 @@ constexpr uint32_t kD0Cont = 1u;
 constexpr uint32_t kD1Rcp = 1u;
 constexpr uint32_t kD2Eor = 1u, kD2Null = 2u, kD2Rcp = 4u;
 constexpr uint32_t kOffMask = ~7u;
-constexpr uint32_t kGsFirst = 1u << 16, kGsNop = 1u << 17;
 constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
 constexpr int kRingSlots = 8;  // 16-byte table loads in flight per lane (schedule.cpp appends 2x that many rows of slack)
-constexpr int kGsDepth = 4;    // gather-sum rows in flight per lane
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // plain vector types load from any address space
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -271,48 +269,51 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t 
   for (int r = 0; r < R; r++) lds_st(xb + 8 * (r * 64 + lane), x[r]);
 }
 
-// ---- the gather-sum machine: out[q] = c0*src[i0] + c1*src[i1] + ...  (left to right), four terms per table row,
-//      table loads kGsDepth rows ahead (same register-ring scheme as the VM)
+// ---- the gather-sum machine (schedule.hpp): out[q] = c0*M[i0] + c1*M[i1] + ...  left to right, four terms per table
+//      row, rows streamed through the AGPR ring (4 rows in flight).  acc starts at -0.0 and padding terms are
+//      (-0.0f)*(0.0 cell), so no flags are needed and the sums are bit-for-bit the flagged ones.
+template <int NQ>
+struct GsOut {
+  double v[NQ];
+};
+
 template <int NT, int NQ>
-__device__ __forceinline__ void gsum_run(const GsDev& P, const double* __restrict__ src, double (&out)[NQ], int wave, int lane) {
-  constexpr int NW = NT / 64;
+__device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev& P, int wave, int lane) {
+  GsOut<NQ> out;
+  int n[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) n[q] = __builtin_amdgcn_readfirstlane((int)G_(P.blk_n)[wave * NQ + q]);
+  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)G_(P.wave_base)[wave] * 64 + lane) * 2;
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
+  vm_ring_load<0>(rp);       vm_ring_load<1, 16>(rp);
+  vm_ring_load<2>(rp + 128); vm_ring_load<3, 16>(rp + 128);
+  vm_ring_load<4>(rp + 256); vm_ring_load<5, 16>(rp + 256);
+  vm_ring_load<6>(rp + 384); vm_ring_load<7, 16>(rp + 384);
+  rp += 4 * 128;
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
-    const int n = G_(P.blk_n)[q * NW + wave];
-    const size_t off = (size_t)G_(P.blk_base)[q * NW + wave] * 64 + lane;
-    gptr<u32x4> ip = G_(reinterpret_cast<const u32x4*>(P.idx)) + off;
-    gptr<f32x4> cp = G_(reinterpret_cast<const f32x4*>(P.coef)) + off;
-    u32x4 iq[kGsDepth];
-    f32x4 cq[kGsDepth];
-#pragma unroll
-    for (int k = 0; k < kGsDepth; k++) {
-      iq[k] = ip[k * 64];
-      cq[k] = cp[k * 64];
-    }
-    ip += kGsDepth * 64;
-    cp += kGsDepth * 64;
-    double acc = 0.0;
-    for (int g = 0; g < n; g += kGsDepth) {
-#pragma unroll
-      for (int k = 0; k < kGsDepth; k++) {
-        const u32x4 ci = iq[k];
-        const f32x4 cc = cq[k];
-        iq[k] = ip[k * 64];
-        cq[k] = cp[k * 64];
-        if (g + k < n) {
-          const double x0 = src[ci.x & 0xFFFFu], x1 = src[ci.y & 0xFFFFu], x2 = src[ci.z & 0xFFFFu], x3 = src[ci.w & 0xFFFFu];
-          const double t0 = (double)cc.x * x0, t1 = (double)cc.y * x1, t2 = (double)cc.z * x2, t3 = (double)cc.w * x3;
-          acc = (ci.x & kGsNop) ? acc : ((ci.x & kGsFirst) ? t0 : acc + t0);
-          acc = (ci.y & kGsNop) ? acc : acc + t1;
-          acc = (ci.z & kGsNop) ? acc : acc + t2;
-          acc = (ci.w & kGsNop) ? acc : acc + t3;
-        }
+    double acc = -0.0;
+    for (int i = 0; i < n[q]; i += 4) {
+#define MISTRA_GS_ROW(K)                                                             \
+      {                                                                              \
+        const u32x4 ad = vm_ring_take<2 * K, 6>();                                   \
+        const u32x4 cb = vm_ring_take<2 * K + 1, 6>();                               \
+        vm_ring_load<2 * K>(rp + K * 128);                                           \
+        vm_ring_load<2 * K + 1, 16>(rp + K * 128);                                   \
+        const double x0 = lds_ld(ad.x), x1 = lds_ld(ad.y), x2 = lds_ld(ad.z), x3 = lds_ld(ad.w); \
+        acc = acc + (double)__builtin_bit_cast(float, cb.x) * x0;                    \
+        acc = acc + (double)__builtin_bit_cast(float, cb.y) * x1;                    \
+        acc = acc + (double)__builtin_bit_cast(float, cb.z) * x2;                    \
+        acc = acc + (double)__builtin_bit_cast(float, cb.w) * x3;                    \
       }
-      ip += kGsDepth * 64;
-      cp += kGsDepth * 64;
+      MISTRA_GS_ROW(0) MISTRA_GS_ROW(1) MISTRA_GS_ROW(2) MISTRA_GS_ROW(3)
+#undef MISTRA_GS_ROW
+      rp += 4 * 128;
     }
-    out[q] = acc;
+    out.v[q] = acc;
   }
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // drain the look-ahead loads before returning
+  return out;
 }
 
 }  // namespace
@@ -389,7 +390,9 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       if ((w >> 48) & 1u) AB[q * NT + t] = p;
     }
     lds_barrier();
-    gsum_run<NT, SPT>(a.vdot, AB, out, wave, lane);
+    const GsOut<SPT> g = gsum_run<NT, SPT>(a.vdot, wave, lane);
+#pragma unroll
+    for (int q = 0; q < SPT; q++) out[q] = g.v[q];
   };
 
   // ---- Jac_SP_x (gas.f:2656) on the V already in X: B products under their reaction, JVS sums into registers
@@ -409,7 +412,9 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       }
     }
     lds_barrier();
-    gsum_run<NT, JPT>(a.jvs, AB, jac0, wave, lane);
+    const GsOut<JPT> g = gsum_run<NT, JPT>(a.jvs, wave, lane);
+#pragma unroll
+    for (int q = 0; q < JPT; q++) jac0[q] = g.v[q];
   };
 
   // ---- ros_PrepareMatrix_x (gas.f:1404), first half: Ghimj = -Jac0, diagonal += 1/(H*gamma).

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cassert>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <numeric>
 #include <stdexcept>
@@ -347,7 +348,8 @@ TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay) {
 
 // ---------------------------------------------------------------------------------------------------------------
 GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,
-                               const std::vector<int>& slot_of_output, int nq, int nt) {
+                               const std::vector<int>& slot_of_output, int nq, int nt, uint32_t src_base_bytes,
+                               uint32_t zero_cell_bytes) {
   GsumProgram P;
   P.nt = nt;
   P.nw = nt / 64;
@@ -358,22 +360,34 @@ GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, doub
     if (s < 0 || s >= nq * nt || output_of_slot[(size_t)s] >= 0) throw std::logic_error("bad gsum slot map");
     output_of_slot[(size_t)s] = (int)o;
   }
-  P.blk_base.assign((size_t)nq * P.nw, 0);
-  P.blk_n.assign((size_t)nq * P.nw, 0);
-  for (int q = 0; q < nq; q++)
-    for (int w = 0; w < P.nw; w++) {
+  P.wave_base.assign((size_t)P.nw, 0);
+  P.blk_n.assign((size_t)P.nw * nq, 0);
+  const float neg_zero = -0.0f;
+  uint32_t neg_zero_bits;
+  static_assert(sizeof neg_zero_bits == sizeof neg_zero, "float is 32 bits");
+  std::memcpy(&neg_zero_bits, &neg_zero, 4);
+  auto pad_row = [&]() {
+    for (int l = 0; l < 64; l++) {
+      for (int k = 0; k < 4; k++) P.recs.push_back(zero_cell_bytes);
+      for (int k = 0; k < 4; k++) P.recs.push_back(neg_zero_bits);
+    }
+  };
+  for (int w = 0; w < P.nw; w++) {
+    P.wave_base[(size_t)w] = (uint32_t)(P.recs.size() / 512);
+    for (int q = 0; q < nq; q++) {
       size_t n = 0;
       for (int l = 0; l < 64; l++) {
         int o = output_of_slot[(size_t)q * nt + w * 64 + l];
         if (o >= 0) n = std::max(n, outputs[(size_t)o].size());
       }
-      const size_t rows = (n + 3) / 4;          // groups of four terms
+      size_t rows = (n + 3) / 4;
+      rows = (rows + GS_ROW_ALIGN - 1) / GS_ROW_ALIGN * GS_ROW_ALIGN;
       if (rows > 0xFFFF) throw std::logic_error("gsum block too long");
-      P.blk_base[(size_t)q * P.nw + w] = (uint32_t)(P.idx.size() / 256);
-      P.blk_n[(size_t)q * P.nw + w] = (uint16_t)rows;
+      P.blk_n[(size_t)w * nq + q] = (uint16_t)rows;
       for (size_t r = 0; r < rows; r++)
         for (int l = 0; l < 64; l++) {
           int o = output_of_slot[(size_t)q * nt + w * 64 + l];
+          uint32_t addr[4], cbits[4];
           for (size_t k = 0; k < 4; k++) {
             size_t s = r * 4 + k;
             if (o >= 0 && s < outputs[(size_t)o].size()) {
@@ -381,30 +395,34 @@ GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, doub
               float cf = (float)term.second;
               if ((double)cf != term.second) throw std::logic_error("stoichiometric coefficient is not a float32 value");
               if (term.first < 0 || term.first > 0xFFFF) throw std::logic_error("gsum source index out of range");
-              P.idx.push_back((uint32_t)term.first | (s == 0 ? GS_FIRST : 0u));
-              P.coef.push_back(cf);
+              addr[k] = src_base_bytes + 8u * (uint32_t)term.first;
+              std::memcpy(&cbits[k], &cf, 4);
               P.n_terms++;
-            } else {
-              P.idx.push_back(GS_NOP);
-              P.coef.push_back(0.0f);
+            } else {            // exact identity: acc + (-0.0f * 0.0) = acc
+              addr[k] = zero_cell_bytes;
+              cbits[k] = neg_zero_bits;
             }
           }
+          for (int k = 0; k < 4; k++) P.recs.push_back(addr[k]);
+          for (int k = 0; k < 4; k++) P.recs.push_back(cbits[k]);
         }
       P.wave_rows += (int64_t)rows;
     }
-  // slack rows for the executor's look-ahead loads
-  for (int i = 0; i < 256 * VM_LOOKAHEAD_ROWS; i++) { P.idx.push_back(GS_NOP); P.coef.push_back(0.0f); }
+    for (int rr = 0; rr < VM_LOOKAHEAD_ROWS; rr++) pad_row();     // slack for the executor's look-ahead loads
+  }
   return P;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-KernelSchedule build_kernel_schedule(const MechTables& m, int nt) {
+KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes) {
   if (nt % 64 != 0 || nt <= 0 || nt > 1024) throw std::invalid_argument("nt must be a multiple of 64 in (0,1024]");
   if ((m.nnz + 2 * m.nvar + 3) * 8 > 160 * 1024) throw std::invalid_argument("mechanism too large for the LDS VM");
   if (m.nx() > 0xFFFF || m.nb >= 0xFFFF || m.nreact > 0xFFFF) throw std::invalid_argument("mechanism too large");
   KernelSchedule S;
   S.nt = nt;
   S.nw = nt / 64;
+  S.ab_base_bytes = ab_base_bytes;
+  const uint32_t zero_cell_bytes = 8u * (uint32_t)VmLayout{m.nnz, m.nvar}.zero();
   S.spt = ceil_div(m.nvar, nt);
   S.rpt = ceil_div(m.nreact, nt);
   const uint64_t one = (uint64_t)(m.nvar + m.nfix);       // X slot of the constant 1.0
@@ -425,7 +443,7 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt) {
       slot[(size_t)s] = s;
       for (int p = m.vd_ptr[s]; p < m.vd_ptr[s + 1]; p++) outs[(size_t)s].emplace_back(m.vd_idx[(size_t)p], m.vd_coef[(size_t)p]);
     }
-    S.vdot = build_gsum_program(outs, slot, S.spt, nt);
+    S.vdot = build_gsum_program(outs, slot, S.spt, nt, ab_base_bytes, zero_cell_bytes);
   }
 
   // ---- Jac_SP_x products, under the owning reaction
@@ -468,7 +486,7 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt) {
       for (int p = m.jv_ptr[k]; p < m.jv_ptr[k + 1]; p++) outs[i].emplace_back(m.jv_idx[(size_t)p], m.jv_coef[(size_t)p]);
       S.jvs_pos[(size_t)slot[i]] = (uint16_t)(k | (is_diag[(size_t)k] ? POS_DIAG : 0));
     }
-    S.jvs = build_gsum_program(outs, slot, S.jpt, nt);
+    S.jvs = build_gsum_program(outs, slot, S.jpt, nt, ab_base_bytes, zero_cell_bytes);
     S.zero_pos.assign((size_t)S.zpt * nt, POS_NONE);
     for (size_t i = 0; i < zero.size(); i++) S.zero_pos[i] = (uint16_t)(zero[i] | (is_diag[(size_t)zero[i]] ? POS_DIAG : 0));
   }

@@ -34,9 +34,12 @@
 //    the CPU test-suite measures what such re-associations do to the reference algorithm itself.
 //
 //  * the gather-sum machine ("gsum"): out = c0*src[i0] + c1*src[i1] + ... left to right, coefficient as float
-//    (every stoichiometric coefficient in the reference is a default-REAL literal or a small integer),
-//    stored as groups of four terms (one 16-byte index load + one 16-byte coefficient load per lane and group).
-//    It expresses the Vdot aggregation of Fun_x (gas.f:2395) and the JVS construction of Jac_SP_x (gas.f:3812).
+//    (every stoichiometric coefficient in the reference is a default-REAL literal or a small integer).
+//    A wave's table is one linear stream of 32-byte records (four absolute LDS byte addresses + four floats per lane
+//    and row), fetched through the same look-ahead ring as the VM; each output's rows are padded to a multiple of
+//    four with the exact identity term (-0.0f * M[0.0 cell]): acc starts at -0.0, so neither the first term nor the
+//    padding needs a flag.  It expresses the Vdot aggregation of Fun_x (gas.f:2395) and the JVS construction of
+//    Jac_SP_x (gas.f:3812) in the reference's term order.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -70,8 +73,7 @@ struct VmLayout {
   int size() const { return nnz + 2 * nvar + 3; }
 };
 
-constexpr uint32_t GS_FIRST = 1u << 16;
-constexpr uint32_t GS_NOP = 1u << 17;
+constexpr int GS_ROW_ALIGN = 4;         // an output's rows are padded to a multiple of this (= ring depth in rows)
 
 constexpr uint16_t POS_DIAG = 0x8000;   // flag on a Ghimj slot number: the slot is a diagonal
 constexpr uint16_t POS_NONE = 0xFFFF;
@@ -98,10 +100,9 @@ struct VmProgram {
 
 struct GsumProgram {
   int nt = 0, nw = 0, nq = 0;
-  std::vector<uint32_t> blk_base;               // [nq*nw]  first group row of (q, wave)
-  std::vector<uint16_t> blk_n;                  // [nq*nw]  group rows (4 terms per lane and row)
-  std::vector<uint32_t> idx;                    // [((blk_base + row)*64 + lane)*4 + k]  src index | GS_FIRST | GS_NOP
-  std::vector<float> coef;                      // same indexing
+  std::vector<uint32_t> wave_base;              // [nw]     first row of each wave's linear stream
+  std::vector<uint16_t> blk_n;                  // [nw*nq]  rows of output block q of wave w (multiple of GS_ROW_ALIGN, may be 0)
+  std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*8 + k]  k<4: LDS byte address, k>=4: float bits
   int64_t n_terms = 0, wave_rows = 0;
 };
 
@@ -124,6 +125,7 @@ struct KernelSchedule {
   int jpt = 0;   // structurally non-zero Jacobian entries per thread
   int zpt = 0;   // structurally zero (fill-in) entries per thread
   int n_jnz = 0, n_jzero = 0;
+  uint32_t ab_base_bytes = 0;
   // Fun_x products: A(r) = RCT(r)*X[f1]*X[f2]*X[f3], padded with the constant 1.0
   std::vector<uint64_t> fun_fac;                // [rpt*nt]  f1 | f2<<16 | f3<<32 | valid<<48
   GsumProgram vdot;                             // src = A (LDS), output (q,t) = species q*nt+t
@@ -145,8 +147,10 @@ std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, int h);
 std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, int h);
 TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay);
 GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,
-                               const std::vector<int>& slot_of_output, int nq, int nt);
-KernelSchedule build_kernel_schedule(const MechTables& m, int nt);
+                               const std::vector<int>& slot_of_output, int nq, int nt, uint32_t src_base_bytes,
+                               uint32_t zero_cell_bytes);
+// ab_base_bytes: LDS byte address of the A/B product array the gather-sum tables point into (ros3_kernel.hpp: LdsLayout)
+KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes);
 std::string describe(const KernelSchedule& s);
 
 }  // namespace mistra

@@ -93,26 +93,29 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
   return 0;
 }
 
-static void run_gsum(const GsumProgram& P, const std::vector<double>& src, std::vector<double>& out) {
+static void run_gsum(const GsumProgram& P, const std::vector<double>& src, uint32_t src_base, uint32_t zero_cell,
+                     std::vector<double>& out) {
   out.assign((size_t)P.nq * P.nt, 0.0);
-  for (int q = 0; q < P.nq; q++)
-    for (int w = 0; w < P.nw; w++) {
-      const uint32_t base = P.blk_base[(size_t)q * P.nw + w];
-      const int n = P.blk_n[(size_t)q * P.nw + w];
+  for (int w = 0; w < P.nw; w++) {
+    size_t row = P.wave_base[(size_t)w];
+    for (int q = 0; q < P.nq; q++) {
+      const int n = P.blk_n[(size_t)w * P.nq + q];
       for (int l = 0; l < 64; l++) {
-        double acc = 0.0;
+        double acc = -0.0;
         for (int ridx = 0; ridx < n; ridx++)
           for (int k = 0; k < 4; k++) {
-            const size_t at = (((size_t)base + ridx) * 64 + l) * 4 + k;
-            uint32_t word = P.idx[at];
-            float cf = P.coef[at];
-            if (word & GS_NOP) continue;
-            double t = (double)cf * src[word & 0xFFFF];
-            acc = (word & GS_FIRST) ? t : acc + t;
+            const size_t at = ((row + ridx) * 64 + l) * 8;
+            const uint32_t addr = P.recs[at + k];
+            float cf;
+            std::memcpy(&cf, &P.recs[at + 4 + k], 4);
+            const double x = addr == zero_cell ? 0.0 : src[(size_t)((addr - src_base) / 8)];
+            acc = acc + (double)cf * x;
           }
         out[(size_t)q * P.nt + w * 64 + l] = acc;
       }
+      row += (size_t)n;
     }
+  }
 }
 
 // The kernel's solve: head forward (VM) -> tail chain forward/backward (one wave, registers) -> head backward (VM).
@@ -166,7 +169,7 @@ void* emu_create(const char* mech_path, int nt) {
   std::string err;
   if (!e->m.load(mech_path, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); delete e; return nullptr; }
   try {
-    e->s = build_kernel_schedule(e->m, nt);
+    e->s = build_kernel_schedule(e->m, nt, 8u * (uint32_t)(VmLayout{e->m.nnz, e->m.nvar}.size() + 1000));   // any base will do here
   } catch (const std::exception& ex) {
     std::fprintf(stderr, "schedule: %s\n", ex.what());
     delete e;
@@ -237,7 +240,7 @@ void emu_fun(void* h, const double* V, const double* F, const double* RCT, doubl
       a = a * X[(w >> 32) & 0xFFFF];
       A[(size_t)r] = a;
     }
-  run_gsum(s.vdot, A, out);
+  run_gsum(s.vdot, A, s.ab_base_bytes, 8u * (uint32_t)e->lay().zero(), out);
   for (int i = 0; i < e->m.nvar; i++) Vdot[i] = out[(size_t)i];
 }
 
@@ -260,7 +263,7 @@ void emu_jac_prepare(void* h, const double* V, const double* F, const double* RC
         v = v * X[(w >> 32) & 0xFFFF];
         B[(size_t)out] = v;
       }
-  run_gsum(s.jvs, B, jac0);
+  run_gsum(s.jvs, B, s.ab_base_bytes, 8u * (uint32_t)e->lay().zero(), jac0);
   for (int i = 0; i < e->m.nnz; i++) G[i] = std::nan("");
   for (size_t i = 0; i < s.jvs_pos.size(); i++) {
     uint16_t p = s.jvs_pos[i];
