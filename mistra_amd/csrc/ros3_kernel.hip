@@ -301,10 +301,12 @@ __device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev& P, int wave
         vm_ring_load<2 * K>(rp + K * 128);                                           \
         vm_ring_load<2 * K + 1, 16>(rp + K * 128);                                   \
         const double x0 = lds_ld(ad.x), x1 = lds_ld(ad.y), x2 = lds_ld(ad.z), x3 = lds_ld(ad.w); \
-        acc = acc + (double)__builtin_bit_cast(float, cb.x) * x0;                    \
-        acc = acc + (double)__builtin_bit_cast(float, cb.y) * x1;                    \
-        acc = acc + (double)__builtin_bit_cast(float, cb.z) * x2;                    \
-        acc = acc + (double)__builtin_bit_cast(float, cb.w) * x3;                    \
+        /* scalars first: __builtin_bit_cast on a vector ELEMENT reads element 0 with this compiler */ \
+        const uint32_t cx = cb.x, cy = cb.y, cz = cb.z, cw = cb.w;                       \
+        acc = acc + (double)__uint_as_float(cx) * x0;                    \
+        acc = acc + (double)__uint_as_float(cy) * x1;                    \
+        acc = acc + (double)__uint_as_float(cz) * x2;                    \
+        acc = acc + (double)__uint_as_float(cw) * x3;                    \
       }
       MISTRA_GS_ROW(0) MISTRA_GS_ROW(1) MISTRA_GS_ROW(2) MISTRA_GS_ROW(3)
 #undef MISTRA_GS_ROW
