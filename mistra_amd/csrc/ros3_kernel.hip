@@ -356,6 +356,12 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     const int r = q * NT + t;
     rct[q] = r < NREACT ? G_(a.rconst)[(size_t)cell * NREACT + r] : 0.0;
   }
+  // Ghimj slots this thread fills in ros_PrepareMatrix (static per mechanism): fetched once, not once per attempt
+  uint32_t jpos[JPT], zpos[ZPT];
+#pragma unroll
+  for (int q = 0; q < JPT; q++) jpos[q] = G_(a.jvs_pos)[q * NT + t];
+#pragma unroll
+  for (int q = 0; q < ZPT; q++) zpos[q] = G_(a.zero_pos)[q * NT + t];
   if (t < NFIX) X[NVAR + t] = G_(a.fix)[(size_t)cell * NFIX + t];
   if (t < NCONST) X[NVAR + NFIX + t] = G_(a.consts)[t];
   if (t == 0) {   // the VM's constant cells: 0.0 (padding update slots) and 1.0 (neutral pivot factor)
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     bool zero_diag = false;
 #pragma unroll
     for (int q = 0; q < JPT; q++) {
-      const uint16_t p = G_(a.jvs_pos)[q * NT + t];
+      const uint32_t p = jpos[q];
       if (p != kPosNone) {
         double v = -jac0[q];
         if (p & kPosDiag) {
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     }
 #pragma unroll
     for (int q = 0; q < ZPT; q++) {
-      const uint16_t p = G_(a.zero_pos)[q * NT + t];
+      const uint32_t p = zpos[q];
       if (p != kPosNone) {
         double v = -0.0;
         if (p & kPosDiag) {

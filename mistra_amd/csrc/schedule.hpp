@@ -140,7 +140,7 @@ struct KernelSchedule {
   TailSolve tail;
 };
 
-VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 4);
+VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 2);
 std::vector<VmEntry> lu_entries(const MechTables& m);
 std::vector<VmEntry> solve_entries(const MechTables& m);
 std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, int h);
