@@ -91,7 +91,7 @@ struct GsBufs {
 
 struct MechState {
   bool ready = false;
-  int nt = 0;
+  int nt = 0, n_temps = 0;
   MechTables tab;
   std::string text;
   DevBuf<double> consts;
@@ -157,7 +157,8 @@ int setup_mech(int mech) {
                                                                     : LdsLayout<TotTraits, 512>::AB);
   KernelSchedule K;
   try {
-    K = build_kernel_schedule(S.tab, S.nt, ab_base);
+    const int max_temps = mech == MISTRA_MECH_GAS ? GasTraits::MAX_TEMPS : mech == MISTRA_MECH_AER ? AerTraits::MAX_TEMPS : TotTraits::MAX_TEMPS;
+    K = build_kernel_schedule(S.tab, S.nt, ab_base, max_temps);
   } catch (const std::exception& ex) {
     return fail(std::string("schedule compiler: ") + ex.what());
   }
@@ -166,6 +167,7 @@ int setup_mech(int mech) {
                                       : traits_match<TotTraits>(S.tab, K.n_jnz, K.tail.regs);
   if (!ok) return fail(std::string(kMechName[mech]) + ": mechanism table does not match the compiled kernel sizes");
   S.text = std::string(kMechName[mech]) + ": " + describe(K);
+  S.n_temps = K.n_temps;
   HIP_TRY(S.consts.upload(S.tab.consts));
   HIP_TRY(S.fun_fac.upload(K.fun_fac));
   HIP_TRY(S.jac_fac.upload(K.jac_fac));
@@ -199,7 +201,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* th) {
   KernelArgs a;
   a.var_in = var_in; a.fix = fix; a.rconst = rconst; a.var_out = var_out; a.ierr = ierr; a.stats = stats;
-  a.texit_hexit = th; a.prof = nullptr; a.tin = tin; a.tout = tout; a.ncell = ncell;
+  a.texit_hexit = th; a.prof = nullptr; a.n_temps = S.n_temps; a.tin = tin; a.tout = tout; a.ncell = ncell;
   a.consts = S.consts.p; a.fun_fac = S.fun_fac.p; a.jac_fac = S.jac_fac.p; a.jvs_pos = S.jvs_pos.p;
   a.zero_pos = S.zero_pos.p; a.diag_pos = S.diag_pos.p;
   a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev(); a.solve_head_fwd = S.solve_head_fwd.dev(); a.solve_head_bwd = S.solve_head_bwd.dev();

@@ -35,6 +35,7 @@ struct KernelArgs {
   unsigned long long* prof;    // [ncell][12] or null: shader-clock cycles per phase (diagnostics, see capi.cpp)
   double tin, tout;
   int32_t ncell;
+  int32_t n_temps;             // partial-sum cells the solve programs use (zeroed per solve)
   // mechanism schedule
   const double* consts;        // [NCONST]
   const uint64_t* fun_fac;

@@ -132,15 +132,15 @@ __device__ __forceinline__ bool vm_step(const u32x4 lo, const u32x4 hi, int& rou
     double acc = lds_ld(tgt);                 // lane's own store (LDS is in-order within a wave), nothing to carry
     const double a1 = lds_ld(lo.z & kOffMask), r1 = lds_ld(lo.w), u1 = lds_ld(hi.x);
     const double a2 = lds_ld(hi.y), r2 = lds_ld(hi.z), u2 = lds_ld(hi.w);
-    const double sc = lds_ld(lo.y & kOffMask);
     acc = acc - (a1 * r1) * u1;
     acc = acc - (a2 * r2) * u2;
-    if (row & kD2Rcp) {                                            // some lane of this row finalises a pivot
+    if (row & kD2Rcp) {                       // some lane of this row publishes a pivot reciprocal or scales by one
       const bool rcp = lo.y & kD1Rcp;
+      const double sc = lds_ld(lo.y & kOffMask);
       lds_st(tgt, rcp ? acc : acc * sc);
       if (rcp) lds_st(lo.y & kOffMask, 1.0 / acc);
-    } else {
-      lds_st(tgt, acc * sc);
+    } else {                                  // plain update record: the scale factor is the 1.0 cell, not even read
+      lds_st(tgt, acc);
     }
   }
   if (row & kD2Eor) {
@@ -364,9 +364,10 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
   for (int q = 0; q < ZPT; q++) zpos[q] = G_(a.zero_pos)[q * NT + t];
   if (t < NFIX) X[NVAR + t] = G_(a.fix)[(size_t)cell * NFIX + t];
   if (t < NCONST) X[NVAR + NFIX + t] = G_(a.consts)[t];
-  if (t == 0) {   // the VM's constant cells: 0.0 (padding update slots) and 1.0 (neutral pivot factor)
+  if (t == 0) {   // the VM's constant cells: 0.0 (padding update slots), 1.0 (neutral factor), -1.0 (partial-sum combine)
     M[NNZ + NVAR] = 0.0;
     M[NNZ + NVAR + 1] = 1.0;
+    M[NNZ + NVAR + 3] = -1.0;
   }
 
   // optional phase timing (diagnostics only): cycles of wave 0 between phase boundaries, summed per cell
@@ -467,12 +468,13 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       const int s = q * NT + t;
       if (s < NVAR) XS[s] = k[q];
     }
+    for (int i = t; i < a.n_temps; i += NT) M[NNZ + 2 * NVAR + 4 + i] = 0.0;       // partial-sum cells of the head sweeps
     lds_barrier();
     lap(6);
     vm_run<NT>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
     lap(8);
     if (wave == 0)                                                                         // tail chain, one wave
-      tail_solve<MT::TAIL_REGS>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 3 + NVAR - 64 * MT::TAIL_REGS), lane);
+      tail_solve<MT::TAIL_REGS>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
     lds_barrier();
     lap(9);
     vm_run<NT>(a.solve_head_bwd, wave, lane);

@@ -2,7 +2,8 @@
 // Sizes: gas_Parameters.h:28-49 | aer_Parameters.h:28-49 | tot_Parameters.h:28-49 (NVAR NFIX NREACT LU_NONZERO);
 // NB / NJNZ are counted from Jac_SP_x (number of B products / of JVS slots that are not `= 0`), NCONST from the
 // factor literals (1.0 padding + the 2 of squared reactants); TAIL_REGS*64 = rows of the solve's tail chain
-// (schedule.cpp: build_tail_solve).  The host checks the loaded table against these.
+// (schedule.cpp: build_tail_solve); MAX_TEMPS = partial-sum cells reserved for the head sweeps of the solves
+// (schedule.cpp: split_long_entries).  The host checks the loaded table against these.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -10,9 +11,9 @@
 
 namespace mistra {
 
-struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1; };
-struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2; };
-struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2; };
+struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 16; };
+struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2, MAX_TEMPS = 192; };
+struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2, MAX_TEMPS = 768; };
 
 constexpr int round_up2(int x) { return (x + 1) & ~1; }
 constexpr int max_i(int a, int b) { return a > b ? a : b; }
@@ -20,8 +21,8 @@ constexpr int max_i(int a, int b) { return a > b ? a : b; }
 // offsets in doubles into the dynamic LDS block
 template <class MT, int NT>
 struct LdsLayout {
-  static constexpr int M = 0;                                                          // Ghimj | XS | 0.0 | 1.0 | trash | R
-  static constexpr int X = M + round_up2(MT::NNZ + 2 * MT::NVAR + 3);                  // V | F | consts
+  static constexpr int M = 0;                                         // Ghimj | XS | 0.0 | 1.0 | trash | -1.0 | R | temps
+  static constexpr int X = M + round_up2(MT::NNZ + 2 * MT::NVAR + 4 + MT::MAX_TEMPS);  // V | F | consts
   static constexpr int AB = X + round_up2(MT::NVAR + MT::NFIX + MT::NCONST);           // A or B products
   static constexpr int RED = AB + round_up2(max_i(MT::NREACT, MT::NB));                // per-wave partial sums
   static constexpr int FLAGS = RED + 32;

@@ -189,7 +189,9 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
         uint32_t row_flags = (r == rows - 1 ? VM_D2_EOR : 0u) | (n == 0 ? VM_D2_NULL : 0u);
         for (int l = 0; l < 64; l++) {
           const auto& w = prog[(size_t)wv * 64 + l];
-          if (r * VM_REC_WORDS < w.size() && (w[r * VM_REC_WORDS + 1] & VM_D1_RCP)) row_flags |= VM_D2_RCP;
+          if (r * VM_REC_WORDS < w.size() &&
+              ((w[r * VM_REC_WORDS + 1] & VM_D1_RCP) || (w[r * VM_REC_WORDS + 1] & VM_OFF_MASK) != one_off))
+            row_flags |= VM_D2_RCP;      // the row needs its aux operand (reciprocal to publish, or a scale factor != 1.0)
         }
         for (int l = 0; l < 64; l++) {
           const auto& w = prog[(size_t)wv * 64 + l];
@@ -222,9 +224,8 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
 // both factors present, ascending j (the order in which the reference's kk/jj loops touch W(c)).  The multiplier is
 // taken as W(k,j)*R(j) from the unscaled slot (see schedule.hpp); pivots publish R(k) = 1/U(k,k) when final; phase 1
 // scales the L slots in place so that the solves find L(k,j) where the reference leaves it.
-std::vector<VmEntry> lu_entries(const MechTables& m) {
+std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay) {
   const int n = m.nvar;
-  const VmLayout lay{m.nnz, m.nvar};
   std::vector<VmEntry> out((size_t)m.nnz);
   std::vector<int> where((size_t)n, -1);    // column -> slot in the current row
   for (int k = 0; k < n; k++) {
@@ -256,11 +257,48 @@ std::vector<VmEntry> lu_entries(const MechTables& m) {
   return out;
 }
 
+// A long serial accumulation  x -= sum_k (a_k*r_k)*u_k  walked by ONE lane becomes the critical path of its rounds.
+// Entries with more than `threshold` updates are cut into partial sums of ~sqrt(n) terms, each accumulated from 0 in
+// its own temp cell (possibly by different lanes, in parallel), and combined:  x -= (T_p * 1.0) * (-1.0).
+// Same terms, different association.  Returns the number of temp cells used from `first_temp` on.
+int split_long_entries(std::vector<VmEntry>& entries, const VmLayout& lay, int threshold, int first_temp) {
+  std::vector<VmEntry> out;
+  int used = 0;
+  for (VmEntry& E : entries) {
+    const int n = (int)E.upd.size();
+    if (n <= threshold) {
+      out.push_back(std::move(E));
+      continue;
+    }
+    int S = 2;
+    while (S * S < n) S += 2;                 // even part length ~ sqrt(n): whole two-update records
+    VmEntry comb;
+    comb.tgt = E.tgt;
+    comb.mulr = E.mulr;
+    comb.rcp = E.rcp;
+    comb.phase = E.phase;
+    comb.keep_order = true;
+    for (int lo = 0; lo < n; lo += S) {
+      if (first_temp + used >= lay.max_temps) throw std::logic_error("out of VM temp cells (raise MAX_TEMPS of the mechanism)");
+      VmEntry part;
+      part.tgt = lay.temp(first_temp + used);
+      used++;
+      part.phase = E.phase;
+      part.keep_order = E.keep_order;
+      part.upd.assign(E.upd.begin() + lo, E.upd.begin() + std::min(n, lo + S));
+      comb.upd.push_back({part.tgt, lay.one(), lay.minus_one()});
+      out.push_back(std::move(part));
+    }
+    out.push_back(std::move(comb));
+  }
+  entries.swap(out);
+  return used;
+}
+
 // KppSolve_x (gas.f:6206-6608) as one program: phase 0 forward sweep with unit L, phase 1 backward sweep.
 // X lives behind Ghimj in VM memory.  (Kept for tests; the kernel runs the head/tail split below.)
-std::vector<VmEntry> solve_entries(const MechTables& m) {
+std::vector<VmEntry> solve_entries(const MechTables& m, const VmLayout& lay) {
   const int n = m.nvar;
-  const VmLayout lay{m.nnz, m.nvar};
   std::vector<VmEntry> out;
   for (int i = 0; i < n; i++) {
     if (m.diag[i] == m.crow[i]) continue;
@@ -284,9 +322,8 @@ std::vector<VmEntry> solve_entries(const MechTables& m) {
 
 // Forward sweep split at row h: head rows completely, tail rows only their head-column terms (the leading terms of the
 // reference's ascending-column order); the tail chain then subtracts the tail-column terms, again ascending.
-std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, int h) {
+std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, const VmLayout& lay, int h) {
   const int n = m.nvar;
-  const VmLayout lay{m.nnz, m.nvar};
   std::vector<VmEntry> out;
   for (int i = 0; i < n; i++) {
     VmEntry E;
@@ -300,8 +337,7 @@ std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, int h) {
 }
 
 // Backward sweep of the head rows, the tail part of X being final already.
-std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, int h) {
-  const VmLayout lay{m.nnz, m.nvar};
+std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, const VmLayout& lay, int h) {
   std::vector<VmEntry> out;
   for (int i = h - 1; i >= 0; i--) {
     VmEntry E;
@@ -414,15 +450,16 @@ GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, doub
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes) {
+KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes, int max_temps) {
   if (nt % 64 != 0 || nt <= 0 || nt > 1024) throw std::invalid_argument("nt must be a multiple of 64 in (0,1024]");
-  if ((m.nnz + 2 * m.nvar + 3) * 8 > 160 * 1024) throw std::invalid_argument("mechanism too large for the LDS VM");
+  if (VmLayout{m.nnz, m.nvar, max_temps}.size() * 8 > 160 * 1024) throw std::invalid_argument("mechanism too large for the LDS VM");
   if (m.nx() > 0xFFFF || m.nb >= 0xFFFF || m.nreact > 0xFFFF) throw std::invalid_argument("mechanism too large");
   KernelSchedule S;
   S.nt = nt;
   S.nw = nt / 64;
   S.ab_base_bytes = ab_base_bytes;
-  const uint32_t zero_cell_bytes = 8u * (uint32_t)VmLayout{m.nnz, m.nvar}.zero();
+  const VmLayout lay{m.nnz, m.nvar, max_temps};                         // M = [Ghimj | XS | 0.0 | 1.0 | trash | -1.0 | R | temps]
+  const uint32_t zero_cell_bytes = 8u * (uint32_t)lay.zero();
   S.spt = ceil_div(m.nvar, nt);
   S.rpt = ceil_div(m.nreact, nt);
   const uint64_t one = (uint64_t)(m.nvar + m.nfix);       // X slot of the constant 1.0
@@ -493,12 +530,16 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   S.diag_pos.assign((size_t)S.spt * nt, POS_NONE);
   for (int s = 0; s < m.nvar; s++) S.diag_pos[(size_t)s] = (uint16_t)m.diag[(size_t)s];
 
-  const VmLayout lay{m.nnz, m.nvar};                                    // M = [Ghimj | XS | 0.0 | 1.0 | R]
-  S.lu = build_vm_program(lu_entries(m), lay, nt);
-  S.solve = build_vm_program(solve_entries(m), lay, nt);
+  S.lu = build_vm_program(lu_entries(m, lay), lay, nt);
+  S.solve = build_vm_program(solve_entries(m, lay), lay, nt);
   S.tail = build_tail_solve(m, lay);
-  S.solve_head_fwd = build_vm_program(solve_head_fwd_entries(m, S.tail.h), lay, nt);
-  S.solve_head_bwd = build_vm_program(solve_head_bwd_entries(m, S.tail.h), lay, nt);
+  {
+    std::vector<VmEntry> fwd = solve_head_fwd_entries(m, lay, S.tail.h), bwd = solve_head_bwd_entries(m, lay, S.tail.h);
+    S.n_temps = split_long_entries(fwd, lay, 6, 0);
+    S.n_temps += split_long_entries(bwd, lay, 6, S.n_temps);
+    S.solve_head_fwd = build_vm_program(std::move(fwd), lay, nt);
+    S.solve_head_bwd = build_vm_program(std::move(bwd), lay, nt);
+  }
   return S;
 }
 
@@ -508,12 +549,12 @@ std::string describe(const KernelSchedule& s) {
                 "nt=%d spt=%d rpt=%d jpt=%d zpt=%d | vdot: %lld terms, %lld wave-rows | jvs: %lld terms, %lld wave-rows | "
                 "LU: %d rounds, %lld updates in %lld items / %lld records, %lld wave-rows, critical %lld | "
                 "solve: tail %d rows in registers of one wave; head fwd %d rounds / %lld rows critical, head bwd %d rounds / %lld rows "
-                "critical (whole solve as one VM program: %d rounds, %lld updates, %lld records, critical %lld)",
+                "critical, %d partial-sum cells (whole solve as one VM program: %d rounds, %lld updates, %lld records, critical %lld)",
                 s.nt, s.spt, s.rpt, s.jpt, s.zpt, (long long)s.vdot.n_terms, (long long)s.vdot.wave_rows,
                 (long long)s.jvs.n_terms, (long long)s.jvs.wave_rows, s.lu.nrounds, (long long)s.lu.n_updates,
                 (long long)s.lu.n_items, (long long)s.lu.n_records, (long long)s.lu.wave_rows, (long long)s.lu.crit_rows,
                 s.tail.m, s.solve_head_fwd.nrounds, (long long)s.solve_head_fwd.crit_rows, s.solve_head_bwd.nrounds,
-                (long long)s.solve_head_bwd.crit_rows, s.solve.nrounds, (long long)s.solve.n_updates, (long long)s.solve.n_records,
+                (long long)s.solve_head_bwd.crit_rows, s.n_temps, s.solve.nrounds, (long long)s.solve.n_updates, (long long)s.solve.n_records,
                 (long long)s.solve.crit_rows);
   return buf;
 }

@@ -3,7 +3,8 @@
 //
 // Two tiny "machines" run inside the kernel, both over LDS-resident data:
 //
-//  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) | 0.0 | 1.0 | trash | R (nvar) ], R(k) = 1/U(k,k).
+//  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) | 0.0 | 1.0 | trash | -1.0 | R (nvar) | temps ],
+//    R(k) = 1/U(k,k).
 //    A program is a list of rounds separated by workgroup barriers; inside a round every lane walks its own list of
 //    fixed 32-byte RECORDS whose fields are LDS byte offsets.  Records are self-contained (no state carried from one
 //    to the next, no per-lane flags to decode):
@@ -30,7 +31,9 @@
 //    dependency depth from ~9600 serial updates (tot) to ~100 rounds.
 //    Triangular sweeps of KppSolve_x (gas.f:6206): updates are (L(i,j), 1.0, X(j)); the backward sweep multiplies by
 //    R(i) instead of dividing and applies its terms in readiness order (keep_order = false: the reference subtracts
-//    U(i,c)*X(c) for ASCENDING c while the X(c) become known in DESCENDING c).  Same terms, round-off level changes;
+//    U(i,c)*X(c) for ASCENDING c while the X(c) become known in DESCENDING c).  Long dot products of the head sweeps
+//    (a tail row has up to 42 head-column terms) are cut into partial sums over the temp cells and combined
+//    (split_long_entries) so that no lane walks them serially.  Same terms, round-off level changes;
 //    the CPU test-suite measures what such re-associations do to the reference algorithm itself.
 //
 //  * the gather-sum machine ("gsum"): out = c0*src[i0] + c1*src[i1] + ... left to right, coefficient as float
@@ -56,7 +59,8 @@ constexpr uint32_t VM_D0_CONT = 1u;    // on d0: continuation record of the lane
 constexpr uint32_t VM_D1_RCP = 1u;     // on d1: publish 1/result to aux instead of scaling by M[aux]
 constexpr uint32_t VM_D2_EOR = 1u;     // on d2 of every lane of a row: last row of this round for the wave -> barrier
 constexpr uint32_t VM_D2_NULL = 2u;    // on d2: the row carries no work (a wave with nothing to do in a round)
-constexpr uint32_t VM_D2_RCP = 4u;     // on d2 of every lane of a row: some lane of the row publishes a reciprocal
+constexpr uint32_t VM_D2_RCP = 4u;     // on d2 of every lane of a row: some lane of the row publishes a reciprocal OR scales by
+                                       // M[aux] != 1.0 cell; rows without the mark skip the aux read and the final multiply
 constexpr uint32_t VM_OFF_MASK = ~7u;
 constexpr int VM_REC_WORDS = 8;
 constexpr int VM_UPD_PER_REC = 2;
@@ -64,13 +68,15 @@ constexpr int VM_LOOKAHEAD_ROWS = 16;    // >= 2x the kernel's table look-ahead 
 
 // VM memory map for a mechanism with nnz LU slots and nvar species
 struct VmLayout {
-  int nnz = 0, nvar = 0;
+  int nnz = 0, nvar = 0, max_temps = 0;         // max_temps: partial-sum cells reserved behind R (ros3_kernel.hpp: MAX_TEMPS)
   int xs(int i = 0) const { return nnz + i; }
   int zero() const { return nnz + nvar; }
   int one() const { return nnz + nvar + 1; }
   int trash() const { return nnz + nvar + 2; }
-  int rdiag(int k = 0) const { return nnz + nvar + 3 + k; }
-  int size() const { return nnz + 2 * nvar + 3; }
+  int minus_one() const { return nnz + nvar + 3; }
+  int rdiag(int k = 0) const { return nnz + nvar + 4 + k; }
+  int temp(int t = 0) const { return nnz + 2 * nvar + 4 + t; }      // partial-sum cells, zeroed before each solve
+  int size() const { return nnz + 2 * nvar + 4 + max_temps; }
 };
 
 constexpr int GS_ROW_ALIGN = 4;         // an output's rows are padded to a multiple of this (= ring depth in rows)
@@ -137,20 +143,22 @@ struct KernelSchedule {
   std::vector<uint16_t> diag_pos;               // [spt*nt] Ghimj slot of (s,s), POS_NONE past nvar
   VmProgram lu, solve;                          // solve = the whole of KppSolve_x as one VM program (kept for tests)
   VmProgram solve_head_fwd, solve_head_bwd;     // head rows (+ head-column part of tail rows) around the tail chain
+  int n_temps = 0;                              // temp cells the two head programs use (zeroed by the kernel per solve)
   TailSolve tail;
 };
 
 VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 2);
-std::vector<VmEntry> lu_entries(const MechTables& m);
-std::vector<VmEntry> solve_entries(const MechTables& m);
-std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, int h);
-std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, int h);
+std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay);
+int split_long_entries(std::vector<VmEntry>& entries, const VmLayout& lay, int threshold, int first_temp);
+std::vector<VmEntry> solve_entries(const MechTables& m, const VmLayout& lay);
+std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, const VmLayout& lay, int h);
+std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, const VmLayout& lay, int h);
 TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay);
 GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,
                                const std::vector<int>& slot_of_output, int nq, int nt, uint32_t src_base_bytes,
                                uint32_t zero_cell_bytes);
 // ab_base_bytes: LDS byte address of the A/B product array the gather-sum tables point into (ros3_kernel.hpp: LdsLayout)
-KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes);
+KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes, int max_temps);
 std::string describe(const KernelSchedule& s);
 
 }  // namespace mistra

@@ -19,15 +19,18 @@ struct Emu {
   MechTables m;
   KernelSchedule s;
   std::string text;
-  VmLayout lay() const { return VmLayout{m.nnz, m.nvar}; }
+  static constexpr int kMaxTemps = 768;
+  VmLayout lay() const { return VmLayout{m.nnz, m.nvar, kMaxTemps}; }
   std::vector<double> fresh_m() const {
     std::vector<double> M((size_t)lay().size(), 0.0);
     M[(size_t)lay().one()] = 1.0;
+    M[(size_t)lay().minus_one()] = -1.0;
     return M;
   }
 };
 
 static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
+  const int one_cell = trash - 1;      // VmLayout: ... | 0.0 | 1.0 | trash | -1.0 | R | temps
   const int nt = P.nt;
   std::vector<int> writer(M.size());
   std::vector<uint32_t> row_of_wave((size_t)P.nw, 0);
@@ -78,9 +81,11 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
             if (wr(aux, 1.0 / acc)) return -2;
             carry = acc;
           } else {
-            const double sc = rd(rec[1]);
-            if (wr(tgt, acc * sc)) return -2;
-            carry = acc * sc;
+            double res = acc;
+            if (rec[2] & VM_D2_RCP) res = acc * rd(rec[1]);        // rows without the mark skip the (then 1.0) factor
+            else if ((int)((rec[1] & VM_OFF_MASK) >> 3) != one_cell) return -9;   // unmarked row with a real scale factor
+            if (wr(tgt, res)) return -2;
+            carry = res;
           }
         }
         if (own_raw) return -8;
@@ -169,7 +174,7 @@ void* emu_create(const char* mech_path, int nt) {
   std::string err;
   if (!e->m.load(mech_path, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); delete e; return nullptr; }
   try {
-    e->s = build_kernel_schedule(e->m, nt, 8u * (uint32_t)(VmLayout{e->m.nnz, e->m.nvar}.size() + 1000));   // any base will do here
+    e->s = build_kernel_schedule(e->m, nt, 8u * (uint32_t)(e->lay().size() + 1000), Emu::kMaxTemps);   // any base will do here
   } catch (const std::exception& ex) {
     std::fprintf(stderr, "schedule: %s\n", ex.what());
     delete e;
@@ -287,6 +292,23 @@ void emu_jac_prepare(void* h, const double* V, const double* F, const double* RC
 extern "C" int emu_round_profile(void* h, int which, int* crit, int* total, int cap) {
   Emu* e = (Emu*)h;
   const VmProgram& P = which ? e->s.solve : e->s.lu;
+  for (int r = 0; r < P.nrounds && r < cap; r++) {
+    int c = 0, t = 0;
+    for (int w = 0; w < P.nw; w++) {
+      int n = P.blk_n[(size_t)r * P.nw + w];
+      c = n > c ? n : c;
+      t += n;
+    }
+    crit[r] = c;
+    total[r] = t;
+  }
+  return P.nrounds;
+}
+
+// per-round profile of the head-sweep programs (which: 0 = head forward, 1 = head backward)
+extern "C" int emu_head_profile(void* h, int which, int* crit, int* total, int cap) {
+  Emu* e = (Emu*)h;
+  const VmProgram& P = which ? e->s.solve_head_bwd : e->s.solve_head_fwd;
   for (int r = 0; r < P.nrounds && r < cap; r++) {
     int c = 0, t = 0;
     for (int w = 0; w < P.nw; w++) {
