@@ -23,8 +23,10 @@ namespace mistra {
 namespace {
 
 // LDS VM record fields (schedule.hpp): LDS byte offsets with flags in the three alignment bits
-constexpr uint32_t kW0Rcp = 1u << 29, kW0Eor = 1u << 30, kW0Null = 1u << 31, kW1RowAux = 1u << 28;
-constexpr uint32_t kIdxMask8 = 0x3FFFu << 3;     // a 14-bit cell index times 8 = LDS byte address of the cell
+constexpr uint32_t kD0Cont = 1u;
+constexpr uint32_t kD1Rcp = 1u;
+constexpr uint32_t kD2Eor = 1u, kD2Null = 2u, kD2Rcp = 4u;
+constexpr uint32_t kOffMask = ~7u;
 constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
 constexpr int kRingSlots = 8;  // 16-byte table loads in flight per lane (schedule.cpp appends 2x that many rows of slack)
 
@@ -121,32 +123,27 @@ __device__ __forceinline__ u32x4 vm_ring_take() {
 }
 static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots");
 
-// One 16-byte record of the LDS VM (schedule.hpp): eight 14-bit cell indices.  M starts at LDS address 0 (checked at
-// kernel entry), so index*8 is the cell's LDS address.  Returns true when the program's last round has been closed.
-__device__ __forceinline__ uint32_t vm_lo(uint32_t w) { return (w << 3) & kIdxMask8; }     // field in bits 0..13
-__device__ __forceinline__ uint32_t vm_hi(uint32_t w) { return (w >> 11) & kIdxMask8; }    // field in bits 14..27
-
-__device__ __forceinline__ bool vm_step(const u32x4 rec, int& rounds_left) {
-  const uint32_t row0 = __builtin_amdgcn_readfirstlane(rec.x);     // row marks are identical in all lanes
-  if (!(row0 & kW0Null)) {
-    const uint32_t tgt = vm_lo(rec.x);        // a continuation record simply reloads what the lane's previous record
-    double acc = lds_ld(tgt);                 // stored (LDS is in-order within a wave)
-    const double a1 = lds_ld(vm_lo(rec.y)), r1 = lds_ld(vm_hi(rec.y)), u1 = lds_ld(vm_lo(rec.z));
-    const double a2 = lds_ld(vm_hi(rec.z)), r2 = lds_ld(vm_lo(rec.w)), u2 = lds_ld(vm_hi(rec.w));
+// One record of the LDS VM (schedule.hpp).  M starts at LDS address 0 (checked at kernel entry), so the record's byte
+// offsets are LDS addresses as they stand.  Returns true when the program's last round has been closed.
+__device__ __forceinline__ bool vm_step(const u32x4 lo, const u32x4 hi, int& rounds_left) {
+  const uint32_t row = __builtin_amdgcn_readfirstlane(lo.z);       // row marks are identical in all lanes
+  if (!(row & kD2Null)) {
+    const uint32_t tgt = lo.x & kOffMask;     // bit 0 marks a continuation record: here the reload simply follows the
+    double acc = lds_ld(tgt);                 // lane's own store (LDS is in-order within a wave), nothing to carry
+    const double a1 = lds_ld(lo.z & kOffMask), r1 = lds_ld(lo.w), u1 = lds_ld(hi.x);
+    const double a2 = lds_ld(hi.y), r2 = lds_ld(hi.z), u2 = lds_ld(hi.w);
     acc = acc - (a1 * r1) * u1;
     acc = acc - (a2 * r2) * u2;
-    const uint32_t row1 = __builtin_amdgcn_readfirstlane(rec.y);
-    if (row1 & kW1RowAux) {                   // some lane of this row publishes a pivot reciprocal or scales by one
-      const bool rcp = rec.x & kW0Rcp;
-      const uint32_t aux = vm_hi(rec.x);
-      const double sc = lds_ld(aux);
+    if (row & kD2Rcp) {                       // some lane of this row publishes a pivot reciprocal or scales by one
+      const bool rcp = lo.y & kD1Rcp;
+      const double sc = lds_ld(lo.y & kOffMask);
       lds_st(tgt, rcp ? acc : acc * sc);
-      if (rcp) lds_st(aux, 1.0 / acc);
+      if (rcp) lds_st(lo.y & kOffMask, 1.0 / acc);
     } else {                                  // plain update record: the scale factor is the 1.0 cell, not even read
       lds_st(tgt, acc);
     }
   }
-  if (row0 & kW0Eor) {
+  if (row & kD2Eor) {
     lds_barrier();
     return --rounds_left == 0;
   }
@@ -155,24 +152,27 @@ __device__ __forceinline__ bool vm_step(const u32x4 rec, int& rounds_left) {
 
 template <int NT>
 __device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int lane) {
-  // 8 records (one 16-byte load each) in flight per lane
-  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + (size_t)G_(P.wave_base)[wave] * 64 + lane;
-  int rounds_left = __builtin_amdgcn_readfirstlane(P.nrounds);
+  // a record is two 16-byte halves: 4 records (8 loads) in flight per lane
+  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)G_(P.wave_base)[wave] * 64 + lane) * 2;
+  int rounds_left = P.nrounds;
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
-  vm_ring_load<0>(rp);       vm_ring_load<1>(rp + 64);  vm_ring_load<2>(rp + 128); vm_ring_load<3>(rp + 192);
-  vm_ring_load<4>(rp + 256); vm_ring_load<5>(rp + 320); vm_ring_load<6>(rp + 384); vm_ring_load<7>(rp + 448);
-  rp += kRingSlots * 64;
+  vm_ring_load<0>(rp);       vm_ring_load<1, 16>(rp);
+  vm_ring_load<2>(rp + 128); vm_ring_load<3, 16>(rp + 128);
+  vm_ring_load<4>(rp + 256); vm_ring_load<5, 16>(rp + 256);
+  vm_ring_load<6>(rp + 384); vm_ring_load<7, 16>(rp + 384);
+  rp += 4 * 128;
   while (rounds_left > 0) {
 #define MISTRA_VM_SLOT(K)                                                \
     {                                                                    \
-      const u32x4 rec = vm_ring_take<K>();     /* the oldest of 8 loads has landed */ \
-      vm_ring_load<K>(rp + K * 64);                                      \
-      if (vm_step(rec, rounds_left)) break;                              \
+      const u32x4 lo = vm_ring_take<2 * K, 6>();      /* the two oldest of 8 loads have landed */ \
+      const u32x4 hi = vm_ring_take<2 * K + 1, 6>();                      \
+      vm_ring_load<2 * K>(rp + K * 128);                                 \
+      vm_ring_load<2 * K + 1, 16>(rp + K * 128);                         \
+      if (vm_step(lo, hi, rounds_left)) break;                           \
     }
     MISTRA_VM_SLOT(0) MISTRA_VM_SLOT(1) MISTRA_VM_SLOT(2) MISTRA_VM_SLOT(3)
-    MISTRA_VM_SLOT(4) MISTRA_VM_SLOT(5) MISTRA_VM_SLOT(6) MISTRA_VM_SLOT(7)
 #undef MISTRA_VM_SLOT
-    rp += kRingSlots * 64;
+    rp += 4 * 128;
   }
   // drain: the look-ahead loads must have landed before this function returns
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");

@@ -18,19 +18,9 @@ struct Item {            // one chunk of one entry inside one round
   bool final;            // completes the entry: apply MULR / RCP
 };
 
-struct VmRec {           // one record before packing
-  int tgt, aux, a1, r1, u1, a2, r2, u2;
-  bool cont, rcp;
-};
-
-void vm_pack(const VmRec& r, uint32_t row_w0, uint32_t row_w1, std::vector<uint32_t>& out) {
-  const int f[8] = {r.tgt, r.aux, r.a1, r.r1, r.u1, r.a2, r.r2, r.u2};
-  for (int v : f)
-    if (v < 0 || (uint32_t)v > VM_IDX_MASK) throw std::logic_error("VM index out of the 14-bit range");
-  out.push_back((uint32_t)r.tgt | ((uint32_t)r.aux << VM_IDX_BITS) | (r.cont ? VM_W0_CONT : 0u) | (r.rcp ? VM_W0_RCP : 0u) | row_w0);
-  out.push_back((uint32_t)r.a1 | ((uint32_t)r.r1 << VM_IDX_BITS) | row_w1);
-  out.push_back((uint32_t)r.u1 | ((uint32_t)r.a2 << VM_IDX_BITS));
-  out.push_back((uint32_t)r.r2 | ((uint32_t)r.u2 << VM_IDX_BITS));
+uint32_t vm_off(int idx, uint32_t flags) {
+  if (idx < 0 || idx >= (1 << 20)) throw std::logic_error("VM index out of range");
+  return ((uint32_t)idx << 3) | flags;
 }
 
 // Snake-deal n work items (already sorted by decreasing cost) over lanes; small sets are packed into few waves.
@@ -138,40 +128,51 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
   P.blk_n.assign((size_t)P.nrounds * P.nw, 0);
   // per-wave linear record streams: stream[w] = rows of 64 records of VM_REC_WORDS words
   std::vector<std::vector<uint32_t>> stream((size_t)P.nw);
-  const int Z = zero_slot, ONE = lay.one();
-  const VmRec idle{lay.trash(), ONE, Z, Z, Z, Z, Z, Z, false, false};     // reads the 0.0 cell, writes the trash cell
+  const uint32_t zoff = vm_off(zero_slot, 0);
+  const uint32_t one_off = vm_off(lay.one(), 0), trash_off = vm_off(lay.trash(), 0);
+  auto idle_record = [&](std::vector<uint32_t>& out, uint32_t row_flags) {
+    out.push_back(trash_off);
+    out.push_back(one_off);
+    out.push_back(zoff | row_flags);
+    for (int q = 3; q < VM_REC_WORDS; q++) out.push_back(zoff);
+  };
   int ridx = 0;
   for (auto& kv : rounds) {
     std::vector<Item>& items = kv.second;
     auto nrec = [](const Item& it) { return std::max(1, (it.count + VM_UPD_PER_REC - 1) / VM_UPD_PER_REC); };
     std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return nrec(a) > nrec(b); });
     std::vector<int> lane = deal((int)items.size(), nt);
-    std::vector<std::vector<VmRec>> prog((size_t)nt);
+    std::vector<std::vector<uint32_t>> prog((size_t)nt);     // VM_REC_WORDS words per record
     for (size_t k = 0; k < items.size(); k++) {
       const Item& it = items[k];
       const VmEntry& E = entries[(size_t)it.entry];
-      std::vector<VmRec>& w = prog[(size_t)lane[k]];
+      std::vector<uint32_t>& w = prog[(size_t)lane[k]];
       const int nr = nrec(it);
       for (int r = 0; r < nr; r++) {
-        VmRec R = idle;
-        R.tgt = E.tgt;
-        R.cont = r > 0;
-        if (r == nr - 1 && it.final) {
-          if (E.mulr >= 0) R.aux = E.mulr;
+        const bool last_rec = r == nr - 1;
+        uint32_t f1 = 0;
+        int aux = lay.one();
+        if (last_rec && it.final) {
+          if (E.mulr >= 0) aux = E.mulr;
           if (E.rcp >= 0) {
             if (E.mulr >= 0) throw std::logic_error("an entry cannot both scale and publish a reciprocal");
-            R.rcp = true;
-            R.aux = E.rcp;
+            f1 = VM_D1_RCP;
+            aux = E.rcp;
           }
         }
+        w.push_back(vm_off(E.tgt, r > 0 ? VM_D0_CONT : 0u));
+        w.push_back(vm_off(aux, f1));
         for (int u = 0; u < VM_UPD_PER_REC; u++) {
           int i = r * VM_UPD_PER_REC + u;
-          if (i >= it.count) break;
-          const VmUpd& up = E.upd[(size_t)(it.first + i)];
-          if (u == 0) { R.a1 = up.a; R.r1 = up.r; R.u1 = up.u; }
-          else { R.a2 = up.a; R.r2 = up.r; R.u2 = up.u; }
+          if (i < it.count) {
+            const VmUpd& up = E.upd[(size_t)(it.first + i)];
+            w.push_back(vm_off(up.a, 0));
+            w.push_back(vm_off(up.r, 0));
+            w.push_back(vm_off(up.u, 0));
+          } else {
+            w.push_back(zoff); w.push_back(zoff); w.push_back(zoff);
+          }
         }
-        w.push_back(R);
       }
       P.n_updates += it.count;
       P.n_items++;
@@ -180,19 +181,25 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
     int crit = 0;
     for (int wv = 0; wv < P.nw; wv++) {
       size_t n = 0;
-      for (int l = 0; l < 64; l++) n = std::max(n, prog[(size_t)wv * 64 + l].size());
+      for (int l = 0; l < 64; l++) n = std::max(n, prog[(size_t)wv * 64 + l].size() / VM_REC_WORDS);
       if (n > 0xFFFF) throw std::logic_error("VM block too long");
       const size_t rows = std::max<size_t>(n, 1);       // a wave with no work still gets a null row carrying the round mark
       P.blk_n[(size_t)ridx * P.nw + wv] = (uint16_t)rows;
       for (size_t r = 0; r < rows; r++) {
-        uint32_t row_w0 = (r == rows - 1 ? VM_W0_EOR : 0u) | (n == 0 ? VM_W0_NULL : 0u), row_w1 = 0;
+        uint32_t row_flags = (r == rows - 1 ? VM_D2_EOR : 0u) | (n == 0 ? VM_D2_NULL : 0u);
         for (int l = 0; l < 64; l++) {
           const auto& w = prog[(size_t)wv * 64 + l];
-          if (r < w.size() && (w[r].rcp || w[r].aux != ONE)) row_w1 = VM_W1_ROWAUX;   // the row needs its aux operand
+          if (r * VM_REC_WORDS < w.size() &&
+              ((w[r * VM_REC_WORDS + 1] & VM_D1_RCP) || (w[r * VM_REC_WORDS + 1] & VM_OFF_MASK) != one_off))
+            row_flags |= VM_D2_RCP;      // the row needs its aux operand (reciprocal to publish, or a scale factor != 1.0)
         }
         for (int l = 0; l < 64; l++) {
           const auto& w = prog[(size_t)wv * 64 + l];
-          vm_pack(r < w.size() ? w[r] : idle, row_w0, row_w1, stream[(size_t)wv]);
+          if (r * VM_REC_WORDS < w.size()) {
+            for (int q = 0; q < VM_REC_WORDS; q++) stream[(size_t)wv].push_back(w[r * VM_REC_WORDS + q] | (q == 2 ? row_flags : 0u));
+          } else {
+            idle_record(stream[(size_t)wv], row_flags);      // loads the 0.0 cell, stores nothing
+          }
         }
       }
       P.wave_rows += (int64_t)rows;
@@ -207,7 +214,7 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
     P.recs.insert(P.recs.end(), stream[(size_t)wv].begin(), stream[(size_t)wv].end());
     // idle rows of slack so that the executor's look-ahead loads past the last record stay in bounds
     for (int rr = 0; rr < VM_LOOKAHEAD_ROWS; rr++)
-      for (int l = 0; l < 64; l++) vm_pack(idle, 0, 0, P.recs);
+      for (int l = 0; l < 64; l++) idle_record(P.recs, 0);
   }
   return P;
 }
@@ -528,9 +535,8 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   S.tail = build_tail_solve(m, lay);
   {
     std::vector<VmEntry> fwd = solve_head_fwd_entries(m, lay, S.tail.h), bwd = solve_head_bwd_entries(m, lay, S.tail.h);
-    // forward sweep only: measured on MI355X the split pays there (tail rows carry up to 42 head-column terms); in the
-    // backward sweep the extra rounds it creates cost more than the shorter critical rows save
     S.n_temps = split_long_entries(fwd, lay, 6, 0);
+    S.n_temps += split_long_entries(bwd, lay, 6, S.n_temps);
     S.solve_head_fwd = build_vm_program(std::move(fwd), lay, nt);
     S.solve_head_bwd = build_vm_program(std::move(bwd), lay, nt);
   }

@@ -6,16 +6,14 @@
 //  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) | 0.0 | 1.0 | trash | -1.0 | R (nvar) | temps ],
 //    R(k) = 1/U(k,k).
 //    A program is a list of rounds separated by workgroup barriers; inside a round every lane walks its own list of
-//    fixed 16-byte RECORDS of eight 14-bit cell indices (the table stream, not LDS or the ALUs, bounds the LU: every
-//    workgroup reads the whole program from L2 once per factorisation).  Records are self-contained (no state carried
-//    from one to the next):
-//        w0 = tgt | aux<<14 | CONT<<28 | RCP<<29 | EOR<<30 | NULL<<31      w1 = a1 | r1<<14 | ROWAUX<<28
-//        w2 = u1 | a2<<14                                                 w3 = r2 | u2<<14
-//        acc = M[tgt];   acc -= (M[a1]*M[r1])*M[u1];   acc -= (M[a2]*M[r2])*M[u2];      (three roundings per update, no
+//    fixed 32-byte RECORDS whose fields are LDS byte offsets.  Records are self-contained (no state carried from one
+//    to the next, no per-lane flags to decode):
+//        d0 = tgt     d1 = aux (| RCP)     d2..d4 = a1,r1,u1     d5..d7 = a2,r2,u2      (d2 also carries the row marks)
+//        acc = CONT ? (what this lane's previous record stored) : M[tgt];
+//        acc -= (M[a1]*M[r1])*M[u1];   acc -= (M[a2]*M[r2])*M[u2];      (three roundings per update, no
 //                                                                                        contraction)
 //        M[tgt] = acc * M[aux]            aux = the 1.0 cell unless the entry is scaled by a pivot reciprocal
-//        RCP:  M[tgt] = acc;  M[aux] = 1/acc           (a pivot publishes its reciprocal)
-//        ROWAUX marks rows in which some lane has RCP or a real scale factor; other rows skip the aux operand.
+//        RCP:  M[tgt] = acc;  M[aux] = 1/acc           (a pivot publishes its reciprocal; rows with such lanes are marked)
 //    An unused update slot points all three operands at the 0.0 cell (acc - (0*0)*0 = acc exactly); an idle lane
 //    targets the trash cell.  An entry with more than two updates in a round takes consecutive records of one lane
 //    (store, reload: LDS is in-order within a wave).  A wave's records form one linear stream over all rounds (the
@@ -54,14 +52,17 @@
 
 namespace mistra {
 
-// record layout: 14-bit cell indices, marks in the top bits of w0 / w1
-constexpr uint32_t VM_IDX_BITS = 14, VM_IDX_MASK = (1u << 14) - 1;
-constexpr uint32_t VM_W0_CONT = 1u << 28;   // continuation record of the lane's previous record (same target)
-constexpr uint32_t VM_W0_RCP = 1u << 29;    // this lane publishes 1/result to aux instead of scaling by M[aux]
-constexpr uint32_t VM_W0_EOR = 1u << 30;    // (every lane of the row) last row of this round for the wave -> barrier
-constexpr uint32_t VM_W0_NULL = 1u << 31;   // (every lane of the row) the row carries no work
-constexpr uint32_t VM_W1_ROWAUX = 1u << 28; // (every lane of the row) some lane publishes a reciprocal or scales by != 1.0
-constexpr int VM_REC_WORDS = 4;
+// record marks (low three bits of an 8-byte-aligned LDS byte offset)
+constexpr uint32_t VM_D0_CONT = 1u;    // on d0: continuation record of the lane's previous record (same target); an executor
+                                       // that prefetches operands must carry the accumulator instead of reloading the target
+                                       // (the shipped one does not prefetch: measured no gain, the loop is issue-bound)
+constexpr uint32_t VM_D1_RCP = 1u;     // on d1: publish 1/result to aux instead of scaling by M[aux]
+constexpr uint32_t VM_D2_EOR = 1u;     // on d2 of every lane of a row: last row of this round for the wave -> barrier
+constexpr uint32_t VM_D2_NULL = 2u;    // on d2: the row carries no work (a wave with nothing to do in a round)
+constexpr uint32_t VM_D2_RCP = 4u;     // on d2 of every lane of a row: some lane of the row publishes a reciprocal OR scales by
+                                       // M[aux] != 1.0 cell; rows without the mark skip the aux read and the final multiply
+constexpr uint32_t VM_OFF_MASK = ~7u;
+constexpr int VM_REC_WORDS = 8;
 constexpr int VM_UPD_PER_REC = 2;
 constexpr int VM_LOOKAHEAD_ROWS = 16;    // >= 2x the kernel's table look-ahead depth (ros3_kernel.hip)
 
@@ -98,7 +99,7 @@ struct VmProgram {
   int nt = 0, nw = 0, nrounds = 0, zero_slot = 0;
   std::vector<uint32_t> wave_base;              // [nw]  first record row of each wave's linear stream
   std::vector<uint16_t> blk_n;                  // [nrounds*nw] record rows of (round, wave), null rows included (census / emulator)
-  std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*4 + k]   one uint4 per lane and row
+  std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*8 + k]   two uint4 per lane and row
   // census
   int64_t n_updates = 0, n_items = 0, n_records = 0, wave_rows = 0, crit_rows = 0;
 };

@@ -49,12 +49,13 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
         bool own_raw = false;
         for (int ridx = 0; ridx < n; ridx++) {
           const uint32_t* rec = &P.recs[((base + ridx) * 64 + l) * VM_REC_WORDS];
-          if ((rec[0] & VM_W0_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
-          if (rec[0] & VM_W0_NULL) continue;
-          auto rd = [&](int i) {
+          if ((rec[2] & VM_D2_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
+          if (rec[2] & VM_D2_NULL) continue;
+          auto rd = [&](uint32_t off) {
+            const int i = (int)((off & VM_OFF_MASK) >> 3);
             if (i != trash) {
               reads.emplace_back(i, lane);
-              if (writer[i] == lane) own_raw = true;   // an executor that prefetches operands could not read this back
+              if (writer[i] == lane) own_raw = true;   // the kernel prefetches operands: a lane may not read back its own store
             }
             return (writer[i] == lane) ? M[(size_t)i] : snapshot[(size_t)i];
           };
@@ -65,27 +66,24 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
             writer[i] = lane;
             return 0;
           };
-          const int tgt = rec[0] & VM_IDX_MASK, aux = (rec[0] >> VM_IDX_BITS) & VM_IDX_MASK;
-          const int a1 = rec[1] & VM_IDX_MASK, r1 = (rec[1] >> VM_IDX_BITS) & VM_IDX_MASK;
-          const int u1 = rec[2] & VM_IDX_MASK, a2 = (rec[2] >> VM_IDX_BITS) & VM_IDX_MASK;
-          const int r2 = rec[3] & VM_IDX_MASK, u2 = (rec[3] >> VM_IDX_BITS) & VM_IDX_MASK;
-          double acc = (rec[0] & VM_W0_CONT) ? carry : rd(tgt);
-          if ((rec[0] & VM_W0_CONT) && ridx == 0) return -7;   // a continuation cannot open a round
-          {
-            const double m1 = rd(a1) * rd(r1);
-            acc = acc - m1 * rd(u1);
-            const double m2 = rd(a2) * rd(r2);
-            acc = acc - m2 * rd(u2);
+          const int tgt = (int)((rec[0] & VM_OFF_MASK) >> 3), aux = (int)((rec[1] & VM_OFF_MASK) >> 3);
+          double acc = (rec[0] & VM_D0_CONT) ? carry : rd(rec[0]);
+          if ((rec[0] & VM_D0_CONT) && ridx == 0) return -7;   // a continuation cannot open a round
+          for (int u = 0; u < VM_UPD_PER_REC; u++) {
+            const double av = rd(rec[2 + 3 * u]), rv = rd(rec[3 + 3 * u]), uv = rd(rec[4 + 3 * u]);
+            const double mlt = av * rv;
+            const double p = mlt * uv;
+            acc = acc - p;
           }
-          if (rec[0] & VM_W0_RCP) {
-            if (!(rec[1] & VM_W1_ROWAUX)) return -6;   // row mark missing
+          if (rec[1] & VM_D1_RCP) {
+            if (!(rec[2] & VM_D2_RCP)) return -6;   // row mark missing
             if (wr(tgt, acc)) return -2;
             if (wr(aux, 1.0 / acc)) return -2;
             carry = acc;
           } else {
             double res = acc;
-            if (rec[1] & VM_W1_ROWAUX) res = acc * rd(aux);      // rows without the mark skip the (then 1.0) factor
-            else if (aux != one_cell) return -9;                 // unmarked row with a real scale factor
+            if (rec[2] & VM_D2_RCP) res = acc * rd(rec[1]);        // rows without the mark skip the (then 1.0) factor
+            else if ((int)((rec[1] & VM_OFF_MASK) >> 3) != one_cell) return -9;   // unmarked row with a real scale factor
             if (wr(tgt, res)) return -2;
             carry = res;
           }
@@ -94,7 +92,8 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
       }
     }
     for (auto& rd : reads)
-      if (writer[rd.first] >= 0 && writer[rd.first] != rd.second) return -3;   // read of a slot another lane writes this round
+      if (writer[rd.first] >= 0 && writer[rd.first] != rd.second) return -3;   // read of a slot another lane writes this round   // read of a slot that is written in this round (the kernel prefetches operands,
+                                              // so not even the writing lane itself may read it back before the barrier)
   }
   return 0;
 }
