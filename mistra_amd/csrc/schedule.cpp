@@ -535,8 +535,9 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   S.tail = build_tail_solve(m, lay);
   {
     std::vector<VmEntry> fwd = solve_head_fwd_entries(m, lay, S.tail.h), bwd = solve_head_bwd_entries(m, lay, S.tail.h);
+    // forward sweep only: measured on MI355X the split pays there (tail rows carry up to 42 head-column terms); in the
+    // backward sweep the extra rounds it creates cost more than the shorter critical rows save
     S.n_temps = split_long_entries(fwd, lay, 6, 0);
-    S.n_temps += split_long_entries(bwd, lay, 6, S.n_temps);
     S.solve_head_fwd = build_vm_program(std::move(fwd), lay, nt);
     S.solve_head_bwd = build_vm_program(std::move(bwd), lay, nt);
   }

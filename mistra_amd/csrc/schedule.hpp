@@ -6,7 +6,8 @@
 //  * the LDS VM ("vm"): memory M = [ Ghimj (nnz) | XS (nvar) | 0.0 | 1.0 | trash | -1.0 | R (nvar) | temps ],
 //    R(k) = 1/U(k,k).
 //    A program is a list of rounds separated by workgroup barriers; inside a round every lane walks its own list of
-//    fixed 32-byte RECORDS whose fields are LDS byte offsets.  Records are self-contained (no state carried from one
+//    fixed 32-byte RECORDS whose fields are LDS byte offsets (a 16-byte packing of 14-bit indices was tried: the extra
+//    decode arithmetic cost more than the halved table stream saved).  Records are self-contained (no state carried from one
 //    to the next, no per-lane flags to decode):
 //        d0 = tgt     d1 = aux (| RCP)     d2..d4 = a1,r1,u1     d5..d7 = a2,r2,u2      (d2 also carries the row marks)
 //        acc = CONT ? (what this lane's previous record stored) : M[tgt];
