@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--cells-per-gpu", type=int, default=100000)
     ap.add_argument("--mech", default="tot", choices=["gas", "aer", "tot"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N>1 (nccl = RCCL; gloo only for rehearsing the rank logic)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (requires --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,11 +122,18 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
+    if args.share_device:
+        if args.backend != "gloo":
+            sys.exit("--share-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     total_cells = args.cells_per_gpu * world
     start, ncell = shard(total_cells, rank, world)
@@ -152,8 +163,10 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
 
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    agg = torch.stack([stats[:, 2].sum().double(), (ierr != 1).sum().double(), torch.tensor(float(ncell), device=dev, dtype=torch.float64)])
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # gloo reduces host tensors
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    agg = torch.stack([stats[:, 2].sum().double(), (ierr != 1).sum().double(),
+                       torch.tensor(float(ncell), device=dev, dtype=torch.float64)]).to(cdev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
