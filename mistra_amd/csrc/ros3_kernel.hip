@@ -188,7 +188,8 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
 }
 
-template <int R>
+// FORWARD = false: the vector has been forward-swept already (stage 1: inside the LU program), only the backward chain runs
+template <int R, bool FORWARD>
 __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t xb, uint32_t rb, int lane) {
   constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
   double x[R], rd[R], dg[R];
@@ -199,7 +200,7 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t 
     dg[r] = lds_ld(mb + 8 * (uint32_t)G_(T.diag)[r * 64 + lane]);
   }
   // ---- forward: for every tail column q ascending:  x(i) -= L(i,q) * x(q)  for the tail rows i > q
-  {
+  if constexpr (FORWARD) {
     gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.fwd)) + lane;
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     vm_ring_load<0>(tp); vm_ring_load<1>(tp + 64); vm_ring_load<2>(tp + 128); vm_ring_load<3>(tp + 192);
@@ -428,9 +429,14 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
 
   // ---- ros_PrepareMatrix_x (gas.f:1404), first half: Ghimj = -Jac0, diagonal += 1/(H*gamma).
   //      Returns (workgroup-uniform) whether a diagonal is exactly zero, the condition KppDecomp_x tests (gas.f:6157).
-  auto prepare = [&](double ghinv) -> bool {
+  auto prepare = [&](double ghinv, const double (&rhs)[SPT]) -> bool {
     if (t == 0) flags[0] = 0;
     lds_barrier();   // also: all readers of M from the previous attempt are done
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {      // stage-1 right-hand side: the LU program forward-sweeps it while it factorises
+      const int s = q * NT + t;
+      if (s < NVAR) XS[s] = rhs[q];
+    }
     bool zero_diag = false;
 #pragma unroll
     for (int q = 0; q < JPT; q++) {
@@ -461,20 +467,27 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     return flags[0] != 0;
   };
 
-  // ---- KppSolve_x (gas.f:6206) on a register vector
-  auto solve = [&](double (&k)[SPT]) {
+  // ---- KppSolve_x (gas.f:6206) on a register vector.  swept = true: XS already holds the forward-swept vector (the LU
+  //      program carried the stage-1 right-hand side through the elimination), only the backward half is left.
+  auto solve = [&](double (&k)[SPT], bool swept) {
+    if (!swept) {
 #pragma unroll
-    for (int q = 0; q < SPT; q++) {
-      const int s = q * NT + t;
-      if (s < NVAR) XS[s] = k[q];
+      for (int q = 0; q < SPT; q++) {
+        const int s = q * NT + t;
+        if (s < NVAR) XS[s] = k[q];
+      }
+      for (int i = t; i < a.n_temps; i += NT) M[NNZ + 2 * NVAR + 4 + i] = 0.0;       // partial-sum cells of the head sweep
+      lds_barrier();
+      lap(6);
+      vm_run<NT>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
+      lap(8);
+      if (wave == 0)                                                                         // tail chain, one wave
+        tail_solve<MT::TAIL_REGS, true>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
+    } else {
+      lap(6);
+      if (wave == 0)
+        tail_solve<MT::TAIL_REGS, false>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
     }
-    for (int i = t; i < a.n_temps; i += NT) M[NNZ + 2 * NVAR + 4 + i] = 0.0;       // partial-sum cells of the head sweeps
-    lds_barrier();
-    lap(6);
-    vm_run<NT>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
-    lap(8);
-    if (wave == 0)                                                                         // tail chain, one wave
-      tail_solve<MT::TAIL_REGS>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
     lds_barrier();
     lap(9);
     vm_run<NT>(a.solve_head_bwd, wave, lane);
@@ -543,11 +556,14 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     bool accepted = false;
     while (!accepted) {
       {
+        // K1's right-hand side, Fcn0 + HG*dFdT with dFdT = +0.0 (see above); independent of H
+#pragma unroll
+        for (int q = 0; q < SPT; q++) k1[q] = fcn0[q] + 0.0;
         int nconsecutive = 0;
         bool singular = true;
         while (singular) {
           const double ghinv = 1.0 / (Direction * H * kRosGamma1);
-          singular = prepare(ghinv);
+          singular = prepare(ghinv, k1);
           ndec += 1;
           lap(2);
           if (singular) {
@@ -564,11 +580,9 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
         if (ierr == -8) break;
       }
       const double dh = Direction * H;
-      // stage 1
-#pragma unroll
-      for (int q = 0; q < SPT; q++) k1[q] = fcn0[q] + (dh * kRosGamma1) * 0.0;
+      // stage 1: its right-hand side went through the LU program above, only the backward half of the solve is left
       lap(6);
-      solve(k1);
+      solve(k1, true);
       lap(4);
       // stage 2: new function value at Y + A21*K1
 #pragma unroll
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
         for (int q = 0; q < SPT; q++) k2[q] = (fcn[q] + hc * k1[q]) + (dh * kRosGamma2) * 0.0;
       }
       lap(6);
-      solve(k2);
+      solve(k2, false);
       lap(4);
       // stage 3 reuses the stage-2 function value
       {
@@ -592,7 +606,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
         for (int q = 0; q < SPT; q++) k3[q] = ((fcn[q] + hc1 * k1[q]) + hc2 * k2[q]) + (dh * kRosGamma3) * 0.0;
       }
       lap(6);
-      solve(k3);
+      solve(k3, false);
       lap(4);
       nsol += 3;
 #pragma unroll

@@ -224,7 +224,7 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
 // both factors present, ascending j (the order in which the reference's kk/jj loops touch W(c)).  The multiplier is
 // taken as W(k,j)*R(j) from the unscaled slot (see schedule.hpp); pivots publish R(k) = 1/U(k,k) when final; phase 1
 // scales the L slots in place so that the solves find L(k,j) where the reference leaves it.
-std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay) {
+std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool with_rhs) {
   const int n = m.nvar;
   std::vector<VmEntry> out((size_t)m.nnz);
   std::vector<int> where((size_t)n, -1);    // column -> slot in the current row
@@ -246,6 +246,15 @@ std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay) {
     }
     for (int p = m.crow[k]; p < m.crow[k + 1]; p++) where[(size_t)m.icol[p]] = -1;
   }
+  if (with_rhs)      // the right-hand side rides along: X(i) -= (W(i,j)*R(j)) * X(j), ascending j as the forward sweep does
+    for (int i = 0; i < n; i++) {
+      if (m.diag[i] == m.crow[i]) continue;
+      VmEntry E;
+      E.tgt = lay.xs(i);
+      E.phase = 0;
+      for (int p = m.crow[i]; p < m.diag[i]; p++) E.upd.push_back({p, lay.rdiag(m.icol[p]), lay.xs(m.icol[p])});
+      out.push_back(std::move(E));
+    }
   for (int k = 0; k < n; k++)
     for (int p = m.crow[k]; p < m.diag[k]; p++) {
       VmEntry E;
@@ -530,7 +539,7 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   S.diag_pos.assign((size_t)S.spt * nt, POS_NONE);
   for (int s = 0; s < m.nvar; s++) S.diag_pos[(size_t)s] = (uint16_t)m.diag[(size_t)s];
 
-  S.lu = build_vm_program(lu_entries(m, lay), lay, nt);
+  S.lu = build_vm_program(lu_entries(m, lay, true), lay, nt);
   S.solve = build_vm_program(solve_entries(m, lay), lay, nt);
   S.tail = build_tail_solve(m, lay);
   {

@@ -30,6 +30,9 @@
 //    chunks, a chunk is issued no earlier than the first round in which its operands are final, chunks of one entry
 //    stay in order; chunks off the critical path are merged forward to save record headers.  That cuts the LU's
 //    dependency depth from ~9600 serial updates (tot) to ~100 rounds.
+//    The LU program also carries the vector in XS through the elimination (X(i) -= (W(i,j)*R(j))*X(j), the forward
+//    sweep of KppSolve_x for the right-hand side known before the factorisation, i.e. stage 1 of the Rosenbrock step):
+//    those records ride in the rounds the factorisation needs anyway.
 //    Triangular sweeps of KppSolve_x (gas.f:6206): updates are (L(i,j), 1.0, X(j)); the backward sweep multiplies by
 //    R(i) instead of dividing and applies its terms in readiness order (keep_order = false: the reference subtracts
 //    U(i,c)*X(c) for ASCENDING c while the X(c) become known in DESCENDING c).  Long dot products of the head sweeps
@@ -149,7 +152,8 @@ struct KernelSchedule {
 };
 
 VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 2);
-std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay);
+// with_rhs: also forward-sweep the vector held in XS while factorising (rows of an appended right-hand-side column)
+std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool with_rhs);
 int split_long_entries(std::vector<VmEntry>& entries, const VmLayout& lay, int threshold, int first_temp);
 std::vector<VmEntry> solve_entries(const MechTables& m, const VmLayout& lay);
 std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, const VmLayout& lay, int h);

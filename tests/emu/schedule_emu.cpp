@@ -125,9 +125,9 @@ static void run_gsum(const GsumProgram& P, const std::vector<double>& src, uint3
 
 // The kernel's solve: head forward (VM) -> tail chain forward/backward (one wave, registers) -> head backward (VM).
 // The tail loops below mirror tail_solve of ros3_kernel.hip statement by statement.
-static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, const VmLayout& lay) {
+static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, const VmLayout& lay, bool forward = true) {
   const int nnz = lay.nnz;
-  int rc = run_vm(s.solve_head_fwd, M, lay.trash());
+  int rc = forward ? run_vm(s.solve_head_fwd, M, lay.trash()) : 0;
   if (rc) return rc;
   const TailSolve& T = s.tail;
   const int R = T.regs, m = T.m;
@@ -141,7 +141,7 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
     uint32_t w = tab[((size_t)(pos / 4) * 64 + lane) * 4 + pos % 4];
     return (int)(r == 0 ? (w & 0xFFFFu) : (w >> 16));
   };
-  for (int q = 0; q < m; q++) {
+  for (int q = 0; forward && q < m; q++) {
     const int rq = q / 64, lq = q % 64;
     const double xq = x[(size_t)rq * 64 + lq];
     for (int r = rq; r < R; r++)
@@ -188,22 +188,34 @@ const char* emu_describe(void* h) { return ((Emu*)h)->text.c_str(); }
 
 // KppDecomp on G (nnz doubles, in place) through the LU program; R (nvar) receives the pivot reciprocals the program
 // publishes.  Returns 0 or a negative hazard code.
-int emu_lu(void* h, double* G, double* R) {
-  Emu* e = (Emu*)h;
-  std::vector<double> M = e->fresh_m();
-  std::memcpy(M.data(), G, sizeof(double) * e->m.nnz);
-  int rc = run_vm(e->s.lu, M, e->lay().trash());
-  std::memcpy(G, M.data(), sizeof(double) * e->m.nnz);
-  if (R) std::memcpy(R, M.data() + e->lay().rdiag(), sizeof(double) * e->m.nvar);
-  return rc;
-}
-
 static std::vector<double> solve_memory(const Emu* e, const double* LU, const double* X) {
   std::vector<double> M = e->fresh_m();
   std::memcpy(M.data(), LU, sizeof(double) * e->m.nnz);
   std::memcpy(M.data() + e->m.nnz, X, sizeof(double) * e->m.nvar);
   for (int k = 0; k < e->m.nvar; k++) M[(size_t)e->lay().rdiag(k)] = 1.0 / LU[e->m.diag[(size_t)k]];
   return M;
+}
+
+// X (nvar, optional): right-hand side in, its forward sweep L^-1 b out (the LU program carries it along).
+int emu_lu(void* h, double* G, double* R, double* X) {
+  Emu* e = (Emu*)h;
+  std::vector<double> M = e->fresh_m();
+  std::memcpy(M.data(), G, sizeof(double) * e->m.nnz);
+  if (X) std::memcpy(M.data() + e->m.nnz, X, sizeof(double) * e->m.nvar);
+  int rc = run_vm(e->s.lu, M, e->lay().trash());
+  std::memcpy(G, M.data(), sizeof(double) * e->m.nnz);
+  if (R) std::memcpy(R, M.data() + e->lay().rdiag(), sizeof(double) * e->m.nvar);
+  if (X) std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
+  return rc;
+}
+
+// backward half of the kernel's solve (tail chain backward + head backward) on a vector already forward-swept
+int emu_solve_backward(void* h, const double* LU, double* X) {
+  Emu* e = (Emu*)h;
+  std::vector<double> M = solve_memory(e, LU, X);
+  int rc = run_solve_split(e->s, M, e->lay(), false);
+  std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
+  return rc;
 }
 
 int emu_solve(void* h, const double* LU, double* X) {

@@ -25,7 +25,8 @@ def emu():
     lib.emu_create.argtypes = [C.c_char_p, C.c_int]
     lib.emu_describe.restype = C.c_char_p
     lib.emu_describe.argtypes = [C.c_void_p]
-    lib.emu_lu.argtypes = [C.c_void_p, dp, dp]
+    lib.emu_lu.argtypes = [C.c_void_p, dp, dp, dp]
+    lib.emu_solve_backward.argtypes = [C.c_void_p, dp, dp]
     lib.emu_solve.argtypes = [C.c_void_p, dp, dp]
     lib.emu_solve_split.argtypes = [C.c_void_p, dp, dp]
     lib.emu_fun.argtypes = [C.c_void_p, dp, dp, dp, dp]
@@ -65,7 +66,9 @@ def test_programs_match_oracle(emu, mech, nt, golden, oracles):
         lu_ref, ier = o.decomp(G_ref)
         assert ier == 0
         R = np.empty(o.nvar)
-        assert emu.emu_lu(h, P(G), P(R)) == 0, "hazard inside an LU round"
+        b1 = rng.normal(size=o.nvar) * np.abs(o.fun(V, F, K)).max()
+        y1 = b1.copy()             # rides through the factorisation: the forward sweep of the stage-1 right-hand side
+        assert emu.emu_lu(h, P(G), P(R), P(y1)) == 0, "hazard inside an LU round"
         # multipliers are formed as W*R(j) instead of W/U(j,j) (schedule.hpp): last-bit differences that the elimination
         # carries along; entries are compared against the scale of their row
         rowmax = np.array([np.abs(lu_ref[t.crow[k]:t.crow[k + 1]]).max() for k in range(o.nvar)])
@@ -78,6 +81,11 @@ def test_programs_match_oracle(emu, mech, nt, golden, oracles):
         assert emu.emu_solve(h, P(lu_ref), P(x)) == 0, "hazard inside a solve round"
         x_ref = o.solve(lu_ref, b)
         assert np.abs(x - x_ref).max() <= 1e-11 * np.abs(x_ref).max()
+        # stage 1 as the kernel runs it: forward sweep inside the LU program, then only the backward half
+        lu_k = G.copy()
+        assert emu.emu_solve_backward(h, P(lu_k), P(y1)) == 0
+        x1_ref = o.solve(lu_ref, b1)
+        assert np.abs(y1 - x1_ref).max() <= 1e-10 * np.abs(x1_ref).max()
         # the form the kernel runs: head rows through the VM, the tail chain by one wave in registers
         x2 = b.copy()
         assert emu.emu_solve_split(h, P(lu_ref), P(x2)) == 0, "hazard inside a head round"
