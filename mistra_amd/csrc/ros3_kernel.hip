@@ -150,11 +150,33 @@ __device__ __forceinline__ bool vm_step(const u32x4 lo, const u32x4 hi, int& rou
   return false;
 }
 
+// Two consecutive records of ONE round (the first is not the round's last row) processed together: 16-18 LDS reads in
+// flight and two independent multiply chains instead of one — a lone wave advances a dependent chain at only one
+// instruction per ~10 cycles.  The second record may be the continuation of the first (same target): then it starts
+// from the first's result, taken from the register instead of from LDS.  Plain rows only (no aux operand).
+__device__ __forceinline__ void vm_step_pair(const u32x4 lo0, const u32x4 hi0, const u32x4 lo1, const u32x4 hi1) {
+  const uint32_t tgt0 = lo0.x & kOffMask, tgt1 = lo1.x & kOffMask;
+  const double base0 = lds_ld(tgt0), base1 = lds_ld(tgt1);
+  const double a01 = lds_ld(lo0.z & kOffMask), r01 = lds_ld(lo0.w), u01 = lds_ld(hi0.x);
+  const double a02 = lds_ld(hi0.y), r02 = lds_ld(hi0.z), u02 = lds_ld(hi0.w);
+  const double a11 = lds_ld(lo1.z & kOffMask), r11 = lds_ld(lo1.w), u11 = lds_ld(hi1.x);
+  const double a12 = lds_ld(hi1.y), r12 = lds_ld(hi1.z), u12 = lds_ld(hi1.w);
+  const double p01 = (a01 * r01) * u01, p02 = (a02 * r02) * u02;
+  const double p11 = (a11 * r11) * u11, p12 = (a12 * r12) * u12;
+  double acc0 = base0 - p01;
+  acc0 = acc0 - p02;
+  lds_st(tgt0, acc0);
+  double acc1 = (lo1.x & kD0Cont) ? acc0 : base1;
+  acc1 = acc1 - p11;
+  acc1 = acc1 - p12;
+  lds_st(tgt1, acc1);
+}
+
 template <int NT>
 __device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int lane) {
-  // a record is two 16-byte halves: 4 records (8 loads) in flight per lane
+  // a record is two 16-byte halves: 4 records (8 loads) in flight per lane, consumed in groups of two
   gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)G_(P.wave_base)[wave] * 64 + lane) * 2;
-  int rounds_left = P.nrounds;
+  int rounds_left = __builtin_amdgcn_readfirstlane(P.nrounds);
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
   vm_ring_load<0>(rp);       vm_ring_load<1, 16>(rp);
   vm_ring_load<2>(rp + 128); vm_ring_load<3, 16>(rp + 128);
@@ -162,16 +184,30 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int l
   vm_ring_load<6>(rp + 384); vm_ring_load<7, 16>(rp + 384);
   rp += 4 * 128;
   while (rounds_left > 0) {
-#define MISTRA_VM_SLOT(K)                                                \
-    {                                                                    \
-      const u32x4 lo = vm_ring_take<2 * K, 6>();      /* the two oldest of 8 loads have landed */ \
-      const u32x4 hi = vm_ring_take<2 * K + 1, 6>();                      \
-      vm_ring_load<2 * K>(rp + K * 128);                                 \
-      vm_ring_load<2 * K + 1, 16>(rp + K * 128);                         \
-      if (vm_step(lo, hi, rounds_left)) break;                           \
+#define MISTRA_VM_GROUP(K)   /* records 2K and 2K+1 of the ring */                                             \
+    {                                                                                                          \
+      const u32x4 lo0 = vm_ring_take<4 * K, 4>();       /* the four oldest of 8 loads have landed */            \
+      const u32x4 hi0 = vm_ring_take<4 * K + 1, 4>();                                                          \
+      const u32x4 lo1 = vm_ring_take<4 * K + 2, 4>();                                                          \
+      const u32x4 hi1 = vm_ring_take<4 * K + 3, 4>();                                                          \
+      vm_ring_load<4 * K>(rp + (2 * K) * 128);                                                                 \
+      vm_ring_load<4 * K + 1, 16>(rp + (2 * K) * 128);                                                         \
+      vm_ring_load<4 * K + 2>(rp + (2 * K + 1) * 128);                                                         \
+      vm_ring_load<4 * K + 3, 16>(rp + (2 * K + 1) * 128);                                                     \
+      const uint32_t row0 = __builtin_amdgcn_readfirstlane(lo0.z), row1 = __builtin_amdgcn_readfirstlane(lo1.z); \
+      if (!((row0 | row1) & (kD2Eor | kD2Null | kD2Rcp)) ) {                                                   \
+        vm_step_pair(lo0, hi0, lo1, hi1);              /* two plain rows inside one round */                    \
+      } else if (!(row0 & (kD2Eor | kD2Null | kD2Rcp)) && !(row1 & (kD2Null | kD2Rcp))) {                      \
+        vm_step_pair(lo0, hi0, lo1, hi1);              /* ... the second one closing the round */               \
+        lds_barrier();                                                                                         \
+        if (--rounds_left == 0) break;                                                                         \
+      } else {                                                                                                 \
+        if (vm_step(lo0, hi0, rounds_left)) break;                                                             \
+        if (vm_step(lo1, hi1, rounds_left)) break;                                                             \
+      }                                                                                                        \
     }
-    MISTRA_VM_SLOT(0) MISTRA_VM_SLOT(1) MISTRA_VM_SLOT(2) MISTRA_VM_SLOT(3)
-#undef MISTRA_VM_SLOT
+    MISTRA_VM_GROUP(0) MISTRA_VM_GROUP(1)
+#undef MISTRA_VM_GROUP
     rp += 4 * 128;
   }
   // drain: the look-ahead loads must have landed before this function returns
