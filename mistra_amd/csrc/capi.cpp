@@ -100,14 +100,13 @@ struct MechState {
   GsBufs vdot, jvs;
   VmBufs lu, solve_head_fwd, solve_head_bwd;
   DevBuf<uint32_t> tail_fwd, tail_bwd;
-  DevBuf<uint16_t> tail_diag;
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
   DevBuf<int32_t> s_ierr, s_stats;
   void release() {
     consts.release(); fun_fac.release(); jac_fac.release(); jvs_pos.release(); zero_pos.release(); diag_pos.release();
     vdot.release(); jvs.release(); lu.release(); solve_head_fwd.release(); solve_head_bwd.release();
-    tail_fwd.release(); tail_bwd.release(); tail_diag.release();
+    tail_fwd.release(); tail_bwd.release();
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release();
     ready = false;
   }
@@ -148,13 +147,12 @@ int setup_mech(int mech) {
   if (!S.tab.load(mech_dir() + "/" + kMechName[mech] + ".mech", &err)) return fail(err);
   S.nt = default_nt(mech);
   const bool nt_ok = (mech == MISTRA_MECH_GAS && S.nt == 128) || (mech == MISTRA_MECH_AER && S.nt == 512) ||
-                     (mech == MISTRA_MECH_TOT && (S.nt == 512 || S.nt == 1024));
+                     (mech == MISTRA_MECH_TOT && S.nt == 512);
   if (!nt_ok) return fail(std::string("no kernel instantiated for workgroup size ") + std::to_string(S.nt) + " of " + kMechName[mech]);
   // LDS byte address of the A/B product array for this <mechanism, workgroup size> (the gather-sum tables hold addresses)
   const uint32_t ab_base = 8u * (uint32_t)(mech == MISTRA_MECH_GAS   ? LdsLayout<GasTraits, 128>::AB
                                            : mech == MISTRA_MECH_AER ? LdsLayout<AerTraits, 512>::AB
-                                           : S.nt == 1024           ? LdsLayout<TotTraits, 1024>::AB
-                                                                    : LdsLayout<TotTraits, 512>::AB);
+                                                                     : LdsLayout<TotTraits, 512>::AB);
   KernelSchedule K;
   try {
     const int max_temps = mech == MISTRA_MECH_GAS ? GasTraits::MAX_TEMPS : mech == MISTRA_MECH_AER ? AerTraits::MAX_TEMPS : TotTraits::MAX_TEMPS;
@@ -181,7 +179,6 @@ int setup_mech(int mech) {
   HIP_TRY(S.solve_head_bwd.upload(K.solve_head_bwd));
   HIP_TRY(S.tail_fwd.upload(K.tail.fwd));
   HIP_TRY(S.tail_bwd.upload(K.tail.bwd));
-  HIP_TRY(S.tail_diag.upload(K.tail.diag));
   S.ready = true;
   return 0;
 }
@@ -191,7 +188,6 @@ int launch(int mech, const KernelArgs& a, hipStream_t stream) {
   hipError_t e = hipErrorInvalidValue;
   if (mech == MISTRA_MECH_GAS) e = launch_ros3<GasTraits, 128>(a, stream);
   else if (mech == MISTRA_MECH_AER) e = launch_ros3<AerTraits, 512>(a, stream);
-  else if (S.nt == 1024) e = launch_ros3<TotTraits, 1024>(a, stream);
   else e = launch_ros3<TotTraits, 512>(a, stream);
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
   return 0;
@@ -205,7 +201,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
   a.consts = S.consts.p; a.fun_fac = S.fun_fac.p; a.jac_fac = S.jac_fac.p; a.jvs_pos = S.jvs_pos.p;
   a.zero_pos = S.zero_pos.p; a.diag_pos = S.diag_pos.p;
   a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev(); a.solve_head_fwd = S.solve_head_fwd.dev(); a.solve_head_bwd = S.solve_head_bwd.dev();
-  a.tail = TailDev{S.tail_fwd.p, S.tail_bwd.p, S.tail_diag.p};
+  a.tail = TailDev{S.tail_fwd.p, S.tail_bwd.p};
   return a;
 }
 

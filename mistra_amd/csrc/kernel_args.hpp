@@ -20,7 +20,6 @@ struct GsDev {                 // gather-sum program in device memory (see sched
 struct TailDev {               // tail chain of the triangular solves (schedule.hpp: TailSolve)
   const uint32_t* fwd;         // u32x4 per lane and group of 4 columns, columns ascending
   const uint32_t* bwd;         // same, columns descending
-  const uint16_t* diag;        // [regs*64]
 };
 
 struct KernelArgs {

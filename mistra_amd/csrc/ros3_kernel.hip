@@ -228,13 +228,22 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 template <int R, bool FORWARD>
 __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t xb, uint32_t rb, int lane) {
   constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
-  double x[R], rd[R], dg[R];
+  double x[R], rd[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
     x[r] = lds_ld(xb + 8 * (r * 64 + lane));
     rd[r] = lds_ld(rb + 8 * (r * 64 + lane));          // R(k) = 1/U(k,k), published by the LU program
-    dg[r] = lds_ld(mb + 8 * (uint32_t)G_(T.diag)[r * 64 + lane]);
   }
+  // Matrix entries of a 4-column group are read from LDS one group AHEAD of the chain that uses them (two register
+  // buffers, alternating): a lone wave would otherwise expose the LDS latency once per group.  Every row slot is read
+  // for every group (rows that take no part point at the 0.0 cell); the arithmetic loops keep their exact row ranges.
+#define MISTRA_TAIL_OPERANDS(BUF, TAB)                                                  \
+  _Pragma("unroll") for (int c = 0; c < 4; c++)                                         \
+    _Pragma("unroll") for (int r = 0; r < R; r++) BUF[c][r] = lds_ld(mb + 8 * ((TAB[c] >> (16 * r)) & 0xFFFFu));
+  // The compiler would otherwise park the off-chain row updates (and their operands) until the row is next read, sixty
+  // columns later: pin every group's results to the end of its group.
+#define MISTRA_TAIL_PIN _Pragma("unroll") for (int r = 0; r < R; r++) asm volatile("" : "+v"(x[r]));
+  double opa[4][R], opb[4][R];
   // ---- forward: for every tail column q ascending:  x(i) -= L(i,q) * x(q)  for the tail rows i > q
   if constexpr (FORWARD) {
     gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.fwd)) + lane;
@@ -242,65 +251,71 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t 
     vm_ring_load<0>(tp); vm_ring_load<1>(tp + 64); vm_ring_load<2>(tp + 128); vm_ring_load<3>(tp + 192);
     vm_ring_load<4>(tp + 256); vm_ring_load<5>(tp + 320); vm_ring_load<6>(tp + 384); vm_ring_load<7>(tp + 448);
     tp += kRingSlots * 64;
+    {
+      const u32x4 first = vm_ring_take<0>();
+      vm_ring_load<0>(tp);
+      MISTRA_TAIL_OPERANDS(opa, first)
+    }
 #pragma unroll
     for (int rq = 0; rq < R; rq++) {
       for (int gb = 0; gb < 16; gb += kRingSlots) {
-#define MISTRA_TAIL_FWD(K)                                                              \
+#define MISTRA_TAIL_FWD(K, CUR, NXT)                                                    \
         {                                                                               \
-          const u32x4 cur = vm_ring_take<K>();                                          \
-          vm_ring_load<K>(tp + K * 64);                                                 \
-          double l[4][R];                                                               \
-          _Pragma("unroll") for (int c = 0; c < 4; c++)                                 \
-            _Pragma("unroll") for (int r = rq; r < R; r++) l[c][r] = lds_ld(mb + 8 * ((cur[c] >> (16 * r)) & 0xFFFFu)); \
+          const u32x4 nxt = vm_ring_take<(K + 1) % kRingSlots>();                       \
+          vm_ring_load<(K + 1) % kRingSlots>(tp + (K + 1) * 64);                        \
+          MISTRA_TAIL_OPERANDS(NXT, nxt)                                                \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const double xq = readlane_f64(x[rq], 4 * (gb + K) + c);                    \
-            _Pragma("unroll") for (int r = rq; r < R; r++) x[r] = x[r] - l[c][r] * xq;  \
+            _Pragma("unroll") for (int r = rq; r < R; r++) x[r] = x[r] - CUR[c][r] * xq; \
           }                                                                             \
+          MISTRA_TAIL_PIN                                                               \
         }
-        MISTRA_TAIL_FWD(0) MISTRA_TAIL_FWD(1) MISTRA_TAIL_FWD(2) MISTRA_TAIL_FWD(3)
-        MISTRA_TAIL_FWD(4) MISTRA_TAIL_FWD(5) MISTRA_TAIL_FWD(6) MISTRA_TAIL_FWD(7)
+        MISTRA_TAIL_FWD(0, opa, opb) MISTRA_TAIL_FWD(1, opb, opa) MISTRA_TAIL_FWD(2, opa, opb) MISTRA_TAIL_FWD(3, opb, opa)
+        MISTRA_TAIL_FWD(4, opa, opb) MISTRA_TAIL_FWD(5, opb, opa) MISTRA_TAIL_FWD(6, opa, opb) MISTRA_TAIL_FWD(7, opb, opa)
 #undef MISTRA_TAIL_FWD
         tp += kRingSlots * 64;
       }
     }
   }
-  // ---- backward: for every tail column q descending:  x(q) = x(q)/U(q,q);  x(i) -= U(i,q) * x(q)  for tail rows i < q.
-  //      The quotient is formed with the published reciprocal R(q) and one correction step (q0 = s*r; q0 + (s - q0*d)*r),
-  //      which lands on the correctly rounded s/d except in rare ties; an IEEE divide sequence would sit on the serial
-  //      chain 128 times.
+  // ---- backward, on the row-scaled triangle U' = D^-1 U that the LU program's last phase leaves in the tail block
+  //      (schedule.cpp: lu_entries): x = R .* x, then for every tail column q descending  x(i) -= U'(i,q) * x(q)  for the
+  //      tail rows i < q.  No quotient on the serial chain: per column it is readlane -> multiply -> subtract.
+#pragma unroll
+  for (int r = 0; r < R; r++) x[r] = x[r] * rd[r];
   {
     gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.bwd)) + lane;
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     vm_ring_load<0>(tp); vm_ring_load<1>(tp + 64); vm_ring_load<2>(tp + 128); vm_ring_load<3>(tp + 192);
     vm_ring_load<4>(tp + 256); vm_ring_load<5>(tp + 320); vm_ring_load<6>(tp + 384); vm_ring_load<7>(tp + 448);
     tp += kRingSlots * 64;
+    {
+      const u32x4 first = vm_ring_take<0>();
+      vm_ring_load<0>(tp);
+      MISTRA_TAIL_OPERANDS(opa, first)
+    }
 #pragma unroll
     for (int rq = R - 1; rq >= 0; rq--) {
       for (int gb = 0; gb < 16; gb += kRingSlots) {
-#define MISTRA_TAIL_BWD(K)                                                              \
+#define MISTRA_TAIL_BWD(K, CUR, NXT)                                                    \
         {                                                                               \
-          const u32x4 cur = vm_ring_take<K>();                                          \
-          vm_ring_load<K>(tp + K * 64);                                                 \
-          double u[4][R];                                                               \
-          _Pragma("unroll") for (int c = 0; c < 4; c++)                                 \
-            _Pragma("unroll") for (int r = 0; r <= rq; r++) u[c][r] = lds_ld(mb + 8 * ((cur[c] >> (16 * r)) & 0xFFFFu)); \
+          const u32x4 nxt = vm_ring_take<(K + 1) % kRingSlots>();                       \
+          vm_ring_load<(K + 1) % kRingSlots>(tp + (K + 1) * 64);                        \
+          MISTRA_TAIL_OPERANDS(NXT, nxt)                                                \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
-            const int lq = 63 - (4 * (gb + K) + c);                                     \
-            const double sv = readlane_f64(x[rq], lq), d = readlane_f64(dg[rq], lq), rr = readlane_f64(rd[rq], lq); \
-            const double q0 = sv * rr;                                                  \
-            const double e = __builtin_fma(-q0, d, sv);                                 \
-            const double xq = __builtin_fma(e, rr, q0);                                 \
-            x[rq] = (lane == lq) ? xq : x[rq];                                          \
-            _Pragma("unroll") for (int r = 0; r <= rq; r++) x[r] = x[r] - u[c][r] * xq; \
+            const double xq = readlane_f64(x[rq], 63 - (4 * (gb + K) + c));             \
+            _Pragma("unroll") for (int r = 0; r <= rq; r++) x[r] = x[r] - CUR[c][r] * xq; \
           }                                                                             \
+          MISTRA_TAIL_PIN                                                               \
         }
-        MISTRA_TAIL_BWD(0) MISTRA_TAIL_BWD(1) MISTRA_TAIL_BWD(2) MISTRA_TAIL_BWD(3)
-        MISTRA_TAIL_BWD(4) MISTRA_TAIL_BWD(5) MISTRA_TAIL_BWD(6) MISTRA_TAIL_BWD(7)
+        MISTRA_TAIL_BWD(0, opa, opb) MISTRA_TAIL_BWD(1, opb, opa) MISTRA_TAIL_BWD(2, opa, opb) MISTRA_TAIL_BWD(3, opb, opa)
+        MISTRA_TAIL_BWD(4, opa, opb) MISTRA_TAIL_BWD(5, opb, opa) MISTRA_TAIL_BWD(6, opa, opb) MISTRA_TAIL_BWD(7, opb, opa)
 #undef MISTRA_TAIL_BWD
         tp += kRingSlots * 64;
       }
     }
   }
+#undef MISTRA_TAIL_OPERANDS
+#undef MISTRA_TAIL_PIN
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
   for (int r = 0; r < R; r++) lds_st(xb + 8 * (r * 64 + lane), x[r]);
@@ -720,6 +735,7 @@ hipError_t launch_ros3(const KernelArgs& a, hipStream_t stream) {
 template hipError_t launch_ros3<GasTraits, 128>(const KernelArgs&, hipStream_t);
 template hipError_t launch_ros3<AerTraits, 512>(const KernelArgs&, hipStream_t);
 template hipError_t launch_ros3<TotTraits, 512>(const KernelArgs&, hipStream_t);
-template hipError_t launch_ros3<TotTraits, 1024>(const KernelArgs&, hipStream_t);
+// (a 1024-thread tot variant was measured slower, and instantiating it caps the register budget of the shared
+//  non-inlined device functions at that of a 16-wave workgroup)
 
 }  // namespace mistra

@@ -223,8 +223,10 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
 // KppDecomp_x (gas.f:6142-6176), entry view: slot p=(k,c) of row k gets  - L(k,j)*U(j,c)  for every j < min(k,c) with
 // both factors present, ascending j (the order in which the reference's kk/jj loops touch W(c)).  The multiplier is
 // taken as W(k,j)*R(j) from the unscaled slot (see schedule.hpp); pivots publish R(k) = 1/U(k,k) when final; phase 1
-// scales the L slots in place so that the solves find L(k,j) where the reference leaves it.
-std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool with_rhs) {
+// scales the L slots in place so that the solves find L(k,j) where the reference leaves it.  tail_h >= 0: phase 1 also
+// scales the strictly-upper entries of the tail block by their ROW's pivot reciprocal, U'(i,c) = U(i,c)*R(i) for
+// i >= tail_h: the tail chain's backward sweep then runs on a unit-diagonal triangle (schedule.hpp: TailSolve).
+std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool with_rhs, int tail_h) {
   const int n = m.nvar;
   std::vector<VmEntry> out((size_t)m.nnz);
   std::vector<int> where((size_t)n, -1);    // column -> slot in the current row
@@ -263,6 +265,15 @@ std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool w
       E.mulr = lay.rdiag(m.icol[p]);
       out.push_back(std::move(E));
     }
+  if (tail_h >= 0)
+    for (int k = tail_h; k < n; k++)
+      for (int p = m.diag[k] + 1; p < m.crow[k + 1]; p++) {
+        VmEntry E;
+        E.tgt = p;
+        E.phase = 1;
+        E.mulr = lay.rdiag(k);
+        out.push_back(std::move(E));
+      }
   return out;
 }
 
@@ -372,14 +383,12 @@ TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay) {
   // + VM_LOOKAHEAD_ROWS groups of slack for the kernel's look-ahead loads
   T.fwd.assign(((size_t)T.m / 4 + VM_LOOKAHEAD_ROWS) * 256, z | (z << 16));
   T.bwd.assign(((size_t)T.m / 4 + VM_LOOKAHEAD_ROWS) * 256, z | (z << 16));
-  T.diag.assign((size_t)T.regs * 64, 0);
   auto put = [&](std::vector<uint32_t>& tab, int group_pos, int lane, int r, int slot) {
     uint32_t& w = tab[((size_t)(group_pos / 4) * 64 + lane) * 4 + group_pos % 4];
     w = r == 0 ? ((w & 0xFFFF0000u) | (uint32_t)slot) : ((w & 0x0000FFFFu) | ((uint32_t)slot << 16));
   };
   for (int ti = 0; ti < T.m; ti++) {
     const int i = T.h + ti, lane = ti % 64, r = ti / 64;
-    T.diag[(size_t)r * 64 + lane] = (uint16_t)m.diag[i];
     for (int p = m.crow[i]; p < m.crow[i + 1]; p++) {
       const int c = m.icol[p];
       if (c < T.h || c == i) continue;
@@ -539,9 +548,9 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   S.diag_pos.assign((size_t)S.spt * nt, POS_NONE);
   for (int s = 0; s < m.nvar; s++) S.diag_pos[(size_t)s] = (uint16_t)m.diag[(size_t)s];
 
-  S.lu = build_vm_program(lu_entries(m, lay, true), lay, nt);
-  S.solve = build_vm_program(solve_entries(m, lay), lay, nt);
   S.tail = build_tail_solve(m, lay);
+  S.lu = build_vm_program(lu_entries(m, lay, true, S.tail.h), lay, nt);
+  S.solve = build_vm_program(solve_entries(m, lay), lay, nt);
   {
     std::vector<VmEntry> fwd = solve_head_fwd_entries(m, lay, S.tail.h), bwd = solve_head_bwd_entries(m, lay, S.tail.h);
     // forward sweep only: measured on MI355X the split pays there (tail rows carry up to 42 head-column terms); in the

@@ -121,11 +121,14 @@ struct GsumProgram {
 // tail of the solution vector in registers (lane l holds rows h+l, h+64+l), the pivot value passed lane-to-lane by
 // v_readlane, and only the matrix entries gathered from LDS through these per-column index tables:
 //   word (16 bit) for column q, lane l, register r  =  Ghimj slot of entry (row h+64r+l, column h+q), or the 0.0 cell
+// Forward: x(i) -= L(i,q)*x(q), columns ascending, as the reference's sweep orders the terms of a row.  Backward: the
+// LU program leaves the tail block's upper triangle ROW-SCALED, U'(i,c) = U(i,c)*R(i), so that with x := R .* x the
+// chain is  x(i) -= U'(i,q)*x(q)  (columns descending) with no quotient between consecutive columns; the reference
+// computes (x(i) - sum U(i,c) x(c)) / U(i,i) — same terms, each carrying one more rounding.
 struct TailSolve {
   int m = 0, h = 0, regs = 0;                   // tail rows [h, h+m), m = 64*regs, regs in {1,2}
   std::vector<uint32_t> fwd;                    // [((q/4)*64 + lane)*4 + q%4]  lo16: r=0, hi16: r=1; columns ascending
   std::vector<uint32_t> bwd;                    // same, columns DEscending: group g, word c  <->  q = m-1-(4g+c)
-  std::vector<uint16_t> diag;                   // [regs*64] Ghimj slot of the diagonal of tail row r*64+lane
 };
 
 struct KernelSchedule {
@@ -153,7 +156,7 @@ struct KernelSchedule {
 
 VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 2);
 // with_rhs: also forward-sweep the vector held in XS while factorising (rows of an appended right-hand-side column)
-std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool with_rhs);
+std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool with_rhs, int tail_h = -1);
 int split_long_entries(std::vector<VmEntry>& entries, const VmLayout& lay, int threshold, int first_temp);
 std::vector<VmEntry> solve_entries(const MechTables& m, const VmLayout& lay);
 std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, const VmLayout& lay, int h);

@@ -131,10 +131,9 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
   if (rc) return rc;
   const TailSolve& T = s.tail;
   const int R = T.regs, m = T.m;
-  std::vector<double> x((size_t)R * 64), dg((size_t)R * 64), rd((size_t)R * 64);
+  std::vector<double> x((size_t)R * 64), rd((size_t)R * 64);
   for (int i = 0; i < m; i++) {
     x[(size_t)i] = M[(size_t)nnz + T.h + i];
-    dg[(size_t)i] = M[T.diag[(size_t)i]];
     rd[(size_t)i] = M[(size_t)lay.rdiag(T.h + i)];        // R(k) = 1/U(k,k), published by the LU program
   }
   auto idx = [&](const std::vector<uint32_t>& tab, int pos, int lane, int r) {
@@ -150,13 +149,11 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
         x[(size_t)r * 64 + lane] = x[(size_t)r * 64 + lane] - l * xq;
       }
   }
+  // backward on the row-scaled triangle the LU program leaves in the tail block: x = R .* x; x(i) -= U'(i,q) * x(q)
+  for (int i = 0; i < m; i++) x[(size_t)i] = x[(size_t)i] * rd[(size_t)i];
   for (int q = m - 1; q >= 0; q--) {
     const int rq = q / 64, lq = q % 64;
-    const double sv = x[(size_t)rq * 64 + lq], d = dg[(size_t)rq * 64 + lq], rr = rd[(size_t)rq * 64 + lq];
-    const double q0 = sv * rr;
-    const double e = std::fma(-q0, d, sv);
-    const double xq = std::fma(e, rr, q0);
-    x[(size_t)rq * 64 + lq] = xq;
+    const double xq = x[(size_t)rq * 64 + lq];
     for (int r = 0; r <= rq; r++)
       for (int lane = 0; lane < 64; lane++) {
         const double u = M[(size_t)idx(T.bwd, m - 1 - q, lane, r)];
@@ -188,11 +185,16 @@ const char* emu_describe(void* h) { return ((Emu*)h)->text.c_str(); }
 
 // KppDecomp on G (nnz doubles, in place) through the LU program; R (nvar) receives the pivot reciprocals the program
 // publishes.  Returns 0 or a negative hazard code.
-static std::vector<double> solve_memory(const Emu* e, const double* LU, const double* X) {
+// LU: factors as the kernel's LU program leaves them (tail block's upper triangle row-scaled), or, with
+// reference_form, as KppDecomp leaves them: the tail rows are then scaled here.
+static std::vector<double> solve_memory(const Emu* e, const double* LU, const double* X, bool reference_form) {
   std::vector<double> M = e->fresh_m();
   std::memcpy(M.data(), LU, sizeof(double) * e->m.nnz);
   std::memcpy(M.data() + e->m.nnz, X, sizeof(double) * e->m.nvar);
   for (int k = 0; k < e->m.nvar; k++) M[(size_t)e->lay().rdiag(k)] = 1.0 / LU[e->m.diag[(size_t)k]];
+  if (reference_form)
+    for (int k = e->s.tail.h; k < e->m.nvar; k++)
+      for (int p = e->m.diag[(size_t)k] + 1; p < e->m.crow[(size_t)k + 1]; p++) M[(size_t)p] = M[(size_t)p] * M[(size_t)e->lay().rdiag(k)];
   return M;
 }
 
@@ -212,7 +214,7 @@ int emu_lu(void* h, double* G, double* R, double* X) {
 // backward half of the kernel's solve (tail chain backward + head backward) on a vector already forward-swept
 int emu_solve_backward(void* h, const double* LU, double* X) {
   Emu* e = (Emu*)h;
-  std::vector<double> M = solve_memory(e, LU, X);
+  std::vector<double> M = solve_memory(e, LU, X, false);     // LU comes from emu_lu
   int rc = run_solve_split(e->s, M, e->lay(), false);
   std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
   return rc;
@@ -220,7 +222,7 @@ int emu_solve_backward(void* h, const double* LU, double* X) {
 
 int emu_solve(void* h, const double* LU, double* X) {
   Emu* e = (Emu*)h;
-  std::vector<double> M = solve_memory(e, LU, X);
+  std::vector<double> M = solve_memory(e, LU, X, false);     // whole-solve VM program: reference-form factors, unscaled
   int rc = run_vm(e->s.solve, M, e->lay().trash());
   std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
   return rc;
@@ -228,7 +230,7 @@ int emu_solve(void* h, const double* LU, double* X) {
 
 int emu_solve_split(void* h, const double* LU, double* X) {
   Emu* e = (Emu*)h;
-  std::vector<double> M = solve_memory(e, LU, X);
+  std::vector<double> M = solve_memory(e, LU, X, true);      // reference-form factors in
   int rc = run_solve_split(e->s, M, e->lay());
   std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
   return rc;

@@ -73,8 +73,13 @@ def test_programs_match_oracle(emu, mech, nt, golden, oracles):
         # carries along; entries are compared against the scale of their row
         rowmax = np.array([np.abs(lu_ref[t.crow[k]:t.crow[k + 1]]).max() for k in range(o.nvar)])
         scale = np.repeat(rowmax, np.diff(t.crow))
-        print(mech, nt, "LU max |diff|/rowmax %.2e" % (np.abs(G - lu_ref) / scale).max())
-        assert (np.abs(G - lu_ref) / scale).max() <= 1e-10
+        # the program leaves the tail block's upper triangle row-scaled, U'(i,c) = U(i,c)*R(i) (schedule.hpp: TailSolve)
+        tail_h = o.nvar - (128 if o.nvar > 192 else 64)
+        G_un = G.copy()
+        for k in range(tail_h, o.nvar):
+            G_un[t.diag[k] + 1:t.crow[k + 1]] *= G[t.diag[k]]
+        print(mech, nt, "LU max |diff|/rowmax %.2e" % (np.abs(G_un - lu_ref) / scale).max())
+        assert (np.abs(G_un - lu_ref) / scale).max() <= 1e-10
         assert np.allclose(R, 1.0 / lu_ref[t.diag], rtol=1e-9, atol=0)
         b = rng.normal(size=o.nvar) * np.abs(o.fun(V, F, K)).max()
         x = b.copy()
