@@ -22,11 +22,6 @@ namespace mistra {
 
 namespace {
 
-// LDS VM record fields (schedule.hpp): LDS byte offsets with flags in the three alignment bits
-constexpr uint32_t kD0Cont = 1u;
-constexpr uint32_t kD1Rcp = 1u;
-constexpr uint32_t kD2Eor = 1u, kD2Null = 2u, kD2Rcp = 4u;
-constexpr uint32_t kOffMask = ~7u;
 constexpr uint16_t kPosDiag = 0x8000, kPosNone = 0xFFFF;
 constexpr int kRingSlots = 8;  // 16-byte table loads in flight per lane (schedule.cpp appends 2x that many rows of slack)
 
@@ -123,96 +118,154 @@ __device__ __forceinline__ u32x4 vm_ring_take() {
 }
 static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots");
 
-// One record of the LDS VM (schedule.hpp).  M starts at LDS address 0 (checked at kernel entry), so the record's byte
-// offsets are LDS addresses as they stand.  Returns true when the program's last round has been closed.
-__device__ __forceinline__ bool vm_step(const u32x4 lo, const u32x4 hi, int& rounds_left) {
-  const uint32_t row = __builtin_amdgcn_readfirstlane(lo.z);       // row marks are identical in all lanes
-  if (!(row & kD2Null)) {
-    const uint32_t tgt = lo.x & kOffMask;     // bit 0 marks a continuation record: here the reload simply follows the
-    double acc = lds_ld(tgt);                 // lane's own store (LDS is in-order within a wave), nothing to carry
-    const double a1 = lds_ld(lo.z & kOffMask), r1 = lds_ld(lo.w), u1 = lds_ld(hi.x);
-    const double a2 = lds_ld(hi.y), r2 = lds_ld(hi.z), u2 = lds_ld(hi.w);
-    acc = acc - (a1 * r1) * u1;
-    acc = acc - (a2 * r2) * u2;
-    if (row & kD2Rcp) {                       // some lane of this row publishes a pivot reciprocal or scales by one
-      const bool rcp = lo.y & kD1Rcp;
-      const double sc = lds_ld(lo.y & kOffMask);
-      lds_st(tgt, rcp ? acc : acc * sc);
-      if (rcp) lds_st(lo.y & kOffMask, 1.0 / acc);
-    } else {                                  // plain update record: the scale factor is the 1.0 cell, not even read
-      lds_st(tgt, acc);
-    }
-  }
-  if (row & kD2Eor) {
-    lds_barrier();
-    return --rounds_left == 0;
-  }
-  return false;
-}
-
-// Two consecutive records of ONE round (the first is not the round's last row) processed together: 16-18 LDS reads in
-// flight and two independent multiply chains instead of one — a lone wave advances a dependent chain at only one
-// instruction per ~10 cycles.  The second record may be the continuation of the first (same target): then it starts
-// from the first's result, taken from the register instead of from LDS.  Plain rows only (no aux operand).
-__device__ __forceinline__ void vm_step_pair(const u32x4 lo0, const u32x4 hi0, const u32x4 lo1, const u32x4 hi1) {
-  const uint32_t tgt0 = lo0.x & kOffMask, tgt1 = lo1.x & kOffMask;
-  const double base0 = lds_ld(tgt0), base1 = lds_ld(tgt1);
-  const double a01 = lds_ld(lo0.z & kOffMask), r01 = lds_ld(lo0.w), u01 = lds_ld(hi0.x);
-  const double a02 = lds_ld(hi0.y), r02 = lds_ld(hi0.z), u02 = lds_ld(hi0.w);
-  const double a11 = lds_ld(lo1.z & kOffMask), r11 = lds_ld(lo1.w), u11 = lds_ld(hi1.x);
-  const double a12 = lds_ld(hi1.y), r12 = lds_ld(hi1.z), u12 = lds_ld(hi1.w);
-  const double p01 = (a01 * r01) * u01, p02 = (a02 * r02) * u02;
-  const double p11 = (a11 * r11) * u11, p12 = (a12 * r12) * u12;
-  double acc0 = base0 - p01;
-  acc0 = acc0 - p02;
-  lds_st(tgt0, acc0);
-  double acc1 = (lo1.x & kD0Cont) ? acc0 : base1;
-  acc1 = acc1 - p11;
-  acc1 = acc1 - p12;
-  lds_st(tgt1, acc1);
-}
+// ---- the LDS VM executor (schedule.hpp), hand-scheduled: one asm statement holds the whole program loop.
+// Measured on the C++ executor it replaces: a round in which every wave has a single record cost ~1000 cycles, ~370 of
+// them plain instruction issue of a lone wave (ring copies, mark decoding, branches) — 89 LU rounds and 33 solve rounds
+// per Rosenbrock step.  Here a plain record is 23 instructions:
+//   * records land straight in VGPRs: a 4-record ring in v48-55 / v64-71 / v80-87 / v96-103 (caller-saved blocks), named
+//     only inside this statement, so no compiler copy can get between a load and its counted wait (cdna_hip_programming.md
+//     §5.7); a slot is refilled (row + 4) as soon as its ds_reads have been ISSUED (they take their addresses at issue);
+//   * d0, d2..d7 of a record are LDS byte addresses as they stand (M starts at LDS address 0, checked at kernel entry);
+//     every mark sits on d1: one v_readfirstlane per record, then s_bitcmp on the row marks;
+//   * table addresses are SGPR base + 32-bit VGPR offset + immediate: two v_add per four records;
+//   * marked rows (aux operand: scale by a pivot reciprocal, or publish one) and null rows run out of line.
+// A continuation record reloads its target: its lane's previous record stored it, and LDS is in-order within a wave.
+// The IEEE reciprocal is the sequence hipcc emits for 1.0/x (v_div_scale, v_rcp, two Newton steps, v_div_fmas, v_div_fixup).
+#define MISTRA_VM_REFILL(LO, HI, VX, OFF_LO, OFF_HI)                                   \
+  "global_load_dwordx4 " LO ", " VX ", %[base] offset:" OFF_LO "\n\t"                   \
+  "global_load_dwordx4 " HI ", " VX ", %[base] offset:" OFF_HI "\n\t"
+#define MISTRA_VM_UPDATES                                                              \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                            \
+  "v_mul_f64 %[a1], %[a1], %[r1]\n\t"                                                   \
+  "s_waitcnt lgkmcnt(3)\n\t"                                                            \
+  "v_mul_f64 %[a1], %[a1], %[u1]\n\t"                                                   \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                            \
+  "v_mul_f64 %[a2], %[a2], %[r2]\n\t"                                                   \
+  "v_add_f64 %[acc], %[acc], -%[a1]\n\t"                                                \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                            \
+  "v_mul_f64 %[a2], %[a2], %[u2]\n\t"                                                   \
+  "v_add_f64 %[acc], %[acc], -%[a2]\n\t"
+// main line of one ring slot: S = slot tag for labels, D0..D7 = the slot's registers
+#define MISTRA_VM_RECORD(S, D0, D1, D2, D3, D4, D5, D6, D7, LO, HI, VX, OFF_LO, OFF_HI) \
+  "s_waitcnt vmcnt(6)\n\t"                      /* 8 loads in flight, the two oldest are this slot's */ \
+  "v_readfirstlane_b32 %[fl], " D1 "\n\t"                                               \
+  "s_bitcmp1_b32 %[fl], 25\n\t"                 /* VM_ROW_NULL */                       \
+  "s_cbranch_scc1 Lvm_null" S "_%=\n\t"                                                 \
+  "ds_read_b64 %[acc], " D0 "\n\t"                                                      \
+  "ds_read_b64 %[a1], " D2 "\n\t"                                                       \
+  "ds_read_b64 %[r1], " D3 "\n\t"                                                       \
+  "ds_read_b64 %[u1], " D4 "\n\t"                                                       \
+  "ds_read_b64 %[a2], " D5 "\n\t"                                                       \
+  "ds_read_b64 %[r2], " D6 "\n\t"                                                       \
+  "ds_read_b64 %[u2], " D7 "\n\t"                                                       \
+  "v_mov_b32 %[tg], " D0 "\n\t"                                                         \
+  "s_bitcmp1_b32 %[fl], 26\n\t"                 /* VM_ROW_AUX */                        \
+  "s_cbranch_scc1 Lvm_aux" S "_%=\n\t"                                                  \
+  MISTRA_VM_REFILL(LO, HI, VX, OFF_LO, OFF_HI)                                          \
+  MISTRA_VM_UPDATES                                                                     \
+  "ds_write_b64 %[tg], %[acc]\n"                                                        \
+  "Lvm_done" S "_%=:\n\t"                                                               \
+  "s_bitcmp1_b32 %[fl], 24\n\t"                 /* VM_ROW_EOR */                        \
+  "s_cbranch_scc0 Lvm_next" S "_%=\n\t"                                                 \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                            \
+  "s_barrier\n\t"                                                                       \
+  "s_sub_u32 %[rounds], %[rounds], 1\n\t"                                               \
+  "s_cmp_eq_u32 %[rounds], 0\n\t"                                                       \
+  "s_cbranch_scc1 Lvm_exit_%=\n"                                                        \
+  "Lvm_next" S "_%=:\n\t"
+// out of line: a row whose lanes scale by M[aux] (aux = d1 & VM_AUX_MASK) or publish the reciprocal of their result there
+#define MISTRA_VM_RECORD_TAIL(S, D0, D1, LO, HI, VX, OFF_LO, OFF_HI)                    \
+  "Lvm_aux" S "_%=:\n\t"                                                                \
+  "v_and_b32 %[ax], 0xfffff8, " D1 "\n\t"                                               \
+  "v_and_b32 %[t], 1, " D1 "\n\t"                                                       \
+  "ds_read_b64 %[sc], %[ax]\n\t"                                                        \
+  "v_cmp_eq_u32 vcc, 1, %[t]\n\t"               /* lanes that publish (VM_D1_RCP) */    \
+  MISTRA_VM_REFILL(LO, HI, VX, OFF_LO, OFF_HI)                                          \
+  "s_waitcnt lgkmcnt(5)\n\t"                                                            \
+  "v_mul_f64 %[a1], %[a1], %[r1]\n\t"                                                   \
+  "s_waitcnt lgkmcnt(4)\n\t"                                                            \
+  "v_mul_f64 %[a1], %[a1], %[u1]\n\t"                                                   \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                            \
+  "v_mul_f64 %[a2], %[a2], %[r2]\n\t"                                                   \
+  "v_add_f64 %[acc], %[acc], -%[a1]\n\t"                                                \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                            \
+  "v_mul_f64 %[a2], %[a2], %[u2]\n\t"                                                   \
+  "v_add_f64 %[acc], %[acc], -%[a2]\n\t"                                                \
+  "s_mov_b64 %[sv], exec\n\t"                                                           \
+  "s_andn2_b64 %[sm], exec, vcc\n\t"                                                    \
+  "s_mov_b64 exec, %[sm]\n\t"                   /* lanes that scale */                  \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                            \
+  "v_mul_f64 %[sc], %[acc], %[sc]\n\t"                                                  \
+  "ds_write_b64 %[tg], %[sc]\n\t"                                                       \
+  "s_and_b64 exec, %[sv], vcc\n\t"              /* lanes that publish */                \
+  "s_cbranch_execz Lvm_auxe" S "_%=\n\t"                                                \
+  "ds_write_b64 %[tg], %[acc]\n\t"                                                      \
+  "v_div_scale_f64 %[a1], vcc, %[acc], %[acc], 1.0\n\t"                                 \
+  "v_rcp_f64 %[r1], %[a1]\n\t"                                                          \
+  "v_div_scale_f64 %[u1], vcc, 1.0, %[acc], 1.0\n\t"                                    \
+  "v_fma_f64 %[a2], -%[a1], %[r1], 1.0\n\t"                                             \
+  "v_fma_f64 %[r1], %[r1], %[a2], %[r1]\n\t"                                            \
+  "v_fma_f64 %[a2], -%[a1], %[r1], 1.0\n\t"                                             \
+  "v_fma_f64 %[r1], %[r1], %[a2], %[r1]\n\t"                                            \
+  "v_mul_f64 %[a2], %[u1], %[r1]\n\t"                                                   \
+  "v_fma_f64 %[a1], -%[a1], %[a2], %[u1]\n\t"                                           \
+  "s_nop 1\n\t"                                                                         \
+  "v_div_fmas_f64 %[a1], %[a1], %[r1], %[a2]\n\t"                                       \
+  "v_div_fixup_f64 %[a1], %[a1], %[acc], 1.0\n\t"                                       \
+  "ds_write_b64 %[ax], %[a1]\n"                                                         \
+  "Lvm_auxe" S "_%=:\n\t"                                                               \
+  "s_mov_b64 exec, %[sv]\n\t"                                                           \
+  "s_branch Lvm_done" S "_%=\n"                                                         \
+  "Lvm_null" S "_%=:\n\t"                                                               \
+  MISTRA_VM_REFILL(LO, HI, VX, OFF_LO, OFF_HI)                                          \
+  "s_branch Lvm_done" S "_%=\n"
 
 template <int NT>
 __device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int lane) {
-  // a record is two 16-byte halves: 4 records (8 loads) in flight per lane, consumed in groups of two
-  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)G_(P.wave_base)[wave] * 64 + lane) * 2;
-  int rounds_left = __builtin_amdgcn_readfirstlane(P.nrounds);
-  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
-  vm_ring_load<0>(rp);       vm_ring_load<1, 16>(rp);
-  vm_ring_load<2>(rp + 128); vm_ring_load<3, 16>(rp + 128);
-  vm_ring_load<4>(rp + 256); vm_ring_load<5, 16>(rp + 256);
-  vm_ring_load<6>(rp + 384); vm_ring_load<7, 16>(rp + 384);
-  rp += 4 * 128;
-  while (rounds_left > 0) {
-#define MISTRA_VM_GROUP(K)   /* records 2K and 2K+1 of the ring */                                             \
-    {                                                                                                          \
-      const u32x4 lo0 = vm_ring_take<4 * K, 4>();       /* the four oldest of 8 loads have landed */            \
-      const u32x4 hi0 = vm_ring_take<4 * K + 1, 4>();                                                          \
-      const u32x4 lo1 = vm_ring_take<4 * K + 2, 4>();                                                          \
-      const u32x4 hi1 = vm_ring_take<4 * K + 3, 4>();                                                          \
-      vm_ring_load<4 * K>(rp + (2 * K) * 128);                                                                 \
-      vm_ring_load<4 * K + 1, 16>(rp + (2 * K) * 128);                                                         \
-      vm_ring_load<4 * K + 2>(rp + (2 * K + 1) * 128);                                                         \
-      vm_ring_load<4 * K + 3, 16>(rp + (2 * K + 1) * 128);                                                     \
-      const uint32_t row0 = __builtin_amdgcn_readfirstlane(lo0.z), row1 = __builtin_amdgcn_readfirstlane(lo1.z); \
-      if (!((row0 | row1) & (kD2Eor | kD2Null | kD2Rcp)) ) {                                                   \
-        vm_step_pair(lo0, hi0, lo1, hi1);              /* two plain rows inside one round */                    \
-      } else if (!(row0 & (kD2Eor | kD2Null | kD2Rcp)) && !(row1 & (kD2Null | kD2Rcp))) {                      \
-        vm_step_pair(lo0, hi0, lo1, hi1);              /* ... the second one closing the round */               \
-        lds_barrier();                                                                                         \
-        if (--rounds_left == 0) break;                                                                         \
-      } else {                                                                                                 \
-        if (vm_step(lo0, hi0, rounds_left)) break;                                                             \
-        if (vm_step(lo1, hi1, rounds_left)) break;                                                             \
-      }                                                                                                        \
-    }
-    MISTRA_VM_GROUP(0) MISTRA_VM_GROUP(1)
-#undef MISTRA_VM_GROUP
-    rp += 4 * 128;
-  }
-  // drain: the look-ahead loads must have landed before this function returns
-  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+  const uint64_t recs = reinterpret_cast<uint64_t>(P.recs);      // the same in every lane: move it to SGPRs
+  const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs) |
+                        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(recs >> 32)) << 32);
+  uint32_t va = ((uint32_t)G_(P.wave_base)[wave] * 64u + (uint32_t)lane) * 32u;     // this lane's first record, bytes
+  uint32_t vb = va + 4096u;                                                          // rows +2, +3
+  int rounds = __builtin_amdgcn_readfirstlane(P.nrounds);
+  double acc, a1, r1, u1, a2, r2, u2, sc;
+  uint32_t tg, ax, t, fl;
+  uint64_t sv, sm;
+  asm volatile(
+      "s_waitcnt vmcnt(0)\n\t"                  // nothing of the caller's may sit between the counted loads
+      "s_nop 4\n\t"
+      MISTRA_VM_REFILL("v[48:51]", "v[52:55]", "%[va]", "0", "16")
+      MISTRA_VM_REFILL("v[64:67]", "v[68:71]", "%[va]", "2048", "2064")
+      MISTRA_VM_REFILL("v[80:83]", "v[84:87]", "%[vb]", "0", "16")
+      MISTRA_VM_REFILL("v[96:99]", "v[100:103]", "%[vb]", "2048", "2064")
+      "v_add_u32 %[va], 0x2000, %[va]\n\t"
+      "v_add_u32 %[vb], 0x2000, %[vb]\n"
+      "Lvm_loop_%=:\n\t"
+      MISTRA_VM_RECORD("0", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[48:51]", "v[52:55]", "%[va]", "0", "16")
+      MISTRA_VM_RECORD("1", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v[64:67]", "v[68:71]", "%[va]", "2048", "2064")
+      MISTRA_VM_RECORD("2", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v[80:83]", "v[84:87]", "%[vb]", "0", "16")
+      MISTRA_VM_RECORD("3", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v[96:99]", "v[100:103]", "%[vb]", "2048", "2064")
+      "v_add_u32 %[va], 0x2000, %[va]\n\t"
+      "v_add_u32 %[vb], 0x2000, %[vb]\n\t"
+      "s_branch Lvm_loop_%=\n"
+      MISTRA_VM_RECORD_TAIL("0", "v48", "v49", "v[48:51]", "v[52:55]", "%[va]", "0", "16")
+      MISTRA_VM_RECORD_TAIL("1", "v64", "v65", "v[64:67]", "v[68:71]", "%[va]", "2048", "2064")
+      MISTRA_VM_RECORD_TAIL("2", "v80", "v81", "v[80:83]", "v[84:87]", "%[vb]", "0", "16")
+      MISTRA_VM_RECORD_TAIL("3", "v96", "v97", "v[96:99]", "v[100:103]", "%[vb]", "2048", "2064")
+      "Lvm_exit_%=:\n\t"
+      "s_waitcnt vmcnt(0)"                      // the look-ahead loads must have landed before the ring registers are reused
+      : [acc] "=&v"(acc), [a1] "=&v"(a1), [r1] "=&v"(r1), [u1] "=&v"(u1), [a2] "=&v"(a2), [r2] "=&v"(r2), [u2] "=&v"(u2),
+        [sc] "=&v"(sc), [tg] "=&v"(tg), [ax] "=&v"(ax), [t] "=&v"(t), [fl] "=&s"(fl), [sv] "=&s"(sv), [sm] "=&s"(sm),
+        [va] "+v"(va), [vb] "+v"(vb), [rounds] "+s"(rounds)
+      : [base] "s"(base)
+      : "memory", "vcc", "scc", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68",
+        "v69", "v70", "v71", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v96", "v97", "v98", "v99", "v100",
+        "v101", "v102", "v103");
 }
+#undef MISTRA_VM_REFILL
+#undef MISTRA_VM_UPDATES
+#undef MISTRA_VM_RECORD
+#undef MISTRA_VM_RECORD_TAIL
 
 // ---- tail chain of the triangular solves (schedule.hpp: TailSolve), run by ONE wave: lane l holds rows h+l and
 //      h+64+l of the solution in registers, the pivot value travels by v_readlane, matrix entries are gathered from

@@ -19,7 +19,7 @@ struct Item {            // one chunk of one entry inside one round
 };
 
 uint32_t vm_off(int idx, uint32_t flags) {
-  if (idx < 0 || idx >= (1 << 20)) throw std::logic_error("VM index out of range");
+  if (idx < 0 || idx >= (1 << 21)) throw std::logic_error("VM index out of range");
   return ((uint32_t)idx << 3) | flags;
 }
 
@@ -132,9 +132,8 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
   const uint32_t one_off = vm_off(lay.one(), 0), trash_off = vm_off(lay.trash(), 0);
   auto idle_record = [&](std::vector<uint32_t>& out, uint32_t row_flags) {
     out.push_back(trash_off);
-    out.push_back(one_off);
-    out.push_back(zoff | row_flags);
-    for (int q = 3; q < VM_REC_WORDS; q++) out.push_back(zoff);
+    out.push_back(one_off | row_flags);
+    for (int q = 2; q < VM_REC_WORDS; q++) out.push_back(zoff);
   };
   int ridx = 0;
   for (auto& kv : rounds) {
@@ -160,8 +159,8 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
             aux = E.rcp;
           }
         }
-        w.push_back(vm_off(E.tgt, r > 0 ? VM_D0_CONT : 0u));
-        w.push_back(vm_off(aux, f1));
+        w.push_back(vm_off(E.tgt, 0));
+        w.push_back(vm_off(aux, f1 | (r > 0 ? VM_D1_CONT : 0u)));
         for (int u = 0; u < VM_UPD_PER_REC; u++) {
           int i = r * VM_UPD_PER_REC + u;
           if (i < it.count) {
@@ -186,17 +185,17 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
       const size_t rows = std::max<size_t>(n, 1);       // a wave with no work still gets a null row carrying the round mark
       P.blk_n[(size_t)ridx * P.nw + wv] = (uint16_t)rows;
       for (size_t r = 0; r < rows; r++) {
-        uint32_t row_flags = (r == rows - 1 ? VM_D2_EOR : 0u) | (n == 0 ? VM_D2_NULL : 0u);
+        uint32_t row_flags = (r == rows - 1 ? VM_ROW_EOR : 0u) | (n == 0 ? VM_ROW_NULL : 0u);
         for (int l = 0; l < 64; l++) {
           const auto& w = prog[(size_t)wv * 64 + l];
           if (r * VM_REC_WORDS < w.size() &&
-              ((w[r * VM_REC_WORDS + 1] & VM_D1_RCP) || (w[r * VM_REC_WORDS + 1] & VM_OFF_MASK) != one_off))
-            row_flags |= VM_D2_RCP;      // the row needs its aux operand (reciprocal to publish, or a scale factor != 1.0)
+              ((w[r * VM_REC_WORDS + 1] & VM_D1_RCP) || (w[r * VM_REC_WORDS + 1] & VM_AUX_MASK) != one_off))
+            row_flags |= VM_ROW_AUX;      // the row needs its aux operand (reciprocal to publish, or a scale factor != 1.0)
         }
         for (int l = 0; l < 64; l++) {
           const auto& w = prog[(size_t)wv * 64 + l];
           if (r * VM_REC_WORDS < w.size()) {
-            for (int q = 0; q < VM_REC_WORDS; q++) stream[(size_t)wv].push_back(w[r * VM_REC_WORDS + q] | (q == 2 ? row_flags : 0u));
+            for (int q = 0; q < VM_REC_WORDS; q++) stream[(size_t)wv].push_back(w[r * VM_REC_WORDS + q] | (q == 1 ? row_flags : 0u));
           } else {
             idle_record(stream[(size_t)wv], row_flags);      // loads the 0.0 cell, stores nothing
           }

@@ -9,8 +9,8 @@
 //    fixed 32-byte RECORDS whose fields are LDS byte offsets (a 16-byte packing of 14-bit indices was tried: the extra
 //    decode arithmetic cost more than the halved table stream saved).  Records are self-contained (no state carried from one
 //    to the next, no per-lane flags to decode):
-//        d0 = tgt     d1 = aux (| RCP)     d2..d4 = a1,r1,u1     d5..d7 = a2,r2,u2      (d2 also carries the row marks)
-//        acc = CONT ? (what this lane's previous record stored) : M[tgt];
+//        d0 = tgt     d1 = aux | marks     d2..d4 = a1,r1,u1     d5..d7 = a2,r2,u2
+//        acc = M[tgt];         (a continuation record finds what the lane's previous record stored)
 //        acc -= (M[a1]*M[r1])*M[u1];   acc -= (M[a2]*M[r2])*M[u2];      (three roundings per update, no
 //                                                                                        contraction)
 //        M[tgt] = acc * M[aux]            aux = the 1.0 cell unless the entry is scaled by a pivot reciprocal
@@ -56,16 +56,18 @@
 
 namespace mistra {
 
-// record marks (low three bits of an 8-byte-aligned LDS byte offset)
-constexpr uint32_t VM_D0_CONT = 1u;    // on d0: continuation record of the lane's previous record (same target); an executor
-                                       // that prefetches operands must carry the accumulator instead of reloading the target
-                                       // (the shipped one does not prefetch: measured no gain, the loop is issue-bound)
-constexpr uint32_t VM_D1_RCP = 1u;     // on d1: publish 1/result to aux instead of scaling by M[aux]
-constexpr uint32_t VM_D2_EOR = 1u;     // on d2 of every lane of a row: last row of this round for the wave -> barrier
-constexpr uint32_t VM_D2_NULL = 2u;    // on d2: the row carries no work (a wave with nothing to do in a round)
-constexpr uint32_t VM_D2_RCP = 4u;     // on d2 of every lane of a row: some lane of the row publishes a reciprocal OR scales by
-                                       // M[aux] != 1.0 cell; rows without the mark skip the aux read and the final multiply
-constexpr uint32_t VM_OFF_MASK = ~7u;
+// record marks: every mark rides on d1 (the aux operand, which only marked rows read), so that d0 and d2..d7 are LDS
+// byte addresses the executor hands to ds_read/ds_write as they stand
+constexpr uint32_t VM_D1_RCP = 1u;           // lane: publish 1/result to aux instead of scaling by M[aux]
+constexpr uint32_t VM_D1_CONT = 2u;          // lane: continuation record of the lane's previous record (same target).  The
+                                             // shipped executor reloads the target (LDS is in-order within a wave); an
+                                             // executor that prefetched operands would have to carry the accumulator
+constexpr uint32_t VM_ROW_EOR = 1u << 24;    // every lane of a row: last row of this round for the wave -> barrier
+constexpr uint32_t VM_ROW_NULL = 1u << 25;   // every lane of a row: the row carries no work (a wave with nothing to do in a round)
+constexpr uint32_t VM_ROW_AUX = 1u << 26;    // every lane of a row: some lane publishes a reciprocal OR scales by M[aux] != 1.0
+                                             // cell; rows without the mark skip the aux read and the final multiply
+constexpr int VM_ROW_EOR_BIT = 24, VM_ROW_NULL_BIT = 25, VM_ROW_AUX_BIT = 26;
+constexpr uint32_t VM_AUX_MASK = 0x00FFFFF8u;   // byte address part of d1
 constexpr int VM_REC_WORDS = 8;
 constexpr int VM_UPD_PER_REC = 2;
 constexpr int VM_LOOKAHEAD_ROWS = 16;    // >= 2x the kernel's table look-ahead depth (ros3_kernel.hip)

@@ -49,10 +49,10 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
         bool own_raw = false;
         for (int ridx = 0; ridx < n; ridx++) {
           const uint32_t* rec = &P.recs[((base + ridx) * 64 + l) * VM_REC_WORDS];
-          if ((rec[2] & VM_D2_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
-          if (rec[2] & VM_D2_NULL) continue;
+          if ((rec[1] & VM_ROW_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
+          if (rec[1] & VM_ROW_NULL) continue;
           auto rd = [&](uint32_t off) {
-            const int i = (int)((off & VM_OFF_MASK) >> 3);
+            const int i = (int)((off & VM_AUX_MASK) >> 3);
             if (i != trash) {
               reads.emplace_back(i, lane);
               if (writer[i] == lane) own_raw = true;   // the kernel prefetches operands: a lane may not read back its own store
@@ -66,9 +66,10 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
             writer[i] = lane;
             return 0;
           };
-          const int tgt = (int)((rec[0] & VM_OFF_MASK) >> 3), aux = (int)((rec[1] & VM_OFF_MASK) >> 3);
-          double acc = (rec[0] & VM_D0_CONT) ? carry : rd(rec[0]);
-          if ((rec[0] & VM_D0_CONT) && ridx == 0) return -7;   // a continuation cannot open a round
+          if ((rec[0] & 7u) || (rec[0] >> 24)) return -10;   // d0 must be a bare address
+          const int tgt = (int)(rec[0] >> 3), aux = (int)((rec[1] & VM_AUX_MASK) >> 3);
+          double acc = (rec[1] & VM_D1_CONT) ? carry : rd(rec[0]);
+          if ((rec[1] & VM_D1_CONT) && ridx == 0) return -7;   // a continuation cannot open a round
           for (int u = 0; u < VM_UPD_PER_REC; u++) {
             const double av = rd(rec[2 + 3 * u]), rv = rd(rec[3 + 3 * u]), uv = rd(rec[4 + 3 * u]);
             const double mlt = av * rv;
@@ -76,14 +77,14 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
             acc = acc - p;
           }
           if (rec[1] & VM_D1_RCP) {
-            if (!(rec[2] & VM_D2_RCP)) return -6;   // row mark missing
+            if (!(rec[1] & VM_ROW_AUX)) return -6;   // row mark missing
             if (wr(tgt, acc)) return -2;
             if (wr(aux, 1.0 / acc)) return -2;
             carry = acc;
           } else {
             double res = acc;
-            if (rec[2] & VM_D2_RCP) res = acc * rd(rec[1]);        // rows without the mark skip the (then 1.0) factor
-            else if ((int)((rec[1] & VM_OFF_MASK) >> 3) != one_cell) return -9;   // unmarked row with a real scale factor
+            if (rec[1] & VM_ROW_AUX) res = acc * rd(rec[1]);        // rows without the mark skip the (then 1.0) factor
+            else if ((int)((rec[1] & VM_AUX_MASK) >> 3) != one_cell) return -9;   // unmarked row with a real scale factor
             if (wr(tgt, res)) return -2;
             carry = res;
           }
