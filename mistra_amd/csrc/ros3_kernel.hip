@@ -73,46 +73,50 @@ constexpr double kRosElo = 3.0;
 __device__ __forceinline__ double fmin_f(double a, double b) { return (a < b || b != b) ? a : b; }   // Fortran MIN
 __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || b != b) ? a : b; }   // Fortran MAX
 
-// ---- the LDS VM (schedule.hpp): rounds separated by LDS barriers; each lane walks 16-byte records of its wave's
-//      linear stream, table loads running kPrefetch records ahead of use
-// Record ring in the accumulator registers a[0:31].  hipcc's own s_waitcnt placement falls back to vmcnt(0) inside the
-// VM loop (branches, barrier), which would serialise every record behind a full memory round trip, so the table loads
-// are issued from asm and counted by hand.  A VGPR destination would be unsafe (the compiler may copy an asm output
-// before the data lands, cdna_hip_programming.md §5.7 item 1); this kernel has no MFMA, so the AGPR half of the
-// register file is free: the loads land in a[4k:4k+3], which only the two statements below ever name, and the consume
-// statement waits and copies out in ONE asm (§5.7 form i).  Loads return in issue order, hence "at most kVmDepth-1
-// outstanding" means the oldest one — the slot about to be consumed — has landed.
+// ---- table look-ahead ring of the tail chain and the gather-sum machine: eight 16-byte loads in flight per lane.
+// hipcc's own s_waitcnt placement falls back to vmcnt(0) around branches and barriers, which would serialise every
+// table row behind a full memory round trip, so the loads are issued from asm and counted by hand.  A compiler-visible
+// VGPR destination would be unsafe (the compiler may copy an asm output before the data lands, cdna_hip_programming.md
+// §5.7 item 1).  The ring therefore lives in four caller-saved register blocks at the top of the file, v192-199,
+// v208-215, v224-231, v240-247, named only by the two statements below; the consume statement waits and copies out in
+// ONE asm (§5.7 form i).  Loads are in flight only inside the two non-inlined functions that use the ring (each drains
+// it before returning), and those functions' own values sit far below v192 (they need < 72 registers;
+// tests/test_capi.py checks the generated ISA), so nothing of the compiler's can be hit by a landing load; the callers
+// see the blocks as ordinary call-clobbered registers.  Loads return in issue
+// order, hence "at most PENDING outstanding" means the oldest one — the slot about to be consumed — has landed.
+// (An earlier version kept the ring in AGPRs: any AGPR use halves the compiler's VGPR budget to 128 on gfx950, which
+// cost the kernel ~100 spilled registers.)
 template <int K, int BYTE_OFFSET = 0>
 __device__ __forceinline__ void vm_ring_load(gptr<u32x4> p) {
-#define MISTRA_RING_LOAD(A0, A1, A2, A3)                                                                              \
-  asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, off offset:%1" : : "v"(p), "n"(BYTE_OFFSET)             \
-               : "memory", "a" #A0, "a" #A1, "a" #A2, "a" #A3)
-  if constexpr (K == 0) MISTRA_RING_LOAD(0, 1, 2, 3);
-  else if constexpr (K == 1) MISTRA_RING_LOAD(4, 5, 6, 7);
-  else if constexpr (K == 2) MISTRA_RING_LOAD(8, 9, 10, 11);
-  else if constexpr (K == 3) MISTRA_RING_LOAD(12, 13, 14, 15);
-  else if constexpr (K == 4) MISTRA_RING_LOAD(16, 17, 18, 19);
-  else if constexpr (K == 5) MISTRA_RING_LOAD(20, 21, 22, 23);
-  else if constexpr (K == 6) MISTRA_RING_LOAD(24, 25, 26, 27);
-  else MISTRA_RING_LOAD(28, 29, 30, 31);
+#define MISTRA_RING_LOAD(R0, R1, R2, R3)                                                                              \
+  asm volatile("global_load_dwordx4 v[" #R0 ":" #R3 "], %0, off offset:%1" : : "v"(p), "n"(BYTE_OFFSET)             \
+               : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3)
+  if constexpr (K == 0) MISTRA_RING_LOAD(192, 193, 194, 195);
+  else if constexpr (K == 1) MISTRA_RING_LOAD(196, 197, 198, 199);
+  else if constexpr (K == 2) MISTRA_RING_LOAD(208, 209, 210, 211);
+  else if constexpr (K == 3) MISTRA_RING_LOAD(212, 213, 214, 215);
+  else if constexpr (K == 4) MISTRA_RING_LOAD(224, 225, 226, 227);
+  else if constexpr (K == 5) MISTRA_RING_LOAD(228, 229, 230, 231);
+  else if constexpr (K == 6) MISTRA_RING_LOAD(240, 241, 242, 243);
+  else MISTRA_RING_LOAD(244, 245, 246, 247);
 #undef MISTRA_RING_LOAD
 }
 
 template <int K, int PENDING = 7>
 __device__ __forceinline__ u32x4 vm_ring_take() {
   uint32_t x, y, z, w;
-#define MISTRA_RING_TAKE(A0, A1, A2, A3)                                                                              \
-  asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1                 \
-               "\n\tv_accvgpr_read_b32 %2, a" #A2 "\n\tv_accvgpr_read_b32 %3, a" #A3                                  \
+#define MISTRA_RING_TAKE(R0, R1, R2, R3)                                                                              \
+  asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1                                   \
+               "\n\tv_mov_b32 %2, v" #R2 "\n\tv_mov_b32 %3, v" #R3                                                    \
                : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : "n"(PENDING) : "memory")
-  if constexpr (K == 0) MISTRA_RING_TAKE(0, 1, 2, 3);
-  else if constexpr (K == 1) MISTRA_RING_TAKE(4, 5, 6, 7);
-  else if constexpr (K == 2) MISTRA_RING_TAKE(8, 9, 10, 11);
-  else if constexpr (K == 3) MISTRA_RING_TAKE(12, 13, 14, 15);
-  else if constexpr (K == 4) MISTRA_RING_TAKE(16, 17, 18, 19);
-  else if constexpr (K == 5) MISTRA_RING_TAKE(20, 21, 22, 23);
-  else if constexpr (K == 6) MISTRA_RING_TAKE(24, 25, 26, 27);
-  else MISTRA_RING_TAKE(28, 29, 30, 31);
+  if constexpr (K == 0) MISTRA_RING_TAKE(192, 193, 194, 195);
+  else if constexpr (K == 1) MISTRA_RING_TAKE(196, 197, 198, 199);
+  else if constexpr (K == 2) MISTRA_RING_TAKE(208, 209, 210, 211);
+  else if constexpr (K == 3) MISTRA_RING_TAKE(212, 213, 214, 215);
+  else if constexpr (K == 4) MISTRA_RING_TAKE(224, 225, 226, 227);
+  else if constexpr (K == 5) MISTRA_RING_TAKE(228, 229, 230, 231);
+  else if constexpr (K == 6) MISTRA_RING_TAKE(240, 241, 242, 243);
+  else MISTRA_RING_TAKE(244, 245, 246, 247);
 #undef MISTRA_RING_TAKE
   return u32x4{x, y, z, w};
 }
@@ -221,7 +225,7 @@ static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots")
   "s_branch Lvm_done" S "_%=\n"
 
 template <int NT>
-__device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int lane) {
+__device__ __attribute__((noinline)) void vm_run(const VmDev P, int wave, int lane) {
   const uint64_t recs = reinterpret_cast<uint64_t>(P.recs);      // the same in every lane: move it to SGPRs
   const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs) |
                         ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(recs >> 32)) << 32);
@@ -269,7 +273,7 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev& P, int wave, int l
 
 // ---- tail chain of the triangular solves (schedule.hpp: TailSolve), run by ONE wave: lane l holds rows h+l and
 //      h+64+l of the solution in registers, the pivot value travels by v_readlane, matrix entries are gathered from
-//      LDS through per-column index tables streamed with the same AGPR ring as the VM (one 16-byte slot = 4 columns).
+//      LDS through per-column index tables streamed through the look-ahead ring (one 16-byte slot = 4 columns).
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   const uint64_t u = __builtin_bit_cast(uint64_t, v);
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
@@ -279,7 +283,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 
 // FORWARD = false: the vector has been forward-swept already (stage 1: inside the LU program), only the backward chain runs
 template <int R, bool FORWARD>
-__device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t xb, uint32_t rb, int lane) {
+__device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t xb, uint32_t rb, int lane) {
   constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
   double x[R], rd[R];
 #pragma unroll
@@ -375,7 +379,7 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev& T, uint32_t 
 }
 
 // ---- the gather-sum machine (schedule.hpp): out[q] = c0*M[i0] + c1*M[i1] + ...  left to right, four terms per table
-//      row, rows streamed through the AGPR ring (4 rows in flight).  acc starts at -0.0 and padding terms are
+//      row, rows streamed through the look-ahead ring (4 rows in flight).  acc starts at -0.0 and padding terms are
 //      (-0.0f)*(0.0 cell), so no flags are needed and the sums are bit-for-bit the flagged ones.
 template <int NQ>
 struct GsOut {
@@ -383,7 +387,7 @@ struct GsOut {
 };
 
 template <int NT, int NQ>
-__device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev& P, int wave, int lane) {
+__device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev P, int wave, int lane) {
   GsOut<NQ> out;
   int n[NQ];
 #pragma unroll
@@ -425,7 +429,7 @@ __device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev& P, int wave
 
 }  // namespace
 
-template <class MT, int NT>
+template <class MT, int NT, bool PROF>
 __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) {
   constexpr int NVAR = MT::NVAR, NFIX = MT::NFIX, NREACT = MT::NREACT, NNZ = MT::NNZ, NB = MT::NB, NCONST = MT::NCONST;
   constexpr int NW = NT / 64;
@@ -467,6 +471,13 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
   for (int q = 0; q < JPT; q++) jpos[q] = G_(a.jvs_pos)[q * NT + t];
 #pragma unroll
   for (int q = 0; q < ZPT; q++) zpos[q] = G_(a.zero_pos)[q * NT + t];
+  // factor words of the products this thread forms in Fun (one per owned reaction) and Jac_SP (up to three): static per
+  // mechanism, kept in registers for the whole integration instead of being fetched ~400 times per cell
+  uint64_t ffac[RPT], jfac[3 * RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; q++) ffac[q] = G_(a.fun_fac)[q * NT + t];
+#pragma unroll
+  for (int q = 0; q < 3 * RPT; q++) jfac[q] = G_(a.jac_fac)[q * NT + t];
   if (t < NFIX) X[NVAR + t] = G_(a.fix)[(size_t)cell * NFIX + t];
   if (t < NCONST) X[NVAR + NFIX + t] = G_(a.consts)[t];
   if (t == 0) {   // the VM's constant cells: 0.0 (padding update slots), 1.0 (neutral factor), -1.0 (partial-sum combine)
@@ -476,11 +487,11 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
   }
 
   // optional phase timing (diagnostics only): cycles of wave 0 between phase boundaries, summed per cell
-  const bool profiling = a.prof != nullptr;
+  constexpr bool profiling = PROF;       // a compile-time variant: twelve 64-bit counters are not carried by the product kernel
   unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = profiling ? clock64() : 0ull;
   const unsigned long long t_begin = t_last;
   auto lap = [&](int slot) {
-    if (profiling) {
+    if constexpr (profiling) {
       const unsigned long long now = clock64();
       pc[slot] += now - t_last;
       t_last = now;
@@ -497,7 +508,8 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     lds_barrier();
 #pragma unroll
     for (int q = 0; q < RPT; q++) {
-      const uint64_t w = G_(a.fun_fac)[q * NT + t];
+      uint64_t w = ffac[q];
+      asm volatile("" : "+v"(w));   // decode here: hoisted out of the step loop, the derived addresses only spill
       double p = rct[q] * X[w & 0xFFFFu];
       p = p * X[(w >> 16) & 0xFFFFu];
       p = p * X[(w >> 32) & 0xFFFFu];
@@ -517,7 +529,8 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     for (int q = 0; q < RPT; q++) {
 #pragma unroll
       for (int b = 0; b < 3; b++) {
-        const uint64_t w = G_(a.jac_fac)[(q * 3 + b) * NT + t];
+        uint64_t w = jfac[q * 3 + b];
+        asm volatile("" : "+v"(w));
         double p = rct[q] * X[w & 0xFFFFu];
         p = p * X[(w >> 16) & 0xFFFFu];
         p = p * X[(w >> 32) & 0xFFFFu];
@@ -756,7 +769,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     GM_(a.ierr)[cell] = ierr;
     gptr_mut<int32_t> st = GM_(a.stats) + (size_t)cell * 8;
     st[0] = nfun; st[1] = njac; st[2] = nstp; st[3] = nacc; st[4] = nrej; st[5] = ndec; st[6] = nsol; st[7] = nsng;
-    if (profiling) {
+    if constexpr (profiling) {
       lap(6);
       pc[7] = clock64() - t_begin;
       for (int k = 0; k < 12; k++) GM_(a.prof)[(size_t)cell * 12 + k] = pc[k];
@@ -773,15 +786,18 @@ template <class MT, int NT>
 hipError_t launch_ros3(const KernelArgs& a, hipStream_t stream) {
   constexpr size_t lds_bytes = LdsLayout<MT, NT>::TOTAL * sizeof(double);
   static bool configured = false;
-  auto kern = ros3_integrate_kernel<MT, NT>;
+  auto kern = ros3_integrate_kernel<MT, NT, false>;
+  auto kern_prof = ros3_integrate_kernel<MT, NT, true>;      // MISTRA_CHEM_PROFILE diagnostics (capi.cpp)
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes);
-    if (e != hipSuccess) return e;
+    for (const void* k : {reinterpret_cast<const void*>(kern), reinterpret_cast<const void*>(kern_prof)}) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+    }
     configured = true;
   }
   if (a.ncell <= 0) return hipSuccess;
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.ncell), dim3(NT), lds_bytes, stream, a);
+  if (a.prof) hipLaunchKernelGGL(kern_prof, dim3((unsigned)a.ncell), dim3(NT), lds_bytes, stream, a);
+  else hipLaunchKernelGGL(kern, dim3((unsigned)a.ncell), dim3(NT), lds_bytes, stream, a);
   return hipGetLastError();
 }
 
