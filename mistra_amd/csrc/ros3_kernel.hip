@@ -466,11 +466,14 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     rct[q] = r < NREACT ? G_(a.rconst)[(size_t)cell * NREACT + r] : 0.0;
   }
   // Ghimj slots this thread fills in ros_PrepareMatrix (static per mechanism): fetched once, not once per attempt
-  uint32_t jpos[JPT], zpos[ZPT];
+  // (two 16-bit positions per register)
+  uint32_t jpos[(JPT + 1) / 2], zpos[(ZPT + 1) / 2];
 #pragma unroll
-  for (int q = 0; q < JPT; q++) jpos[q] = G_(a.jvs_pos)[q * NT + t];
+  for (int q = 0; q < (JPT + 1) / 2; q++)
+    jpos[q] = (uint32_t)G_(a.jvs_pos)[(2 * q) * NT + t] | ((2 * q + 1 < JPT ? (uint32_t)G_(a.jvs_pos)[(2 * q + 1) * NT + t] : (uint32_t)kPosNone) << 16);
 #pragma unroll
-  for (int q = 0; q < ZPT; q++) zpos[q] = G_(a.zero_pos)[q * NT + t];
+  for (int q = 0; q < (ZPT + 1) / 2; q++)
+    zpos[q] = (uint32_t)G_(a.zero_pos)[(2 * q) * NT + t] | ((2 * q + 1 < ZPT ? (uint32_t)G_(a.zero_pos)[(2 * q + 1) * NT + t] : (uint32_t)kPosNone) << 16);
   // factor words of the products this thread forms in Fun (one per owned reaction) and Jac_SP (up to three): static per
   // mechanism, kept in registers for the whole integration instead of being fetched ~400 times per cell
   uint64_t ffac[RPT], jfac[3 * RPT];
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       double p = rct[q] * X[w & 0xFFFFu];
       p = p * X[(w >> 16) & 0xFFFFu];
       p = p * X[(w >> 32) & 0xFFFFu];
-      if ((w >> 48) & 1u) AB[q * NT + t] = p;
+      AB[(uint32_t)(w >> 48)] = p;            // a slot without a reaction (rct = 0) writes the spare cell: no branch
     }
     lds_barrier();
     const GsOut<SPT> g = gsum_run<NT, SPT>(a.vdot, wave, lane);
@@ -534,8 +537,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
         double p = rct[q] * X[w & 0xFFFFu];
         p = p * X[(w >> 16) & 0xFFFFu];
         p = p * X[(w >> 32) & 0xFFFFu];
-        const uint32_t o = (uint32_t)(w >> 48);
-        if (o != 0xFFFFu) AB[o] = p;
+        AB[(uint32_t)(w >> 48)] = p;          // unused product slots write the spare cell: no branch, the products interleave
       }
     }
     lds_barrier();
@@ -557,7 +559,9 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     bool zero_diag = false;
 #pragma unroll
     for (int q = 0; q < JPT; q++) {
-      const uint32_t p = jpos[q];
+      uint32_t pw = jpos[q / 2];
+      asm volatile("" : "+v"(pw));        // unpack here, not hoisted into registers that live across the step loop
+      const uint32_t p = (q & 1) ? (pw >> 16) : (pw & 0xFFFFu);
       if (p != kPosNone) {
         double v = -jac0[q];
         if (p & kPosDiag) {
@@ -569,7 +573,9 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
     }
 #pragma unroll
     for (int q = 0; q < ZPT; q++) {
-      const uint32_t p = zpos[q];
+      uint32_t pw = zpos[q / 2];
+      asm volatile("" : "+v"(pw));
+      const uint32_t p = (q & 1) ? (pw >> 16) : (pw & 0xFFFFu);
       if (p != kPosNone) {
         double v = -0.0;
         if (p & kPosDiag) {

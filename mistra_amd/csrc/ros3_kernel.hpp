@@ -24,7 +24,8 @@ struct LdsLayout {
   static constexpr int M = 0;                                         // Ghimj | XS | 0.0 | 1.0 | trash | -1.0 | R | temps
   static constexpr int X = M + round_up2(MT::NNZ + 2 * MT::NVAR + 4 + MT::MAX_TEMPS);  // V | F | consts
   static constexpr int AB = X + round_up2(MT::NVAR + MT::NFIX + MT::NCONST);           // A or B products
-  static constexpr int RED = AB + round_up2(max_i(MT::NREACT, MT::NB));                // per-wave partial sums
+  static constexpr int AB_TRASH = max_i(MT::NREACT, MT::NB);                           // spare cell: products no reaction owns land here
+  static constexpr int RED = AB + round_up2(AB_TRASH + 1);                             // per-wave partial sums
   static constexpr int FLAGS = RED + 32;
   static constexpr int TOTAL = FLAGS + 2;
   static_assert(TOTAL * 8 <= 160 * 1024, "cell state does not fit the 160 KiB LDS of a gfx950 CU");

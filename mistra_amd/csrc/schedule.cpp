@@ -482,13 +482,14 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   const uint64_t one = (uint64_t)(m.nvar + m.nfix);       // X slot of the constant 1.0
 
   // ---- Fun_x products
-  S.fun_fac.assign((size_t)S.rpt * nt, one | (one << 16) | (one << 32));
+  const uint64_t ab_trash = (uint64_t)std::max(m.nreact, m.nb);     // spare cell behind the A/B product array (LdsLayout::AB_TRASH)
+  S.fun_fac.assign((size_t)S.rpt * nt, one | (one << 16) | (one << 32) | (ab_trash << 48));
   for (int r = 0; r < m.nreact; r++) {
     uint64_t f[3] = {one, one, one};
     int nf = m.a_ptr[r + 1] - m.a_ptr[r];
     if (nf > 3) throw std::logic_error("reaction with more than 3 factors");
     for (int i = 0; i < nf; i++) f[i] = (uint64_t)m.a_fac[(size_t)m.a_ptr[r] + i];
-    S.fun_fac[(size_t)r] = f[0] | (f[1] << 16) | (f[2] << 32) | (1ull << 48);
+    S.fun_fac[(size_t)r] = f[0] | (f[1] << 16) | (f[2] << 32) | ((uint64_t)r << 48);
   }
   {
     std::vector<std::vector<std::pair<int, double>>> outs((size_t)m.nvar);
@@ -501,7 +502,7 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   }
 
   // ---- Jac_SP_x products, under the owning reaction
-  S.jac_fac.assign((size_t)S.rpt * 3 * nt, one | (one << 16) | (one << 32) | (0xFFFFull << 48));
+  S.jac_fac.assign((size_t)S.rpt * 3 * nt, one | (one << 16) | (one << 32) | (ab_trash << 48));
   {
     std::vector<int> used((size_t)m.nreact, 0);
     for (int b = 0; b < m.nb; b++) {

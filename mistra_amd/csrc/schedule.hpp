@@ -142,10 +142,10 @@ struct KernelSchedule {
   int n_jnz = 0, n_jzero = 0;
   uint32_t ab_base_bytes = 0;
   // Fun_x products: A(r) = RCT(r)*X[f1]*X[f2]*X[f3], padded with the constant 1.0
-  std::vector<uint64_t> fun_fac;                // [rpt*nt]  f1 | f2<<16 | f3<<32 | valid<<48
+  std::vector<uint64_t> fun_fac;                // [rpt*nt]  f1 | f2<<16 | f3<<32 | out<<48   (out = reaction, or the spare cell max(nreact,nb) for a thread without one)
   GsumProgram vdot;                             // src = A (LDS), output (q,t) = species q*nt+t
   // Jac_SP_x products, grouped under the reaction that owns the rate constant: up to 3 B's per reaction
-  std::vector<uint64_t> jac_fac;                // [(q*3 + b)*nt + t]  f1 | f2<<16 | f3<<32 | out<<48 (0xFFFF = none)
+  std::vector<uint64_t> jac_fac;                // [(q*3 + b)*nt + t]  f1 | f2<<16 | f3<<32 | out<<48 (the spare cell = none)
   GsumProgram jvs;                              // src = B (LDS), output (q,t) = jac0 register q of thread t
   std::vector<uint16_t> jvs_pos;                // [jpt*nt] Ghimj slot (| POS_DIAG) of that output, POS_NONE = idle
   std::vector<uint16_t> zero_pos;               // [zpt*nt] Ghimj slots that Jac_SP_x sets to 0 (| POS_DIAG)

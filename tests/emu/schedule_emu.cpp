@@ -3,6 +3,7 @@
 // without a GPU: same words, same per-lane order, lanes executed one after the other, with a hazard check that no
 // lane reads an M slot another lane writes in the same round.  It is NOT part of the product library and is never
 // a fallback: mistra_amd/ does not link it.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -252,8 +253,9 @@ void emu_fun(void* h, const double* V, const double* F, const double* RCT, doubl
   for (int q = 0; q < s.rpt; q++)
     for (int t = 0; t < s.nt; t++) {
       uint64_t w = s.fun_fac[(size_t)q * s.nt + t];
-      if (!((w >> 48) & 1)) continue;
-      int r = q * s.nt + t;
+      const int out = (int)((w >> 48) & 0xFFFF), r = q * s.nt + t;
+      if (out == std::max(e->m.nreact, e->m.nb)) continue;       // the spare cell: this thread owns no reaction in slot q
+      if (out != r) std::abort();
       double a = RCT[r];
       a = a * X[w & 0xFFFF];
       a = a * X[(w >> 16) & 0xFFFF];
@@ -276,7 +278,7 @@ void emu_jac_prepare(void* h, const double* V, const double* F, const double* RC
       for (int t = 0; t < s.nt; t++) {
         uint64_t w = s.jac_fac[((size_t)q * 3 + b) * s.nt + t];
         int out = (int)((w >> 48) & 0xFFFF);
-        if (out == 0xFFFF) continue;
+        if (out == std::max(e->m.nreact, e->m.nb)) continue;
         double v = RCT[q * s.nt + t];
         v = v * X[w & 0xFFFF];
         v = v * X[(w >> 16) & 0xFFFF];
