@@ -108,6 +108,7 @@ struct VmProgram {
   std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*8 + k]   two uint4 per lane and row
   // census
   int64_t n_updates = 0, n_items = 0, n_records = 0, wave_rows = 0, crit_rows = 0;
+  int64_t lds_cycles = 0;                       // modelled LDS-array cycles of all operand gathers and stores (bank conflicts included)
 };
 
 struct GsumProgram {
