@@ -61,5 +61,38 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def ring_register_report(isa_path=None):
+    """Checks the one assumption the table look-ahead ring of ros3_kernel.hip rests on (see the comment there): in the
+    non-inlined device functions, every register the COMPILER allocates stays below the ring's blocks (v192..v247), so a
+    table load landing in the ring can never hit a compiler value.  Compiles the kernel source to gfx950 assembly and
+    scans it.  Returns {function: highest VGPR named outside inline asm}; raises if a device function reaches v192."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        if isa_path is None:
+            isa_path = os.path.join(tmp, "ros3_kernel.s")
+            cmd = [hipcc(), "--offload-arch=" + ARCH] + [f for f in COMMON if f != "-fPIC"] + \
+                  ["-S", "--offload-device-only", os.path.join(CSRC, "ros3_kernel.hip"), "-o", isa_path]
+            subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        lines = open(isa_path).read().split("\n")
+    starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_ZN6mistra.*:", l)]
+    starts.append((len(lines), "end"))
+    report = {}
+    for (i, name), (j, _) in zip(starts, starts[1:]):
+        in_asm, hi = False, 0
+        for l in lines[i:j]:
+            if "ASMSTART" in l:
+                in_asm = True
+            elif "ASMEND" in l:
+                in_asm = False
+            elif not in_asm and not l.strip().startswith((";", ".")):
+                for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", l):
+                    hi = max(hi, int(m.group(1) or m.group(3)))
+        report[name] = hi
+        if "kernel" not in name and hi >= 192:
+            raise RuntimeError("%s: the compiler allocates v%d, inside the look-ahead ring's register blocks" % (name, hi))
+    return report
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))

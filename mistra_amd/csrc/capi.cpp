@@ -185,7 +185,6 @@ int setup_mech(int mech) {
 }
 
 int launch(int mech, const KernelArgs& a, hipStream_t stream) {
-  const MechState& S = g_mech[mech];
   hipError_t e = hipErrorInvalidValue;
   if (mech == MISTRA_MECH_GAS) e = launch_ros3<GasTraits, 128>(a, stream);
   else if (mech == MISTRA_MECH_AER) e = launch_ros3<AerTraits, 512>(a, stream);

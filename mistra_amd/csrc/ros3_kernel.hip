@@ -431,7 +431,7 @@ __device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev P, int wave,
 
 template <class MT, int NT, bool PROF>
 __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) {
-  constexpr int NVAR = MT::NVAR, NFIX = MT::NFIX, NREACT = MT::NREACT, NNZ = MT::NNZ, NB = MT::NB, NCONST = MT::NCONST;
+  constexpr int NVAR = MT::NVAR, NFIX = MT::NFIX, NREACT = MT::NREACT, NNZ = MT::NNZ, NCONST = MT::NCONST;
   constexpr int NW = NT / 64;
   constexpr int SPT = (NVAR + NT - 1) / NT, RPT = (NREACT + NT - 1) / NT;
   constexpr int JPT = (MT::NJNZ + NT - 1) / NT, ZPT = (NNZ - MT::NJNZ + NT - 1) / NT;

@@ -3,7 +3,7 @@
 
 Provenance (all steps happen in the build container, where /root/reference exists):
   1. oracle/build_ref.sh all          compiles the reference's own Fortran sources with flang -O2 -ffp-contract=off
-  2. oracle/capture_run.sh BTZ96 1 ...  runs the reference's shipped stratus case (namelists/namelist.BTZ96 with chem=T,
+  2. oracle/capture_run.sh BTZ96 <hours> ...  runs the reference's shipped stratus case (namelists/namelist.BTZ96 with chem=T,
                                        netcdf=F, 1 model hour) through oracle/column_driver.f90 and records real
                                        INTEGRATE_g/a/t calls (oracle/capture_wrap.c): /GDATA_x/ before and after, /Statistics/
   3. this script                        converts the records into the small fixtures committed here
@@ -19,17 +19,38 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle.oracle import read_capture  # noqa: E402
 
-CAPTURE = os.path.join(HERE, "..", "..", "oracle", "_ref", "capture_BTZ96.bin")
-CMD = ("oracle/capture_run.sh BTZ96 1 MISTRA_CAPTURE_SKIP_t=1500 MISTRA_CAPTURE_EVERY_t=241 MISTRA_CAPTURE_MAX_t=64 "
-       "MISTRA_CAPTURE_SKIP_a=1000 MISTRA_CAPTURE_EVERY_a=331 MISTRA_CAPTURE_MAX_a=32 "
-       "MISTRA_CAPTURE_SKIP_g=2000 MISTRA_CAPTURE_EVERY_g=701 MISTRA_CAPTURE_MAX_g=32")
+REF = os.path.join(HERE, "..", "..", "oracle", "_ref")
+# name suffix -> (capture file, what was run)
+SETS = {
+    "": (os.path.join(REF, "capture_BTZ96.bin"),
+         "reference namelist.BTZ96 (chem=T, netcdf=F, lstmax=1: first model hour, night); "
+         "oracle/capture_run.sh BTZ96 1 MISTRA_CAPTURE_SKIP_t=1500 MISTRA_CAPTURE_EVERY_t=241 MISTRA_CAPTURE_MAX_t=64 "
+         "MISTRA_CAPTURE_SKIP_a=1000 MISTRA_CAPTURE_EVERY_a=331 MISTRA_CAPTURE_MAX_a=32 "
+         "MISTRA_CAPTURE_SKIP_g=2000 MISTRA_CAPTURE_EVERY_g=701 MISTRA_CAPTURE_MAX_g=32"),
+    "_day": (os.path.join(REF, "capture_BTZ96_day.bin"),
+             "reference namelist.BTZ96 (chem=T, netcdf=F, lstmax=8: calls from model hours 6.5-8, after sunrise, photolysis on); "
+             "oracle/capture_run.sh BTZ96 8 MISTRA_CAPTURE_SKIP_t=110000 MISTRA_CAPTURE_EVERY_t=1201 MISTRA_CAPTURE_MAX_t=24 "
+             "MISTRA_CAPTURE_SKIP_a=70000 MISTRA_CAPTURE_EVERY_a=1301 MISTRA_CAPTURE_MAX_a=16 "
+             "MISTRA_CAPTURE_SKIP_g=150000 MISTRA_CAPTURE_EVERY_g=2203 MISTRA_CAPTURE_MAX_g=16"),
+}
 
 
 def main():
-    recs = read_capture(CAPTURE)
+    for suffix, (capture, cmd) in SETS.items():
+        if os.path.exists(capture):
+            convert(suffix, capture, cmd)
+        else:
+            print("no capture", capture, "- skipped")
+
+
+def convert(suffix, capture, cmd):
+    recs = read_capture(capture)
     info = open(os.path.join(HERE, "..", "..", "oracle", "_ref", "BUILD_INFO")).read()
     for mech in ("gas", "aer", "tot"):
         rs = [r for r in recs if r["mech"] == mech]
+        if not rs:
+            print(mech, suffix, "no records")
+            continue
         out = dict(
             var_in=np.stack([r["var_in"] for r in rs]), fix=np.stack([r["fix"] for r in rs]),
             rconst=np.stack([r["rconst"] for r in rs]), var_out=np.stack([r["var_out"] for r in rs]),
@@ -37,8 +58,8 @@ def main():
             tin=np.array([r["tin"] for r in rs]), tout=np.array([r["tout"] for r in rs]),
             tin_out=np.array([r["tin_out"] for r in rs]), stepmin_out=np.array([r["stepmin_out"] for r in rs]),
             callno=np.array([r["callno"] for r in rs], np.int32),
-            provenance=np.array("reference namelist.BTZ96 (chem=T, netcdf=F, lstmax=1); " + CMD + "; " + info.replace("\n", "; ")))
-        path = os.path.join(HERE, "integrate_%s.npz" % mech)
+            provenance=np.array(cmd + "; " + info.replace("\n", "; ")))
+        path = os.path.join(HERE, "integrate_%s%s.npz" % (mech, suffix))
         np.savez_compressed(path, **out)
         print(mech, len(rs), "records ->", path, os.path.getsize(path), "bytes; steps", out["stats"][:, 2].min(), "..", out["stats"][:, 2].max())
 

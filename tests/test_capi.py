@@ -60,3 +60,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 text = open(os.path.join(root, f), errors="replace").read()
                 assert "oracle." not in text and "oracle/" not in text and "kpp_ros3" not in text and "libmistra_ref" not in text, f
+
+
+def test_lookahead_ring_registers_are_out_of_the_compilers_reach():
+    """ros3_kernel.hip streams its tables through a ring of fixed high VGPRs (v192..v247) inside two non-inlined device
+    functions; that is only sound while the compiler's own values in those functions stay below v192 (build.py scans the
+    generated gfx950 assembly).  Cross-compiles, no GPU needed."""
+    from mistra_amd.build import ring_register_report
+    rep = ring_register_report()
+    dev = {k: v for k, v in rep.items() if "kernel" not in k}
+    assert any("gsum_run" in k for k in dev) and any("tail_solve" in k for k in dev)
+    assert max(dev.values()) < 192, dev
