@@ -202,7 +202,8 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
   a.zero_pos = S.zero_pos.p; a.diag_pos = S.diag_pos.p;
   a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev();
   if (const char* cut = std::getenv("MISTRA_DIAG_LU_ROUNDS"))      // timing diagnostic only (tools/profile_lu_rounds.py): results are garbage
-    a.lu.nrounds = std::max(1, std::min(a.lu.nrounds, std::atoi(cut))); a.solve_head_fwd = S.solve_head_fwd.dev(); a.solve_head_bwd = S.solve_head_bwd.dev();
+    a.lu.nrounds = std::max(1, std::min(a.lu.nrounds, std::atoi(cut)));
+  a.solve_head_fwd = S.solve_head_fwd.dev(); a.solve_head_bwd = S.solve_head_bwd.dev();
   a.tail = TailDev{S.tail_fwd.p, S.tail_bwd.p};
   return a;
 }
