@@ -22,6 +22,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_day():
+    """A second capture of the same reference run, model hours 6.5-8 (after sunrise: photolysis reactions switched on)."""
+    return {m: dict(np.load(os.path.join(REPO, "tests", "golden", "integrate_%s_day.npz" % m))) for m in MECHS}
+
+
+@pytest.fixture(scope="session")
 def oracles():
     from oracle.oracle import Oracle
     return {m: Oracle(m) for m in MECHS}

@@ -52,6 +52,15 @@ def test_golden_reference_calls_host_buffers(chem, mech, golden):
 
 
 @pytest.mark.parametrize("mech", MECHS)
+def test_golden_daytime_reference_calls(chem, mech, golden_day):
+    g = golden_day[mech]
+    res = chem.integrate(mech, g["var_in"], g["fix"], g["rconst"], 0.0, 10.0)
+    assert np.all(res.ierr == 1)
+    check(res.var, g["var_out"], "%s: %d daytime reference calls," % (mech, len(res.var)))
+    assert np.array_equal(res.stats, g["stats"]), "COMMON /Statistics/ differs from the reference"
+
+
+@pytest.mark.parametrize("mech", MECHS)
 def test_golden_reference_calls_device_buffers(chem, mech, golden):
     import torch
     g = golden[mech]

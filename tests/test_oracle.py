@@ -19,6 +19,20 @@ def test_oracle_reproduces_captured_reference_calls_bit_exactly(mech, golden, or
 
 
 @pytest.mark.parametrize("mech", MECHS)
+def test_oracle_reproduces_daytime_reference_calls_bit_exactly(mech, golden, golden_day, oracles):
+    g, o = golden_day[mech], oracles[mech]
+    # the set differs from the night one where it should: photolysis rate constants are no longer all zero
+    night_off = (golden[mech]["rconst"] == 0).all(axis=0)
+    assert (night_off & ~(g["rconst"] == 0).all(axis=0)).sum() >= 20
+    for i in range(g["var_in"].shape[0]):
+        v, ierr, st, te, he = o.integrate(g["var_in"][i], g["fix"][i], g["rconst"][i], g["tin"][i], g["tout"][i])
+        assert ierr == 1
+        assert np.array_equal(v, g["var_out"][i]), "record %d: concentrations differ from the reference" % i
+        assert np.array_equal(st, g["stats"][i]), "record %d: /Statistics/ differ" % i
+        assert te == g["tin_out"][i] and he == g["stepmin_out"][i]
+
+
+@pytest.mark.parametrize("mech", MECHS)
 def test_golden_files_are_sane(mech, golden):
     g = golden[mech]
     n = g["var_in"].shape[0]
