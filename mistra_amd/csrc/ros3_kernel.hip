@@ -229,7 +229,7 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev P, int wave, int la
   const uint64_t recs = reinterpret_cast<uint64_t>(P.recs);      // the same in every lane: move it to SGPRs
   const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs) |
                         ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(recs >> 32)) << 32);
-  uint32_t va = ((uint32_t)G_(P.wave_base)[wave] * 64u + (uint32_t)lane) * 32u;     // this lane's first record, bytes
+  uint32_t va = (uint32_t)G_(P.wave_base)[wave] * 2048u + (uint32_t)lane * 16u;     // this lane's first record (planar rows: lo plane, hi plane + 1024), bytes
   uint32_t vb = va + 4096u;                                                          // rows +2, +3
   int rounds = __builtin_amdgcn_readfirstlane(P.nrounds);
   double acc, a1, r1, u1, a2, r2, u2, sc;
@@ -238,24 +238,24 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev P, int wave, int la
   asm volatile(
       "s_waitcnt vmcnt(0)\n\t"                  // nothing of the caller's may sit between the counted loads
       "s_nop 4\n\t"
-      MISTRA_VM_REFILL("v[48:51]", "v[52:55]", "%[va]", "0", "16")
-      MISTRA_VM_REFILL("v[64:67]", "v[68:71]", "%[va]", "2048", "2064")
-      MISTRA_VM_REFILL("v[80:83]", "v[84:87]", "%[vb]", "0", "16")
-      MISTRA_VM_REFILL("v[96:99]", "v[100:103]", "%[vb]", "2048", "2064")
+      MISTRA_VM_REFILL("v[48:51]", "v[52:55]", "%[va]", "0", "1024")
+      MISTRA_VM_REFILL("v[64:67]", "v[68:71]", "%[va]", "2048", "3072")
+      MISTRA_VM_REFILL("v[80:83]", "v[84:87]", "%[vb]", "0", "1024")
+      MISTRA_VM_REFILL("v[96:99]", "v[100:103]", "%[vb]", "2048", "3072")
       "v_add_u32 %[va], 0x2000, %[va]\n\t"
       "v_add_u32 %[vb], 0x2000, %[vb]\n"
       "Lvm_loop_%=:\n\t"
-      MISTRA_VM_RECORD("0", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[48:51]", "v[52:55]", "%[va]", "0", "16")
-      MISTRA_VM_RECORD("1", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v[64:67]", "v[68:71]", "%[va]", "2048", "2064")
-      MISTRA_VM_RECORD("2", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v[80:83]", "v[84:87]", "%[vb]", "0", "16")
-      MISTRA_VM_RECORD("3", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v[96:99]", "v[100:103]", "%[vb]", "2048", "2064")
+      MISTRA_VM_RECORD("0", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[48:51]", "v[52:55]", "%[va]", "0", "1024")
+      MISTRA_VM_RECORD("1", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v[64:67]", "v[68:71]", "%[va]", "2048", "3072")
+      MISTRA_VM_RECORD("2", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v[80:83]", "v[84:87]", "%[vb]", "0", "1024")
+      MISTRA_VM_RECORD("3", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v[96:99]", "v[100:103]", "%[vb]", "2048", "3072")
       "v_add_u32 %[va], 0x2000, %[va]\n\t"
       "v_add_u32 %[vb], 0x2000, %[vb]\n\t"
       "s_branch Lvm_loop_%=\n"
-      MISTRA_VM_RECORD_TAIL("0", "v48", "v49", "v[48:51]", "v[52:55]", "%[va]", "0", "16")
-      MISTRA_VM_RECORD_TAIL("1", "v64", "v65", "v[64:67]", "v[68:71]", "%[va]", "2048", "2064")
-      MISTRA_VM_RECORD_TAIL("2", "v80", "v81", "v[80:83]", "v[84:87]", "%[vb]", "0", "16")
-      MISTRA_VM_RECORD_TAIL("3", "v96", "v97", "v[96:99]", "v[100:103]", "%[vb]", "2048", "2064")
+      MISTRA_VM_RECORD_TAIL("0", "v48", "v49", "v[48:51]", "v[52:55]", "%[va]", "0", "1024")
+      MISTRA_VM_RECORD_TAIL("1", "v64", "v65", "v[64:67]", "v[68:71]", "%[va]", "2048", "3072")
+      MISTRA_VM_RECORD_TAIL("2", "v80", "v81", "v[80:83]", "v[84:87]", "%[vb]", "0", "1024")
+      MISTRA_VM_RECORD_TAIL("3", "v96", "v97", "v[96:99]", "v[100:103]", "%[vb]", "2048", "3072")
       "Lvm_exit_%=:\n\t"
       "s_waitcnt vmcnt(0)"                      // the look-ahead loads must have landed before the ring registers are reused
       : [acc] "=&v"(acc), [a1] "=&v"(a1), [r1] "=&v"(r1), [u1] "=&v"(u1), [a2] "=&v"(a2), [r2] "=&v"(r2), [u2] "=&v"(u2),

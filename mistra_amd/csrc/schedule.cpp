@@ -322,10 +322,16 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
   P.wave_base.assign((size_t)P.nw, 0);
   for (int wv = 0; wv < P.nw; wv++) {
     P.wave_base[(size_t)wv] = (uint32_t)(P.recs.size() / (64 * VM_REC_WORDS));
-    P.recs.insert(P.recs.end(), stream[(size_t)wv].begin(), stream[(size_t)wv].end());
     // idle rows of slack so that the executor's look-ahead loads past the last record stay in bounds
+    std::vector<uint32_t>& st = stream[(size_t)wv];
     for (int rr = 0; rr < VM_LOOKAHEAD_ROWS; rr++)
-      for (int l = 0; l < 64; l++) idle_record(P.recs, 0);
+      for (int l = 0; l < 64; l++) idle_record(st, 0);
+    // device layout: planar rows (vm_rec_index)
+    const size_t rows = st.size() / (64 * VM_REC_WORDS), row0 = P.wave_base[(size_t)wv];
+    P.recs.resize((row0 + rows) * 64 * VM_REC_WORDS);
+    for (size_t r = 0; r < rows; r++)
+      for (int l = 0; l < 64; l++)
+        for (int k = 0; k < VM_REC_WORDS; k++) P.recs[vm_rec_index(row0 + r, l, k)] = st[(r * 64 + (size_t)l) * VM_REC_WORDS + (size_t)k];
   }
   return P;
 }

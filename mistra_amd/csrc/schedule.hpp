@@ -69,6 +69,7 @@ constexpr uint32_t VM_ROW_AUX = 1u << 26;    // every lane of a row: some lane p
 constexpr int VM_ROW_EOR_BIT = 24, VM_ROW_NULL_BIT = 25, VM_ROW_AUX_BIT = 26;
 constexpr uint32_t VM_AUX_MASK = 0x00FFFFF8u;   // byte address part of d1
 constexpr int VM_REC_WORDS = 8;
+inline size_t vm_rec_index(size_t row, int lane, int k) { return row * 512 + (k < 4 ? 0 : 256) + (size_t)lane * 4 + (size_t)(k & 3); }
 constexpr int VM_UPD_PER_REC = 2;
 constexpr int VM_LOOKAHEAD_ROWS = 16;    // >= 2x the kernel's table look-ahead depth (ros3_kernel.hip)
 
@@ -105,7 +106,9 @@ struct VmProgram {
   int nt = 0, nw = 0, nrounds = 0, zero_slot = 0;
   std::vector<uint32_t> wave_base;              // [nw]  first record row of each wave's linear stream
   std::vector<uint16_t> blk_n;                  // [nrounds*nw] record rows of (round, wave), null rows included (census / emulator)
-  std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*8 + k]   two uint4 per lane and row
+  std::vector<uint32_t> recs;                   // per row 512 words, PLANAR: words 0-3 of all 64 lanes, then words 4-7 of all
+                                                // lanes (vm_rec_index): each of the executor's two 16-byte loads per record then
+                                                // covers 16 whole cache lines instead of half of 32
   // census
   int64_t n_updates = 0, n_items = 0, n_records = 0, wave_rows = 0, crit_rows = 0;
   int64_t lds_cycles = 0;                       // modelled LDS-array cycles of all operand gathers and stores (bank conflicts included)

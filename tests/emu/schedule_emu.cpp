@@ -49,7 +49,8 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
         double carry = 0.0;
         bool own_raw = false;
         for (int ridx = 0; ridx < n; ridx++) {
-          const uint32_t* rec = &P.recs[((base + ridx) * 64 + l) * VM_REC_WORDS];
+          uint32_t rec[VM_REC_WORDS];
+          for (int k = 0; k < VM_REC_WORDS; k++) rec[k] = P.recs[vm_rec_index(base + (size_t)ridx, l, k)];
           if ((rec[1] & VM_ROW_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
           if (rec[1] & VM_ROW_NULL) continue;
           auto rd = [&](uint32_t off) {
