@@ -8,11 +8,11 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REFROOT="${MISTRA_REFERENCE:-/root/reference}"
 CASE="$1"; HOURS="$2"; shift 2
-RUN="$HERE/_ref/run_$CASE"
+RUN="$HERE/_ref/run_${CASE}${MISTRA_RUN_TAG:-}"
 rm -rf "$RUN/out"; mkdir -p "$RUN/out"
 sed -e 's/^\( *netcdf *= *\)T/\1F/' -e 's/^\( *chem *= *\)F/\1T/' -e "s/^\( *lstmax *= *\)[0-9]*/\1$HOURS/" \
     "$REFROOT/namelists/namelist.$CASE" > "$RUN/namelist"
 cd "$RUN"
 env INPDIR="$REFROOT/input/" MECHDIR="$REFROOT/src/mech/" OUTDIR="$RUN/out/" NAMELIST="$RUN/namelist" \
-    MISTRA_CAPTURE_FILE="$HERE/_ref/capture_$CASE.bin" "$@" "$HERE/_ref/mistra_capture" > "$RUN/stdout.log" 2> "$RUN/stderr.log"
+    MISTRA_CAPTURE_FILE="$HERE/_ref/capture_${CASE}${MISTRA_RUN_TAG:-}.bin" "$@" "$HERE/_ref/mistra_capture" > "$RUN/stdout.log" 2> "$RUN/stderr.log"
 tail -4 "$RUN/stderr.log"

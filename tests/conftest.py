@@ -21,10 +21,13 @@ def golden():
     return {m: dict(np.load(os.path.join(REPO, "tests", "golden", "integrate_%s.npz" % m))) for m in MECHS}
 
 
-@pytest.fixture(scope="session")
-def golden_day():
-    """A second capture of the same reference run, model hours 6.5-8 (after sunrise: photolysis reactions switched on)."""
-    return {m: dict(np.load(os.path.join(REPO, "tests", "golden", "integrate_%s_day.npz" % m))) for m in MECHS}
+# further captured sets, (set, mechanism): "day" = the BTZ96 run at model hours 6.5-8 (after sunrise: photolysis reactions
+# switched on), "base1" = the reference's cloud-free namelist.base1 (no tot calls in it)
+EXTRA_SETS = [("day", "gas"), ("day", "aer"), ("day", "tot"), ("base1", "gas"), ("base1", "aer")]
+
+
+def load_golden(mech, suffix=""):
+    return dict(np.load(os.path.join(REPO, "tests", "golden", "integrate_%s%s.npz" % (mech, suffix))))
 
 
 @pytest.fixture(scope="session")

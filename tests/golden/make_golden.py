@@ -32,6 +32,11 @@ SETS = {
              "oracle/capture_run.sh BTZ96 8 MISTRA_CAPTURE_SKIP_t=110000 MISTRA_CAPTURE_EVERY_t=1201 MISTRA_CAPTURE_MAX_t=24 "
              "MISTRA_CAPTURE_SKIP_a=70000 MISTRA_CAPTURE_EVERY_a=1301 MISTRA_CAPTURE_MAX_a=16 "
              "MISTRA_CAPTURE_SKIP_g=150000 MISTRA_CAPTURE_EVERY_g=2203 MISTRA_CAPTURE_MAX_g=16"),
+    "_base1": (os.path.join(REF, "capture_base1.bin"),
+               "reference namelist.base1 (chem=T as shipped, netcdf=F, lstmax=2: cloud-free marine boundary layer, gas and aerosol "
+               "chemistry); oracle/capture_run.sh base1 2 MISTRA_CAPTURE_SKIP_t=200 MISTRA_CAPTURE_EVERY_t=997 MISTRA_CAPTURE_MAX_t=12 "
+               "MISTRA_CAPTURE_SKIP_a=500 MISTRA_CAPTURE_EVERY_a=2003 MISTRA_CAPTURE_MAX_a=16 "
+               "MISTRA_CAPTURE_SKIP_g=500 MISTRA_CAPTURE_EVERY_g=3001 MISTRA_CAPTURE_MAX_g=12"),
 }
 
 

@@ -17,7 +17,7 @@ bookkeeping (COMMON /Statistics/).
 import numpy as np
 import pytest
 
-from conftest import MECHS, rel_diff
+from conftest import EXTRA_SETS, MECHS, load_golden, rel_diff
 
 pytestmark = pytest.mark.gpu
 RTOL = 2e-5          # all species, floor 1e-12 of the cell maximum
@@ -51,12 +51,12 @@ def test_golden_reference_calls_host_buffers(chem, mech, golden):
     assert np.array_equal(res.stats, g["stats"]), "COMMON /Statistics/ differs from the reference"
 
 
-@pytest.mark.parametrize("mech", MECHS)
-def test_golden_daytime_reference_calls(chem, mech, golden_day):
-    g = golden_day[mech]
+@pytest.mark.parametrize("which,mech", EXTRA_SETS)
+def test_golden_further_reference_captures(chem, which, mech):
+    g = load_golden(mech, "_" + which)
     res = chem.integrate(mech, g["var_in"], g["fix"], g["rconst"], 0.0, 10.0)
     assert np.all(res.ierr == 1)
-    check(res.var, g["var_out"], "%s: %d daytime reference calls," % (mech, len(res.var)))
+    check(res.var, g["var_out"], "%s: %d reference calls of set '%s'," % (mech, len(res.var), which))
     assert np.array_equal(res.stats, g["stats"]), "COMMON /Statistics/ differs from the reference"
 
 

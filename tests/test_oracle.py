@@ -3,7 +3,7 @@ reference exists (oracle/_ref, this container) — the reference's own routines 
 import numpy as np
 import pytest
 
-from conftest import MECHS
+from conftest import EXTRA_SETS, MECHS, load_golden
 from oracle.oracle import Reference
 
 
@@ -18,12 +18,12 @@ def test_oracle_reproduces_captured_reference_calls_bit_exactly(mech, golden, or
         assert te == g["tin_out"][i] and he == g["stepmin_out"][i]
 
 
-@pytest.mark.parametrize("mech", MECHS)
-def test_oracle_reproduces_daytime_reference_calls_bit_exactly(mech, golden, golden_day, oracles):
-    g, o = golden_day[mech], oracles[mech]
-    # the set differs from the night one where it should: photolysis rate constants are no longer all zero
-    night_off = (golden[mech]["rconst"] == 0).all(axis=0)
-    assert (night_off & ~(g["rconst"] == 0).all(axis=0)).sum() >= 20
+@pytest.mark.parametrize("which,mech", EXTRA_SETS)
+def test_oracle_reproduces_further_reference_captures_bit_exactly(which, mech, golden, oracles):
+    g, o = load_golden(mech, "_" + which), oracles[mech]
+    if which == "day":     # the set differs from the night one where it should: photolysis rate constants are no longer all zero
+        night_off = (golden[mech]["rconst"] == 0).all(axis=0)
+        assert (night_off & ~(g["rconst"] == 0).all(axis=0)).sum() >= 20
     for i in range(g["var_in"].shape[0]):
         v, ierr, st, te, he = o.integrate(g["var_in"][i], g["fix"][i], g["rconst"][i], g["tin"][i], g["tout"][i])
         assert ierr == 1
