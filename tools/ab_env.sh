@@ -1,7 +1,12 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# Same-box A/B of one build under two environments: tools/ab_env.sh VAR=value [mech] [cells]
+# (e.g. MISTRA_DIAG_PLAIN_DEAL=1, MISTRA_NT_TOT=1024).  Prints timesteps/s of alternating runs.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+SETTING=$1; MECH=${2:-tot}; CELLS=${3:-25600}
 for rep in 1 2; do
   for V in 0 1; do
-    if [ $V = 1 ]; then export MISTRA_DIAG_PLAIN_DEAL=1; else unset MISTRA_DIAG_PLAIN_DEAL; fi
-    timeout -k 10 200 python bench.py --no-cpu-baseline --cells-per-gpu 25600 --steps 2 --warmup 1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('plain_deal=$V', '%.0f' % d['value'], 'timesteps/s')"
+    if [ $V = 1 ]; then PRE="env $SETTING"; else PRE=""; fi
+    $PRE timeout -k 10 200 python bench.py --no-cpu-baseline --mech $MECH --cells-per-gpu $CELLS --steps 2 --warmup 1 2>/dev/null \
+      | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('${SETTING} applied=$V', '%.0f' % d['value'], 'timesteps/s')"
   done
 done
