@@ -104,11 +104,20 @@ struct MechState {
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
   DevBuf<int32_t> s_ierr, s_stats;
+  // one-cell calls (the Fortran shim): one contiguous device block in, one out, pinned host mirrors, a private stream
+  double* one_dev = nullptr;      // [C(NSPEC) | RCONST(NREACT)]  then  [VAR out | Texit Hexit | 8 stats + ierr as int32]
+  double* one_host = nullptr;
+  hipStream_t one_stream = nullptr;
   void release() {
     consts.release(); fun_fac.release(); jac_fac.release(); jvs_pos.release(); zero_pos.release(); diag_pos.release();
     vdot.release(); jvs.release(); lu.release(); solve_head_fwd.release(); solve_head_bwd.release();
     tail_fwd.release(); tail_bwd.release();
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release();
+    if (one_dev) (void)hipFree(one_dev);
+    if (one_host) (void)hipHostFree(one_host);
+    if (one_stream) (void)hipStreamDestroy(one_stream);
+    one_dev = one_host = nullptr;
+    one_stream = nullptr;
     ready = false;
   }
 };
@@ -330,27 +339,31 @@ int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tou
   int32_t ierr = 0;
   MechState& S = g_mech[mech];
   {
+    // One call = one cell: what costs here is synchronisation, not bytes.  /GDATA_x/ holds C and RCONST back to back, so
+    // the inputs go up in ONE copy from a pinned mirror and everything the kernel writes comes back in ONE, on a private
+    // stream with a single wait (seven blocking calls before: 340 us per gas call, of which the kernel is a fraction).
     std::lock_guard<std::mutex> lock(g_mu);
-    HIP_TRY(S.s_var.reserve((size_t)nv));
-    HIP_TRY(S.s_fix.reserve((size_t)nf));
-    HIP_TRY(S.s_rct.reserve((size_t)nr));
-    HIP_TRY(S.s_ierr.reserve(1));
-    HIP_TRY(S.s_stats.reserve(8));
-    HIP_TRY(S.s_th.reserve(2));
-    HIP_TRY(hipMemcpy(S.s_var.p, c, nv * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S.s_fix.p, c + nv, nf * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(S.s_rct.p, rconst, nr * sizeof(double), hipMemcpyHostToDevice));
-    KernelArgs a = make_args(S, 1, S.s_var.p, S.s_fix.p, S.s_rct.p, *tin, *tout, S.s_var.p, S.s_ierr.p, S.s_stats.p, S.s_th.p);
-    if (int rc = launch(mech, a, nullptr)) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    double th[2];
-    HIP_TRY(hipMemcpy(c, S.s_var.p, nv * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&ierr, S.s_ierr.p, sizeof ierr, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(th, S.s_th.p, sizeof th, hipMemcpyDeviceToHost));
+    const size_t n_in = (size_t)(nv + nf + nr), n_out = (size_t)nv + 2 + 5;       // out tail: 9 int32 in 5 doubles
+    if (!S.one_dev) {
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&S.one_dev), (n_in + n_out) * sizeof(double)));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S.one_host), (n_in + n_out) * sizeof(double), hipHostMallocDefault));
+      HIP_TRY(hipStreamCreateWithFlags(&S.one_stream, hipStreamNonBlocking));
+    }
+    std::memcpy(S.one_host, c, n_in * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(S.one_dev, S.one_host, n_in * sizeof(double), hipMemcpyHostToDevice, S.one_stream));
+    double* d_out = S.one_dev + n_in;
+    int32_t* d_stats = reinterpret_cast<int32_t*>(d_out + nv + 2);
+    KernelArgs a = make_args(S, 1, S.one_dev, S.one_dev + nv, S.one_dev + nv + nf, *tin, *tout, d_out, d_stats + 8, d_stats, d_out + nv);
+    if (int rc = launch(mech, a, S.one_stream)) return rc;
+    double* h_out = S.one_host + n_in;
+    HIP_TRY(hipMemcpyAsync(h_out, d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, S.one_stream));
+    HIP_TRY(hipStreamSynchronize(S.one_stream));
+    std::memcpy(c, h_out, (size_t)nv * sizeof(double));
+    std::memcpy(&ierr, reinterpret_cast<const int32_t*>(h_out + nv + 2) + 8, sizeof ierr);
     if (ierr < 0)   // the reference prints and continues (gas.f:764-767)
       std::printf(" Rosenbrock: Unsucessful step at T=%g (IERR=%d)\n", *tin, ierr);
-    *tin = th[0];        // TIN = RPAR(11), exit time
-    *stepmin = th[1];    // STEPMIN = RPAR(12), last step
+    *tin = h_out[nv];          // TIN = RPAR(11), exit time
+    *stepmin = h_out[nv + 1];  // STEPMIN = RPAR(12), last step
   }
   return 0;
 }
