@@ -77,46 +77,72 @@ __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || 
 // hipcc's own s_waitcnt placement falls back to vmcnt(0) around branches and barriers, which would serialise every
 // table row behind a full memory round trip, so the loads are issued from asm and counted by hand.  A compiler-visible
 // VGPR destination would be unsafe (the compiler may copy an asm output before the data lands, cdna_hip_programming.md
-// §5.7 item 1).  The ring therefore lives in four caller-saved register blocks at the top of the file, v192-199,
-// v208-215, v224-231, v240-247, named only by the two statements below; the consume statement waits and copies out in
-// ONE asm (§5.7 form i).  Loads are in flight only inside the two non-inlined functions that use the ring (each drains
-// it before returning), and those functions' own values sit far below v192 (they need < 72 registers;
-// tests/test_capi.py checks the generated ISA), so nothing of the compiler's can be hit by a landing load; the callers
-// see the blocks as ordinary call-clobbered registers.  Loads return in issue
-// order, hence "at most PENDING outstanding" means the oldest one — the slot about to be consumed — has landed.
-// (An earlier version kept the ring in AGPRs: any AGPR use halves the compiler's VGPR budget to 128 on gfx950, which
-// cost the kernel ~100 spilled registers.)
-template <int K, int BYTE_OFFSET = 0>
+// §5.7 item 1).  The ring therefore lives in fixed registers named only by the two statements below; the consume
+// statement waits and copies out in ONE asm (§5.7 form i).  Loads are in flight only inside the two non-inlined functions
+// that use the ring (each drains it before returning), and those functions' own values sit below the ring (they need
+// < 72 registers; tests/test_capi.py checks the generated ISA), so nothing of the compiler's can be hit by a landing
+// load; the callers see the blocks as ordinary call-clobbered registers.  Two placements (LOW):
+//   false  v192-199, v208-215, v224-231, v240-247: four caller-saved blocks at the top of the file, nothing to save — for
+//          kernels that run two waves per SIMD and have 256 registers (tot: one cell fills a CU's LDS anyway);
+//   true   v96-127: for kernels held to 128 registers so that FOUR waves per SIMD fit (aer: two cells per CU instead of
+//          one, +39 %; gas: eight instead of four); two of the four blocks are callee-saved there and cost a save/restore
+//          per call (~1 % on tot, which is why tot keeps the high placement).
+// Loads return in issue order, hence "at most PENDING outstanding" means the oldest one — the slot about to be
+// consumed — has landed.  (An earlier version kept the ring in AGPRs: any AGPR use halves the compiler's VGPR budget
+// on gfx950, which cost the kernel ~100 spilled registers.)
+template <bool LOW, int K, int BYTE_OFFSET = 0>
 __device__ __forceinline__ void vm_ring_load(gptr<u32x4> p) {
 #define MISTRA_RING_LOAD(R0, R1, R2, R3)                                                                              \
   asm volatile("global_load_dwordx4 v[" #R0 ":" #R3 "], %0, off offset:%1" : : "v"(p), "n"(BYTE_OFFSET)             \
                : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3)
-  if constexpr (K == 0) MISTRA_RING_LOAD(192, 193, 194, 195);
-  else if constexpr (K == 1) MISTRA_RING_LOAD(196, 197, 198, 199);
-  else if constexpr (K == 2) MISTRA_RING_LOAD(208, 209, 210, 211);
-  else if constexpr (K == 3) MISTRA_RING_LOAD(212, 213, 214, 215);
-  else if constexpr (K == 4) MISTRA_RING_LOAD(224, 225, 226, 227);
-  else if constexpr (K == 5) MISTRA_RING_LOAD(228, 229, 230, 231);
-  else if constexpr (K == 6) MISTRA_RING_LOAD(240, 241, 242, 243);
-  else MISTRA_RING_LOAD(244, 245, 246, 247);
+  if constexpr (LOW) {
+    if constexpr (K == 0) MISTRA_RING_LOAD(96, 97, 98, 99);
+    else if constexpr (K == 1) MISTRA_RING_LOAD(100, 101, 102, 103);
+    else if constexpr (K == 2) MISTRA_RING_LOAD(104, 105, 106, 107);
+    else if constexpr (K == 3) MISTRA_RING_LOAD(108, 109, 110, 111);
+    else if constexpr (K == 4) MISTRA_RING_LOAD(112, 113, 114, 115);
+    else if constexpr (K == 5) MISTRA_RING_LOAD(116, 117, 118, 119);
+    else if constexpr (K == 6) MISTRA_RING_LOAD(120, 121, 122, 123);
+    else MISTRA_RING_LOAD(124, 125, 126, 127);
+  } else {
+    if constexpr (K == 0) MISTRA_RING_LOAD(192, 193, 194, 195);
+    else if constexpr (K == 1) MISTRA_RING_LOAD(196, 197, 198, 199);
+    else if constexpr (K == 2) MISTRA_RING_LOAD(208, 209, 210, 211);
+    else if constexpr (K == 3) MISTRA_RING_LOAD(212, 213, 214, 215);
+    else if constexpr (K == 4) MISTRA_RING_LOAD(224, 225, 226, 227);
+    else if constexpr (K == 5) MISTRA_RING_LOAD(228, 229, 230, 231);
+    else if constexpr (K == 6) MISTRA_RING_LOAD(240, 241, 242, 243);
+    else MISTRA_RING_LOAD(244, 245, 246, 247);
+  }
 #undef MISTRA_RING_LOAD
 }
 
-template <int K, int PENDING = 7>
+template <bool LOW, int K, int PENDING = 7>
 __device__ __forceinline__ u32x4 vm_ring_take() {
   uint32_t x, y, z, w;
 #define MISTRA_RING_TAKE(R0, R1, R2, R3)                                                                              \
   asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1                                   \
                "\n\tv_mov_b32 %2, v" #R2 "\n\tv_mov_b32 %3, v" #R3                                                    \
                : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : "n"(PENDING) : "memory")
-  if constexpr (K == 0) MISTRA_RING_TAKE(192, 193, 194, 195);
-  else if constexpr (K == 1) MISTRA_RING_TAKE(196, 197, 198, 199);
-  else if constexpr (K == 2) MISTRA_RING_TAKE(208, 209, 210, 211);
-  else if constexpr (K == 3) MISTRA_RING_TAKE(212, 213, 214, 215);
-  else if constexpr (K == 4) MISTRA_RING_TAKE(224, 225, 226, 227);
-  else if constexpr (K == 5) MISTRA_RING_TAKE(228, 229, 230, 231);
-  else if constexpr (K == 6) MISTRA_RING_TAKE(240, 241, 242, 243);
-  else MISTRA_RING_TAKE(244, 245, 246, 247);
+  if constexpr (LOW) {
+    if constexpr (K == 0) MISTRA_RING_TAKE(96, 97, 98, 99);
+    else if constexpr (K == 1) MISTRA_RING_TAKE(100, 101, 102, 103);
+    else if constexpr (K == 2) MISTRA_RING_TAKE(104, 105, 106, 107);
+    else if constexpr (K == 3) MISTRA_RING_TAKE(108, 109, 110, 111);
+    else if constexpr (K == 4) MISTRA_RING_TAKE(112, 113, 114, 115);
+    else if constexpr (K == 5) MISTRA_RING_TAKE(116, 117, 118, 119);
+    else if constexpr (K == 6) MISTRA_RING_TAKE(120, 121, 122, 123);
+    else MISTRA_RING_TAKE(124, 125, 126, 127);
+  } else {
+    if constexpr (K == 0) MISTRA_RING_TAKE(192, 193, 194, 195);
+    else if constexpr (K == 1) MISTRA_RING_TAKE(196, 197, 198, 199);
+    else if constexpr (K == 2) MISTRA_RING_TAKE(208, 209, 210, 211);
+    else if constexpr (K == 3) MISTRA_RING_TAKE(212, 213, 214, 215);
+    else if constexpr (K == 4) MISTRA_RING_TAKE(224, 225, 226, 227);
+    else if constexpr (K == 5) MISTRA_RING_TAKE(228, 229, 230, 231);
+    else if constexpr (K == 6) MISTRA_RING_TAKE(240, 241, 242, 243);
+    else MISTRA_RING_TAKE(244, 245, 246, 247);
+  }
 #undef MISTRA_RING_TAKE
   return u32x4{x, y, z, w};
 }
@@ -282,7 +308,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 
 // FORWARD = false: the vector has been forward-swept already (stage 1: inside the LU program), only the backward chain runs
-template <int R, bool FORWARD>
+template <int R, bool FORWARD, bool LOW>
 __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t xb, uint32_t rb, int lane) {
   constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
   double x[R], rd[R];
@@ -305,12 +331,12 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
   if constexpr (FORWARD) {
     gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.fwd)) + lane;
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-    vm_ring_load<0>(tp); vm_ring_load<1>(tp + 64); vm_ring_load<2>(tp + 128); vm_ring_load<3>(tp + 192);
-    vm_ring_load<4>(tp + 256); vm_ring_load<5>(tp + 320); vm_ring_load<6>(tp + 384); vm_ring_load<7>(tp + 448);
+    vm_ring_load<LOW, 0>(tp); vm_ring_load<LOW, 1>(tp + 64); vm_ring_load<LOW, 2>(tp + 128); vm_ring_load<LOW, 3>(tp + 192);
+    vm_ring_load<LOW, 4>(tp + 256); vm_ring_load<LOW, 5>(tp + 320); vm_ring_load<LOW, 6>(tp + 384); vm_ring_load<LOW, 7>(tp + 448);
     tp += kRingSlots * 64;
     {
-      const u32x4 first = vm_ring_take<0>();
-      vm_ring_load<0>(tp);
+      const u32x4 first = vm_ring_take<LOW, 0>();
+      vm_ring_load<LOW, 0>(tp);
       MISTRA_TAIL_OPERANDS(opa, first)
     }
 #pragma unroll
@@ -318,8 +344,8 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
       for (int gb = 0; gb < 16; gb += kRingSlots) {
 #define MISTRA_TAIL_FWD(K, CUR, NXT)                                                    \
         {                                                                               \
-          const u32x4 nxt = vm_ring_take<(K + 1) % kRingSlots>();                       \
-          vm_ring_load<(K + 1) % kRingSlots>(tp + (K + 1) * 64);                        \
+          const u32x4 nxt = vm_ring_take<LOW, (K + 1) % kRingSlots>();                       \
+          vm_ring_load<LOW, (K + 1) % kRingSlots>(tp + (K + 1) * 64);                        \
           MISTRA_TAIL_OPERANDS(NXT, nxt)                                                \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const double xq = readlane_f64(x[rq], 4 * (gb + K) + c);                    \
@@ -342,12 +368,12 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
   {
     gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.bwd)) + lane;
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-    vm_ring_load<0>(tp); vm_ring_load<1>(tp + 64); vm_ring_load<2>(tp + 128); vm_ring_load<3>(tp + 192);
-    vm_ring_load<4>(tp + 256); vm_ring_load<5>(tp + 320); vm_ring_load<6>(tp + 384); vm_ring_load<7>(tp + 448);
+    vm_ring_load<LOW, 0>(tp); vm_ring_load<LOW, 1>(tp + 64); vm_ring_load<LOW, 2>(tp + 128); vm_ring_load<LOW, 3>(tp + 192);
+    vm_ring_load<LOW, 4>(tp + 256); vm_ring_load<LOW, 5>(tp + 320); vm_ring_load<LOW, 6>(tp + 384); vm_ring_load<LOW, 7>(tp + 448);
     tp += kRingSlots * 64;
     {
-      const u32x4 first = vm_ring_take<0>();
-      vm_ring_load<0>(tp);
+      const u32x4 first = vm_ring_take<LOW, 0>();
+      vm_ring_load<LOW, 0>(tp);
       MISTRA_TAIL_OPERANDS(opa, first)
     }
 #pragma unroll
@@ -355,8 +381,8 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
       for (int gb = 0; gb < 16; gb += kRingSlots) {
 #define MISTRA_TAIL_BWD(K, CUR, NXT)                                                    \
         {                                                                               \
-          const u32x4 nxt = vm_ring_take<(K + 1) % kRingSlots>();                       \
-          vm_ring_load<(K + 1) % kRingSlots>(tp + (K + 1) * 64);                        \
+          const u32x4 nxt = vm_ring_take<LOW, (K + 1) % kRingSlots>();                       \
+          vm_ring_load<LOW, (K + 1) % kRingSlots>(tp + (K + 1) * 64);                        \
           MISTRA_TAIL_OPERANDS(NXT, nxt)                                                \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const double xq = readlane_f64(x[rq], 63 - (4 * (gb + K) + c));             \
@@ -386,7 +412,7 @@ struct GsOut {
   double v[NQ];
 };
 
-template <int NT, int NQ>
+template <int NT, int NQ, bool LOW>
 __device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev P, int wave, int lane) {
   GsOut<NQ> out;
   int n[NQ];
@@ -394,10 +420,10 @@ __device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev P, int wave,
   for (int q = 0; q < NQ; q++) n[q] = __builtin_amdgcn_readfirstlane((int)G_(P.blk_n)[wave * NQ + q]);
   gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)G_(P.wave_base)[wave] * 64 + lane) * 2;
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
-  vm_ring_load<0>(rp);       vm_ring_load<1, 16>(rp);
-  vm_ring_load<2>(rp + 128); vm_ring_load<3, 16>(rp + 128);
-  vm_ring_load<4>(rp + 256); vm_ring_load<5, 16>(rp + 256);
-  vm_ring_load<6>(rp + 384); vm_ring_load<7, 16>(rp + 384);
+  vm_ring_load<LOW, 0>(rp);       vm_ring_load<LOW, 1, 16>(rp);
+  vm_ring_load<LOW, 2>(rp + 128); vm_ring_load<LOW, 3, 16>(rp + 128);
+  vm_ring_load<LOW, 4>(rp + 256); vm_ring_load<LOW, 5, 16>(rp + 256);
+  vm_ring_load<LOW, 6>(rp + 384); vm_ring_load<LOW, 7, 16>(rp + 384);
   rp += 4 * 128;
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
@@ -405,10 +431,10 @@ __device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev P, int wave,
     for (int i = 0; i < n[q]; i += 4) {
 #define MISTRA_GS_ROW(K)                                                             \
       {                                                                              \
-        const u32x4 ad = vm_ring_take<2 * K, 6>();                                   \
-        const u32x4 cb = vm_ring_take<2 * K + 1, 6>();                               \
-        vm_ring_load<2 * K>(rp + K * 128);                                           \
-        vm_ring_load<2 * K + 1, 16>(rp + K * 128);                                   \
+        const u32x4 ad = vm_ring_take<LOW, 2 * K, 6>();                                   \
+        const u32x4 cb = vm_ring_take<LOW, 2 * K + 1, 6>();                               \
+        vm_ring_load<LOW, 2 * K>(rp + K * 128);                                           \
+        vm_ring_load<LOW, 2 * K + 1, 16>(rp + K * 128);                                   \
         const double x0 = lds_ld(ad.x), x1 = lds_ld(ad.y), x2 = lds_ld(ad.z), x3 = lds_ld(ad.w); \
         /* scalars first: __builtin_bit_cast on a vector ELEMENT reads element 0 with this compiler */ \
         const uint32_t cx = cb.x, cy = cb.y, cz = cb.z, cw = cb.w;                       \
@@ -430,7 +456,7 @@ __device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev P, int wave,
 }  // namespace
 
 template <class MT, int NT, bool PROF>
-__global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(const KernelArgs a) {
   constexpr int NVAR = MT::NVAR, NFIX = MT::NFIX, NREACT = MT::NREACT, NNZ = MT::NNZ, NCONST = MT::NCONST;
   constexpr int NW = NT / 64;
   constexpr int SPT = (NVAR + NT - 1) / NT, RPT = (NREACT + NT - 1) / NT;
@@ -519,7 +545,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       AB[(uint32_t)(w >> 48)] = p;            // a slot without a reaction (rct = 0) writes the spare cell: no branch
     }
     lds_barrier();
-    const GsOut<SPT> g = gsum_run<NT, SPT>(a.vdot, wave, lane);
+    const GsOut<SPT> g = gsum_run<NT, SPT, MT::RING_LOW>(a.vdot, wave, lane);
 #pragma unroll
     for (int q = 0; q < SPT; q++) out[q] = g.v[q];
   };
@@ -541,7 +567,7 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       }
     }
     lds_barrier();
-    const GsOut<JPT> g = gsum_run<NT, JPT>(a.jvs, wave, lane);
+    const GsOut<JPT> g = gsum_run<NT, JPT, MT::RING_LOW>(a.jvs, wave, lane);
 #pragma unroll
     for (int q = 0; q < JPT; q++) jac0[q] = g.v[q];
   };
@@ -605,11 +631,11 @@ __global__ __launch_bounds__(NT) void ros3_integrate_kernel(const KernelArgs a) 
       vm_run<NT>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
       lap(8);
       if (wave == 0)                                                                         // tail chain, one wave
-        tail_solve<MT::TAIL_REGS, true>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
+        tail_solve<MT::TAIL_REGS, true, MT::RING_LOW>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
     } else {
       lap(6);
       if (wave == 0)
-        tail_solve<MT::TAIL_REGS, false>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
+        tail_solve<MT::TAIL_REGS, false, MT::RING_LOW>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
     }
     lds_barrier();
     lap(9);

@@ -63,11 +63,12 @@ def test_product_does_not_import_oracle():
 
 
 def test_lookahead_ring_registers_are_out_of_the_compilers_reach():
-    """ros3_kernel.hip streams its tables through a ring of fixed high VGPRs (v192..v247) inside two non-inlined device
-    functions; that is only sound while the compiler's own values in those functions stay below v192 (build.py scans the
+    """ros3_kernel.hip streams its tables through a ring of fixed VGPRs (v192..v247, or v96..v127 for the mechanisms run at four waves
+    per SIMD) inside two non-inlined device functions; that is only sound while the compiler's own values in those
+    functions stay below the ring (build.py scans the
     generated gfx950 assembly).  Cross-compiles, no GPU needed."""
     from mistra_amd.build import ring_register_report
-    rep = ring_register_report()
-    dev = {k: v for k, v in rep.items() if "kernel" not in k}
-    assert any("gsum_run" in k for k in dev) and any("tail_solve" in k for k in dev)
-    assert max(dev.values()) < 192, dev
+    rep = ring_register_report()          # raises if a function's own registers reach its ring
+    dev = {k: v for k, v in rep.items() if "gsum_run" in k or "tail_solve" in k}
+    assert len(dev) >= 8, rep
+    assert max(dev.values()) < 96, dev    # today all of them stay clear even of the low placement
