@@ -79,15 +79,15 @@ struct VmBufs {
 
 struct GsBufs {
   DevBuf<uint32_t> wave_base, recs;
-  DevBuf<uint16_t> blk_n;
+  DevBuf<uint16_t> rows;
   hipError_t upload(const GsumProgram& P) {
     hipError_t e;
     if ((e = wave_base.upload(P.wave_base)) != hipSuccess) return e;
-    if ((e = blk_n.upload(P.blk_n)) != hipSuccess) return e;
+    if ((e = rows.upload(P.rows)) != hipSuccess) return e;
     return recs.upload(P.recs);
   }
-  GsDev dev() const { return GsDev{wave_base.p, blk_n.p, recs.p}; }
-  void release() { wave_base.release(); recs.release(); blk_n.release(); }
+  GsDev dev() const { return GsDev{wave_base.p, rows.p, recs.p}; }
+  void release() { wave_base.release(); recs.release(); rows.release(); }
 };
 
 struct MechState {

@@ -13,7 +13,7 @@ struct VmDev {                 // LDS VM program in device memory (see schedule.
 
 struct GsDev {                 // gather-sum program in device memory (see schedule.hpp)
   const uint32_t* wave_base;   // [NW]     first row of each wave's stream
-  const uint16_t* blk_n;       // [NW*NQ]  rows per (wave, output block), multiples of 4
+  const uint16_t* rows;        // [NW]     rows of each wave's stream, multiples of 4
   const uint32_t* recs;        // two uint4 per lane and row: 4 LDS byte addresses, 4 float coefficients
 };
 

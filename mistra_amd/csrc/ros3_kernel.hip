@@ -404,20 +404,14 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
   for (int r = 0; r < R; r++) lds_st(xb + 8 * (r * 64 + lane), x[r]);
 }
 
-// ---- the gather-sum machine (schedule.hpp): out[q] = c0*M[i0] + c1*M[i1] + ...  left to right, four terms per table
-//      row, rows streamed through the look-ahead ring (4 rows in flight).  acc starts at -0.0 and padding terms are
-//      (-0.0f)*(0.0 cell), so no flags are needed and the sums are bit-for-bit the flagged ones.
-template <int NQ>
-struct GsOut {
-  double v[NQ];
-};
-
-template <int NT, int NQ, bool LOW>
-__device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev P, int wave, int lane) {
-  GsOut<NQ> out;
-  int n[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; q++) n[q] = __builtin_amdgcn_readfirstlane((int)G_(P.blk_n)[wave * NQ + q]);
+// ---- the gather-sum machine (schedule.hpp): out = c0*M[i0] + c1*M[i1] + ...  left to right, four terms per table row,
+//      rows streamed through the look-ahead ring (4 rows in flight).  acc starts at -0.0 and padding terms are
+//      (-0.0f)*(0.0 cell), so terms need no flags and the sums are bit-for-bit the flagged ones.  A row whose first
+//      address carries GS_ROW_FLUSH completes the lane's current output: it is stored to the lane's next output cell in
+//      LDS (out_addr, then every out_stride bytes) — the caller reads its own cells back, no barrier needed.
+template <int NT, bool LOW>
+__device__ __attribute__((noinline)) void gsum_run(const GsDev P, int wave, int lane, uint32_t out_addr, uint32_t out_stride) {
+  const int n = __builtin_amdgcn_readfirstlane((int)G_(P.rows)[wave]);
   gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)G_(P.wave_base)[wave] * 64 + lane) * 2;
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
   vm_ring_load<LOW, 0>(rp);       vm_ring_load<LOW, 1, 16>(rp);
@@ -425,32 +419,34 @@ __device__ __attribute__((noinline)) GsOut<NQ> gsum_run(const GsDev P, int wave,
   vm_ring_load<LOW, 4>(rp + 256); vm_ring_load<LOW, 5, 16>(rp + 256);
   vm_ring_load<LOW, 6>(rp + 384); vm_ring_load<LOW, 7, 16>(rp + 384);
   rp += 4 * 128;
-#pragma unroll
-  for (int q = 0; q < NQ; q++) {
-    double acc = -0.0;
-    for (int i = 0; i < n[q]; i += 4) {
+  double acc = -0.0;
+  for (int i = 0; i < n; i += 4) {
 #define MISTRA_GS_ROW(K)                                                             \
-      {                                                                              \
-        const u32x4 ad = vm_ring_take<LOW, 2 * K, 6>();                                   \
-        const u32x4 cb = vm_ring_take<LOW, 2 * K + 1, 6>();                               \
-        vm_ring_load<LOW, 2 * K>(rp + K * 128);                                           \
-        vm_ring_load<LOW, 2 * K + 1, 16>(rp + K * 128);                                   \
-        const double x0 = lds_ld(ad.x), x1 = lds_ld(ad.y), x2 = lds_ld(ad.z), x3 = lds_ld(ad.w); \
-        /* scalars first: __builtin_bit_cast on a vector ELEMENT reads element 0 with this compiler */ \
-        const uint32_t cx = cb.x, cy = cb.y, cz = cb.z, cw = cb.w;                       \
-        acc = acc + (double)__uint_as_float(cx) * x0;                    \
-        acc = acc + (double)__uint_as_float(cy) * x1;                    \
-        acc = acc + (double)__uint_as_float(cz) * x2;                    \
-        acc = acc + (double)__uint_as_float(cw) * x3;                    \
-      }
-      MISTRA_GS_ROW(0) MISTRA_GS_ROW(1) MISTRA_GS_ROW(2) MISTRA_GS_ROW(3)
-#undef MISTRA_GS_ROW
-      rp += 4 * 128;
+    {                                                                                \
+      const u32x4 ad = vm_ring_take<LOW, 2 * K, 6>();                                \
+      const u32x4 cb = vm_ring_take<LOW, 2 * K + 1, 6>();                            \
+      vm_ring_load<LOW, 2 * K>(rp + K * 128);                                        \
+      vm_ring_load<LOW, 2 * K + 1, 16>(rp + K * 128);                                \
+      const uint32_t a0 = ad.x;                                                      \
+      const bool flush = __builtin_amdgcn_readfirstlane((int)a0) & 1;   /* the mark is the same in every lane */ \
+      const double x0 = lds_ld(a0 & ~7u), x1 = lds_ld(ad.y), x2 = lds_ld(ad.z), x3 = lds_ld(ad.w); \
+      /* scalars first: __builtin_bit_cast on a vector ELEMENT reads element 0 with this compiler */ \
+      const uint32_t cx = cb.x, cy = cb.y, cz = cb.z, cw = cb.w;                     \
+      acc = acc + (double)__uint_as_float(cx) * x0;                                  \
+      acc = acc + (double)__uint_as_float(cy) * x1;                                  \
+      acc = acc + (double)__uint_as_float(cz) * x2;                                  \
+      acc = acc + (double)__uint_as_float(cw) * x3;                                  \
+      if (flush) {                                                                   \
+        lds_st(out_addr, acc);                                                       \
+        out_addr += out_stride;                                                      \
+        acc = -0.0;                                                                  \
+      }                                                                              \
     }
-    out.v[q] = acc;
+    MISTRA_GS_ROW(0) MISTRA_GS_ROW(1) MISTRA_GS_ROW(2) MISTRA_GS_ROW(3)
+#undef MISTRA_GS_ROW
+    rp += 4 * 128;
   }
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // drain the look-ahead loads before returning
-  return out;
 }
 
 }  // namespace
@@ -528,6 +524,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   };
 
   // ---- Fun_x (gas.f:2043): X <- v; A(r) = RCT(r)*X*X*X; Vdot = signed sums of A
+  static_assert(SPT == 1 && JPT * NT <= NNZ, "output cells of the gather-sum machine: one species per thread, JVS sums inside Ghimj");
   auto fun = [&](const double (&v)[SPT], double (&out)[SPT]) {
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
@@ -545,9 +542,15 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       AB[(uint32_t)(w >> 48)] = p;            // a slot without a reaction (rct = 0) writes the spare cell: no branch
     }
     lds_barrier();
-    const GsOut<SPT> g = gsum_run<NT, SPT, MT::RING_LOW>(a.vdot, wave, lane);
+    // sums land in this thread's own cells of XS (free here: the solves copy their result out before Fun runs again);
+    // a thread without a species parks its (empty) sum in the trash cell
+    gsum_run<NT, MT::RING_LOW>(a.vdot, wave, lane, t < NVAR ? 8u * (uint32_t)(NNZ + t) : 8u * (uint32_t)(NNZ + NVAR + 2),
+                               t < NVAR ? 8u * (uint32_t)NT : 0u);
 #pragma unroll
-    for (int q = 0; q < SPT; q++) out[q] = g.v[q];
+    for (int q = 0; q < SPT; q++) {
+      const int s = q * NT + t;
+      out[q] = s < NVAR ? XS[s] : 0.0;
+    }
   };
 
   // ---- Jac_SP_x (gas.f:2656) on the V already in X: B products under their reaction, JVS sums into registers
@@ -567,9 +570,10 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       }
     }
     lds_barrier();
-    const GsOut<JPT> g = gsum_run<NT, JPT, MT::RING_LOW>(a.jvs, wave, lane);
+    // sums land in this thread's own cells of the Ghimj area (free here: ros_PrepareMatrix rebuilds it from jac0)
+    gsum_run<NT, MT::RING_LOW>(a.jvs, wave, lane, 8u * (uint32_t)t, 8u * (uint32_t)NT);
 #pragma unroll
-    for (int q = 0; q < JPT; q++) jac0[q] = g.v[q];
+    for (int q = 0; q < JPT; q++) jac0[q] = M[q * NT + t];
   };
 
   // ---- ros_PrepareMatrix_x (gas.f:1404), first half: Ghimj = -Jac0, diagonal += 1/(H*gamma).

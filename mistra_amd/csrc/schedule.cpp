@@ -532,7 +532,7 @@ GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, doub
     output_of_slot[(size_t)s] = (int)o;
   }
   P.wave_base.assign((size_t)P.nw, 0);
-  P.blk_n.assign((size_t)P.nw * nq, 0);
+  P.rows.assign((size_t)P.nw, 0);
   const float neg_zero = -0.0f;
   uint32_t neg_zero_bits;
   static_assert(sizeof neg_zero_bits == sizeof neg_zero, "float is 32 bits");
@@ -543,18 +543,17 @@ GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, doub
       for (int k = 0; k < 4; k++) P.recs.push_back(neg_zero_bits);
     }
   };
+  if (zero_cell_bytes & 7u) throw std::logic_error("gsum addresses must leave their low bits to the row marks");
   for (int w = 0; w < P.nw; w++) {
     P.wave_base[(size_t)w] = (uint32_t)(P.recs.size() / 512);
+    size_t wave_rows = 0;
     for (int q = 0; q < nq; q++) {
       size_t n = 0;
       for (int l = 0; l < 64; l++) {
         int o = output_of_slot[(size_t)q * nt + w * 64 + l];
         if (o >= 0) n = std::max(n, outputs[(size_t)o].size());
       }
-      size_t rows = (n + 3) / 4;
-      rows = (rows + GS_ROW_ALIGN - 1) / GS_ROW_ALIGN * GS_ROW_ALIGN;
-      if (rows > 0xFFFF) throw std::logic_error("gsum block too long");
-      P.blk_n[(size_t)w * nq + q] = (uint16_t)rows;
+      const size_t rows = std::max<size_t>(1, (n + 3) / 4);       // at least one row: it carries the block's flush mark
       for (size_t r = 0; r < rows; r++)
         for (int l = 0; l < 64; l++) {
           int o = output_of_slot[(size_t)q * nt + w * 64 + l];
@@ -574,11 +573,16 @@ GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, doub
               cbits[k] = neg_zero_bits;
             }
           }
+          if (r == rows - 1) addr[0] |= GS_ROW_FLUSH;      // every lane of the row: the output is complete after this row
           for (int k = 0; k < 4; k++) P.recs.push_back(addr[k]);
           for (int k = 0; k < 4; k++) P.recs.push_back(cbits[k]);
         }
-      P.wave_rows += (int64_t)rows;
+      wave_rows += rows;
     }
+    while (wave_rows % GS_ROW_ALIGN) { pad_row(); wave_rows++; }       // the executor walks whole turns of its ring
+    if (wave_rows > 0xFFFF) throw std::logic_error("gsum stream too long");
+    P.rows[(size_t)w] = (uint16_t)wave_rows;
+    P.wave_rows += (int64_t)wave_rows;
     for (int rr = 0; rr < VM_LOOKAHEAD_ROWS; rr++) pad_row();     // slack for the executor's look-ahead loads
   }
   return P;

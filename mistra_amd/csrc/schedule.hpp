@@ -43,10 +43,12 @@
 //  * the gather-sum machine ("gsum"): out = c0*src[i0] + c1*src[i1] + ... left to right, coefficient as float
 //    (every stoichiometric coefficient in the reference is a default-REAL literal or a small integer).
 //    A wave's table is one linear stream of 32-byte records (four absolute LDS byte addresses + four floats per lane
-//    and row), fetched through the same look-ahead ring as the VM; each output's rows are padded to a multiple of
-//    four with the exact identity term (-0.0f * M[0.0 cell]): acc starts at -0.0, so neither the first term nor the
-//    padding needs a flag.  It expresses the Vdot aggregation of Fun_x (gas.f:2395) and the JVS construction of
-//    Jac_SP_x (gas.f:3812) in the reference's term order.
+//    and row), fetched through the same look-ahead ring as the tail chain.  Every lane of a wave produces its q-th output
+//    in the same rows; the last of them carries a flush mark: the accumulator goes to the lane's q-th output cell in LDS
+//    and restarts at -0.0 (so neither the first term nor the padding terms, (-0.0f * M[0.0 cell]), need a flag).  An
+//    output with few terms costs one row, not a turn of the ring: the Jacobian's 4 709 outputs have two terms on
+//    average.  It expresses the Vdot aggregation of Fun_x (gas.f:2395) and the JVS construction of Jac_SP_x (gas.f:3812)
+//    in the reference's term order.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -86,7 +88,8 @@ struct VmLayout {
   int size() const { return nnz + 2 * nvar + 4 + max_temps; }
 };
 
-constexpr int GS_ROW_ALIGN = 4;         // an output's rows are padded to a multiple of this (= ring depth in rows)
+constexpr int GS_ROW_ALIGN = 4;         // a wave's row count is padded to a multiple of this (= ring depth in rows)
+constexpr uint32_t GS_ROW_FLUSH = 1u;   // on the first address of every lane of a row: the lane's output is complete after this row
 
 constexpr uint16_t POS_DIAG = 0x8000;   // flag on a Ghimj slot number: the slot is a diagonal
 constexpr uint16_t POS_NONE = 0xFFFF;
@@ -117,8 +120,8 @@ struct VmProgram {
 struct GsumProgram {
   int nt = 0, nw = 0, nq = 0;
   std::vector<uint32_t> wave_base;              // [nw]     first row of each wave's linear stream
-  std::vector<uint16_t> blk_n;                  // [nw*nq]  rows of output block q of wave w (multiple of GS_ROW_ALIGN, may be 0)
-  std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*8 + k]  k<4: LDS byte address, k>=4: float bits
+  std::vector<uint16_t> rows;                   // [nw]     rows of the wave's stream (multiple of GS_ROW_ALIGN); exactly nq of them carry GS_ROW_FLUSH
+  std::vector<uint32_t> recs;                   // [((wave_base[w] + row)*64 + lane)*8 + k]  k<4: LDS byte address (| mark on k=0), k>=4: float bits
   int64_t n_terms = 0, wave_rows = 0;
 };
 

@@ -104,26 +104,27 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
 static void run_gsum(const GsumProgram& P, const std::vector<double>& src, uint32_t src_base, uint32_t zero_cell,
                      std::vector<double>& out) {
   out.assign((size_t)P.nq * P.nt, 0.0);
-  for (int w = 0; w < P.nw; w++) {
-    size_t row = P.wave_base[(size_t)w];
-    for (int q = 0; q < P.nq; q++) {
-      const int n = P.blk_n[(size_t)w * P.nq + q];
-      for (int l = 0; l < 64; l++) {
-        double acc = -0.0;
-        for (int ridx = 0; ridx < n; ridx++)
-          for (int k = 0; k < 4; k++) {
-            const size_t at = ((row + ridx) * 64 + l) * 8;
-            const uint32_t addr = P.recs[at + k];
-            float cf;
-            std::memcpy(&cf, &P.recs[at + 4 + k], 4);
-            const double x = addr == zero_cell ? 0.0 : src[(size_t)((addr - src_base) / 8)];
-            acc = acc + (double)cf * x;
-          }
-        out[(size_t)q * P.nt + w * 64 + l] = acc;
+  for (int w = 0; w < P.nw; w++)
+    for (int l = 0; l < 64; l++) {
+      double acc = -0.0;
+      int q = 0;
+      for (size_t row = P.wave_base[(size_t)w]; row < (size_t)P.wave_base[(size_t)w] + P.rows[(size_t)w]; row++) {
+        const size_t at = (row * 64 + (size_t)l) * 8;
+        for (int k = 0; k < 4; k++) {
+          const uint32_t addr = P.recs[at + k] & ~7u;
+          float cf;
+          std::memcpy(&cf, &P.recs[at + 4 + k], 4);
+          const double x = addr == zero_cell ? 0.0 : src[(size_t)((addr - src_base) / 8)];
+          acc = acc + (double)cf * x;
+        }
+        if (P.recs[at] & GS_ROW_FLUSH) {
+          if (q >= P.nq) std::abort();
+          out[(size_t)q++ * P.nt + (size_t)w * 64 + (size_t)l] = acc;
+          acc = -0.0;
+        }
       }
-      row += (size_t)n;
+      if (q != P.nq) std::abort();        // every lane flushes exactly nq times
     }
-  }
 }
 
 // The kernel's solve: head forward (VM) -> tail chain forward/backward (one wave, registers) -> head backward (VM).
