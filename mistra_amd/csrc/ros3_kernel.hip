@@ -586,34 +586,26 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       const int s = q * NT + t;
       if (s < NVAR) XS[s] = rhs[q];
     }
+    // branch-free: a slot the thread does not have stores to the trash cell, the diagonal term is a select
     bool zero_diag = false;
+    auto put = [&](uint32_t p, double minus_jac) {
+      const bool none = p == kPosNone, dg = !none && (p & kPosDiag);
+      const double vd = minus_jac + ghinv;
+      const double v = dg ? vd : minus_jac;
+      zero_diag |= dg && (v == 0.0);
+      M[none ? (uint32_t)(NNZ + NVAR + 2) : (p & 0x7FFFu)] = v;
+    };
 #pragma unroll
     for (int q = 0; q < JPT; q++) {
       uint32_t pw = jpos[q / 2];
       asm volatile("" : "+v"(pw));        // unpack here, not hoisted into registers that live across the step loop
-      const uint32_t p = (q & 1) ? (pw >> 16) : (pw & 0xFFFFu);
-      if (p != kPosNone) {
-        double v = -jac0[q];
-        if (p & kPosDiag) {
-          v = v + ghinv;
-          zero_diag |= (v == 0.0);
-        }
-        M[p & 0x7FFFu] = v;
-      }
+      put((q & 1) ? (pw >> 16) : (pw & 0xFFFFu), -jac0[q]);
     }
 #pragma unroll
     for (int q = 0; q < ZPT; q++) {
       uint32_t pw = zpos[q / 2];
       asm volatile("" : "+v"(pw));
-      const uint32_t p = (q & 1) ? (pw >> 16) : (pw & 0xFFFFu);
-      if (p != kPosNone) {
-        double v = -0.0;
-        if (p & kPosDiag) {
-          v = v + ghinv;
-          zero_diag |= (v == 0.0);
-        }
-        M[p & 0x7FFFu] = v;
-      }
+      put((q & 1) ? (pw >> 16) : (pw & 0xFFFFu), -0.0);
     }
     if (zero_diag) flags[0] = 1;
     lds_barrier();
