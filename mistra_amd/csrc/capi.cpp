@@ -100,7 +100,8 @@ struct MechState {
   DevBuf<uint16_t> jvs_pos, zero_pos, diag_pos;
   GsBufs vdot, jvs;
   VmBufs lu, solve_head_fwd, solve_head_bwd;
-  DevBuf<uint32_t> tail_fwd, tail_bwd;
+  DevBuf<uint32_t> tail_fwd, tail_bwd, lu_scale;
+  int lu_scale_slots = 0;
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
   DevBuf<int32_t> s_ierr, s_stats;
@@ -111,7 +112,7 @@ struct MechState {
   void release() {
     consts.release(); fun_fac.release(); jac_fac.release(); jvs_pos.release(); zero_pos.release(); diag_pos.release();
     vdot.release(); jvs.release(); lu.release(); solve_head_fwd.release(); solve_head_bwd.release();
-    tail_fwd.release(); tail_bwd.release();
+    tail_fwd.release(); tail_bwd.release(); lu_scale.release();
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release();
     if (one_dev) (void)hipFree(one_dev);
     if (one_host) (void)hipHostFree(one_host);
@@ -146,8 +147,8 @@ int default_nt(int mech) {
 }
 
 template <class MT>
-bool traits_match(const MechTables& t, int n_jnz, int tail_regs) {
-  return tail_regs == MT::TAIL_REGS && t.nvar == MT::NVAR && t.nfix == MT::NFIX && t.nreact == MT::NREACT && t.nnz == MT::NNZ && t.nb == MT::NB &&
+bool traits_match(const MechTables& t, int n_jnz, int tail_regs, bool scale_pass) {
+  return tail_regs == MT::TAIL_REGS && scale_pass == MT::SCALE_PASS && t.nvar == MT::NVAR && t.nfix == MT::NFIX && t.nreact == MT::NREACT && t.nnz == MT::NNZ && t.nb == MT::NB &&
          t.nconst == MT::NCONST && n_jnz == MT::NJNZ;
 }
 
@@ -170,9 +171,9 @@ int setup_mech(int mech) {
   } catch (const std::exception& ex) {
     return fail(std::string("schedule compiler: ") + ex.what());
   }
-  bool ok = mech == MISTRA_MECH_GAS   ? traits_match<GasTraits>(S.tab, K.n_jnz, K.tail.regs)
-            : mech == MISTRA_MECH_AER ? traits_match<AerTraits>(S.tab, K.n_jnz, K.tail.regs)
-                                      : traits_match<TotTraits>(S.tab, K.n_jnz, K.tail.regs);
+  bool ok = mech == MISTRA_MECH_GAS   ? traits_match<GasTraits>(S.tab, K.n_jnz, K.tail.regs, K.lu_scale.nslots > 0)
+            : mech == MISTRA_MECH_AER ? traits_match<AerTraits>(S.tab, K.n_jnz, K.tail.regs, K.lu_scale.nslots > 0)
+                                      : traits_match<TotTraits>(S.tab, K.n_jnz, K.tail.regs, K.lu_scale.nslots > 0);
   if (!ok) return fail(std::string(kMechName[mech]) + ": mechanism table does not match the compiled kernel sizes");
   S.text = std::string(kMechName[mech]) + ": " + describe(K);
   S.n_temps = K.n_temps;
@@ -189,6 +190,8 @@ int setup_mech(int mech) {
   HIP_TRY(S.solve_head_bwd.upload(K.solve_head_bwd));
   HIP_TRY(S.tail_fwd.upload(K.tail.fwd));
   HIP_TRY(S.tail_bwd.upload(K.tail.bwd));
+  HIP_TRY(S.lu_scale.upload(K.lu_scale.recs));
+  S.lu_scale_slots = K.lu_scale.nslots;
   S.ready = true;
   return 0;
 }
@@ -214,6 +217,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
     a.lu.nrounds = std::max(1, std::min(a.lu.nrounds, std::atoi(cut)));
   a.solve_head_fwd = S.solve_head_fwd.dev(); a.solve_head_bwd = S.solve_head_bwd.dev();
   a.tail = TailDev{S.tail_fwd.p, S.tail_bwd.p};
+  a.lu_scale = ScaleDev{S.lu_scale.p, S.lu_scale_slots, S.lu_scale_slots + VM_LOOKAHEAD_ROWS};
   return a;
 }
 

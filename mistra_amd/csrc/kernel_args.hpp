@@ -17,6 +17,12 @@ struct GsDev {                 // gather-sum program in device memory (see sched
   const uint32_t* recs;        // two uint4 per lane and row: 4 LDS byte addresses, 4 float coefficients
 };
 
+struct ScaleDev {              // final scaling of the factorisation (schedule.hpp: ScaleProgram)
+  const uint32_t* recs;        // u32x4 per lane and slot: two (tgt, aux) LDS byte-address pairs
+  int nslots;                  // per lane, multiple of 8
+  int wave_slots;              // wave w starts at slot w*wave_slots (nslots + the look-ahead slack)
+};
+
 struct TailDev {               // tail chain of the triangular solves (schedule.hpp: TailSolve)
   const uint32_t* fwd;         // u32x4 per lane and group of 4 columns, columns ascending
   const uint32_t* bwd;         // same, columns descending
@@ -44,6 +50,7 @@ struct KernelArgs {
   const uint16_t* diag_pos;
   GsDev vdot, jvs;
   VmDev lu, solve_head_fwd, solve_head_bwd;
+  ScaleDev lu_scale;
   TailDev tail;
 };
 

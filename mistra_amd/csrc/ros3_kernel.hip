@@ -449,6 +449,33 @@ __device__ __attribute__((noinline)) void gsum_run(const GsDev P, int wave, int 
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // drain the look-ahead loads before returning
 }
 
+// ---- the factorisation's last act (schedule.hpp: ScaleProgram): M[tgt] *= M[aux] for two cells per 16-byte slot,
+//      slots streamed through the look-ahead ring.  All cells are distinct: no ordering among lanes.
+template <int NT, bool LOW>
+__device__ __attribute__((noinline)) void scale_run(const ScaleDev P, int wave, int lane) {
+  const int n = __builtin_amdgcn_readfirstlane(P.nslots);
+  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)wave * (size_t)P.wave_slots * 64 + lane);
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
+  vm_ring_load<LOW, 0>(rp);       vm_ring_load<LOW, 1>(rp + 64);  vm_ring_load<LOW, 2>(rp + 128); vm_ring_load<LOW, 3>(rp + 192);
+  vm_ring_load<LOW, 4>(rp + 256); vm_ring_load<LOW, 5>(rp + 320); vm_ring_load<LOW, 6>(rp + 384); vm_ring_load<LOW, 7>(rp + 448);
+  rp += kRingSlots * 64;
+  for (int i = 0; i < n; i += kRingSlots) {
+#define MISTRA_SCALE_SLOT(K)                                                         \
+    {                                                                                \
+      const u32x4 ad = vm_ring_take<LOW, K>();                                       \
+      vm_ring_load<LOW, K>(rp + K * 64);                                             \
+      const double v0 = lds_ld(ad.x), f0 = lds_ld(ad.y), v1 = lds_ld(ad.z), f1 = lds_ld(ad.w); \
+      lds_st(ad.x, v0 * f0);                                                         \
+      lds_st(ad.z, v1 * f1);                                                         \
+    }
+    MISTRA_SCALE_SLOT(0) MISTRA_SCALE_SLOT(1) MISTRA_SCALE_SLOT(2) MISTRA_SCALE_SLOT(3)
+    MISTRA_SCALE_SLOT(4) MISTRA_SCALE_SLOT(5) MISTRA_SCALE_SLOT(6) MISTRA_SCALE_SLOT(7)
+#undef MISTRA_SCALE_SLOT
+    rp += kRingSlots * 64;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // drain the look-ahead loads before returning
+}
+
 }  // namespace
 
 template <class MT, int NT, bool PROF>
@@ -719,6 +746,10 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
             else { ierr = -8; break; }
           } else {
             vm_run<NT>(a.lu, wave, lane);
+            if constexpr (MT::SCALE_PASS) {      // else the scaling is the LU program's last round
+              scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);      // L(k,j) *= R(j); tail block: U(i,c) *= R(i)
+              lds_barrier();
+            }
             lap(3);
           }
         }

@@ -52,6 +52,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "mech_tables.hpp"
@@ -140,6 +141,15 @@ struct TailSolve {
   std::vector<uint32_t> bwd;                    // same, columns DEscending: group g, word c  <->  q = m-1-(4g+c)
 };
 
+// The factorisation's last act, M[tgt] *= M[aux] for ~11 000 independent cells of the tot mechanism (L(k,j) *= R(j), and
+// U(i,c) *= R(i) inside the tail block): far cheaper as its own tight pass than as VM rows, which would drag six unused
+// operand gathers and the mark decoding along for every pair.
+struct ScaleProgram {
+  int nt = 0, nw = 0, nslots = 0;               // nslots: 16-byte slots per lane (multiple of 8), two (tgt, aux) byte-address pairs each
+  std::vector<uint32_t> recs;                   // [((w*nslots + slot)*64 + lane)*4 + k]  (+ VM_LOOKAHEAD_ROWS slots of slack per wave)
+  int64_t n_pairs = 0;
+};
+
 struct KernelSchedule {
   int nt = 0, nw = 0;
   int spt = 0;   // species per thread          s = q*nt + t
@@ -158,6 +168,7 @@ struct KernelSchedule {
   std::vector<uint16_t> zero_pos;               // [zpt*nt] Ghimj slots that Jac_SP_x sets to 0 (| POS_DIAG)
   std::vector<uint16_t> diag_pos;               // [spt*nt] Ghimj slot of (s,s), POS_NONE past nvar
   VmProgram lu, solve;                          // solve = the whole of KppSolve_x as one VM program (kept for tests)
+  ScaleProgram lu_scale;                        // runs right after lu
   VmProgram solve_head_fwd, solve_head_bwd;     // head rows (+ head-column part of tail rows) around the tail chain
   int n_temps = 0;                              // temp cells the two head programs use (zeroed by the kernel per solve)
   TailSolve tail;
@@ -165,7 +176,10 @@ struct KernelSchedule {
 
 VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 2);
 // with_rhs: also forward-sweep the vector held in XS while factorising (rows of an appended right-hand-side column)
-std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool with_rhs, int tail_h = -1);
+// scale_pairs: where to put the (tgt, aux) pairs of the final scaling; nullptr = keep them as a last phase of VM entries
+std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool with_rhs, int tail_h = -1,
+                                std::vector<std::pair<int, int>>* scale_pairs = nullptr);
+ScaleProgram build_scale_program(const std::vector<std::pair<int, int>>& pairs, const VmLayout& lay, int nt);
 int split_long_entries(std::vector<VmEntry>& entries, const VmLayout& lay, int threshold, int first_temp);
 std::vector<VmEntry> solve_entries(const MechTables& m, const VmLayout& lay);
 std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, const VmLayout& lay, int h);

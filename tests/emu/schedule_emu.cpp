@@ -209,6 +209,18 @@ int emu_lu(void* h, double* G, double* R, double* X) {
   std::memcpy(M.data(), G, sizeof(double) * e->m.nnz);
   if (X) std::memcpy(M.data() + e->m.nnz, X, sizeof(double) * e->m.nvar);
   int rc = run_vm(e->s.lu, M, e->lay().trash());
+  {   // the scaling pass that follows the LU program (ros3_kernel.hip: scale_run)
+    const ScaleProgram& sp = e->s.lu_scale;
+    const size_t wave_slots = (size_t)sp.nslots + VM_LOOKAHEAD_ROWS;
+    for (int w = 0; w < sp.nw; w++)
+      for (int sl = 0; sl < sp.nslots; sl++)
+        for (int l = 0; l < 64; l++)
+          for (int k = 0; k < 2; k++) {
+            const size_t at = (((size_t)w * wave_slots + (size_t)sl) * 64 + (size_t)l) * 4 + 2 * (size_t)k;
+            const size_t tgt = sp.recs[at] / 8, aux = sp.recs[at + 1] / 8;
+            M[tgt] = M[tgt] * M[aux];
+          }
+  }
   std::memcpy(G, M.data(), sizeof(double) * e->m.nnz);
   if (R) std::memcpy(R, M.data() + e->lay().rdiag(), sizeof(double) * e->m.nvar);
   if (X) std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
