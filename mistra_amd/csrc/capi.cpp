@@ -314,9 +314,9 @@ int mistra_chem_integrate(int mech, int ncell, const double* var_in, const doubl
     double sum[12] = {0};
     for (size_t c = 0; c < nc; c++)
       for (int k = 0; k < 12; k++) sum[k] += (double)h[c * 12 + k];
-    const char* names[12] = {"fun", "jac", "prepare", "lu", "solve(rest)", "norm", "other", "total", "solve_head_fwd", "solve_tail", "solve_head_bwd", "-"};
+    const char* names[12] = {"fun", "jac", "prepare", "lu", "solve(rest)", "norm", "other", "total", "solve_head_fwd", "solve_tail", "solve_head_bwd", "lu_scale"};
     std::fprintf(stderr, "[mistra_chem profile] %s, %zu cells, mean shader-clock ticks per cell:", kMechName[mech], nc);
-    for (int k = 0; k < 11; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
+    for (int k = 0; k < 12; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
     std::fprintf(stderr, "\n");
     prof.release();
   }

@@ -460,17 +460,23 @@ __device__ __attribute__((noinline)) void scale_run(const ScaleDev P, int wave, 
   vm_ring_load<LOW, 4>(rp + 256); vm_ring_load<LOW, 5>(rp + 320); vm_ring_load<LOW, 6>(rp + 384); vm_ring_load<LOW, 7>(rp + 448);
   rp += kRingSlots * 64;
   for (int i = 0; i < n; i += kRingSlots) {
-#define MISTRA_SCALE_SLOT(K)                                                         \
+    // four slots at a time: sixteen gathers in flight, then the eight products (a lone gather-multiply-store chain per
+    // slot would expose the LDS latency sixteen times over)
+#define MISTRA_SCALE_GROUP(K)                                                        \
     {                                                                                \
-      const u32x4 ad = vm_ring_take<LOW, K>();                                       \
-      vm_ring_load<LOW, K>(rp + K * 64);                                             \
-      const double v0 = lds_ld(ad.x), f0 = lds_ld(ad.y), v1 = lds_ld(ad.z), f1 = lds_ld(ad.w); \
-      lds_st(ad.x, v0 * f0);                                                         \
-      lds_st(ad.z, v1 * f1);                                                         \
+      const u32x4 a0 = vm_ring_take<LOW, K>();     vm_ring_load<LOW, K>(rp + K * 64);         \
+      const u32x4 a1 = vm_ring_take<LOW, K + 1>(); vm_ring_load<LOW, K + 1>(rp + (K + 1) * 64); \
+      const u32x4 a2 = vm_ring_take<LOW, K + 2>(); vm_ring_load<LOW, K + 2>(rp + (K + 2) * 64); \
+      const u32x4 a3 = vm_ring_take<LOW, K + 3>(); vm_ring_load<LOW, K + 3>(rp + (K + 3) * 64); \
+      const double v0 = lds_ld(a0.x), f0 = lds_ld(a0.y), v1 = lds_ld(a0.z), f1 = lds_ld(a0.w); \
+      const double v2 = lds_ld(a1.x), f2 = lds_ld(a1.y), v3 = lds_ld(a1.z), f3 = lds_ld(a1.w); \
+      const double v4 = lds_ld(a2.x), f4 = lds_ld(a2.y), v5 = lds_ld(a2.z), f5 = lds_ld(a2.w); \
+      const double v6 = lds_ld(a3.x), f6 = lds_ld(a3.y), v7 = lds_ld(a3.z), f7 = lds_ld(a3.w); \
+      lds_st(a0.x, v0 * f0); lds_st(a0.z, v1 * f1); lds_st(a1.x, v2 * f2); lds_st(a1.z, v3 * f3); \
+      lds_st(a2.x, v4 * f4); lds_st(a2.z, v5 * f5); lds_st(a3.x, v6 * f6); lds_st(a3.z, v7 * f7); \
     }
-    MISTRA_SCALE_SLOT(0) MISTRA_SCALE_SLOT(1) MISTRA_SCALE_SLOT(2) MISTRA_SCALE_SLOT(3)
-    MISTRA_SCALE_SLOT(4) MISTRA_SCALE_SLOT(5) MISTRA_SCALE_SLOT(6) MISTRA_SCALE_SLOT(7)
-#undef MISTRA_SCALE_SLOT
+    MISTRA_SCALE_GROUP(0) MISTRA_SCALE_GROUP(4)
+#undef MISTRA_SCALE_GROUP
     rp += kRingSlots * 64;
   }
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // drain the look-ahead loads before returning
@@ -747,8 +753,10 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
           } else {
             vm_run<NT>(a.lu, wave, lane);
             if constexpr (MT::SCALE_PASS) {      // else the scaling is the LU program's last round
+              lap(3);
               scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);      // L(k,j) *= R(j); tail block: U(i,c) *= R(i)
               lds_barrier();
+              lap(11);
             }
             lap(3);
           }
