@@ -648,13 +648,13 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   // ---- KppSolve_x (gas.f:6206) on a register vector.  swept = true: XS already holds the forward-swept vector (the LU
   //      program carried the stage-1 right-hand side through the elimination), only the backward half is left.
   auto solve = [&](double (&k)[SPT], bool swept) {
+    for (int i = t; i < a.n_temps; i += NT) M[NNZ + 2 * NVAR + 4 + i] = 0.0;         // partial-sum cells of the head sweeps
     if (!swept) {
 #pragma unroll
       for (int q = 0; q < SPT; q++) {
         const int s = q * NT + t;
         if (s < NVAR) XS[s] = k[q];
       }
-      for (int i = t; i < a.n_temps; i += NT) M[NNZ + 2 * NVAR + 4 + i] = 0.0;       // partial-sum cells of the head sweep
       lds_barrier();
       lap(6);
       vm_run<NT>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves

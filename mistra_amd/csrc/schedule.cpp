@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <numeric>
 #include <stdexcept>
@@ -473,19 +474,51 @@ std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, const VmLayout&
   return out;
 }
 
-// Backward sweep of the head rows, the tail part of X being final already.
-std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, const VmLayout& lay, int h) {
-  std::vector<VmEntry> out;
+// Backward sweep of the head rows, the tail part of X being final already.  A head row couples to up to 42 tail columns;
+// walked by one lane those terms make the first round 17 records long in one wave while the others hold 1-2.  All of them
+// are available when the program starts (they need only the tail's X), so rows with more than `split_over` tail terms
+// first collect them as partial sums in temp cells (phase 0: one extra round, every part independent), and the row's own
+// entry (phase 1) starts from those.  Same terms, different association — as in the forward sweep (split_long_entries).
+// first_temp / temps_used: the temp cells taken (zeroed by the kernel before every solve).
+std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, const VmLayout& lay, int h, int split_over, int first_temp,
+                                            int* temps_used) {
+  std::vector<VmEntry> parts, rows;
+  int used = 0;
   for (int i = h - 1; i >= 0; i--) {
     VmEntry E;
     E.tgt = lay.xs(i);
-    E.phase = 0;
+    E.phase = 1;
     E.keep_order = false;
     E.mulr = lay.rdiag(i);
-    for (int p = m.diag[i] + 1; p < m.crow[i + 1]; p++) E.upd.push_back({p, lay.one(), lay.xs(m.icol[p])});
-    out.push_back(std::move(E));
+    std::vector<VmUpd> tail_terms;
+    for (int p = m.diag[i] + 1; p < m.crow[i + 1]; p++) {
+      const VmUpd u{p, lay.one(), lay.xs(m.icol[p])};
+      (m.icol[p] >= h ? tail_terms : E.upd).push_back(u);
+    }
+    if (split_over > 0 && (int)tail_terms.size() > split_over) {
+      const int n = (int)tail_terms.size();
+      int S = 2;
+      while (S * S < 2 * n) S += 2;            // part length ~ sqrt(2n), whole two-update records
+      std::vector<VmUpd> combine;
+      for (int lo = 0; lo < n; lo += S) {
+        if (first_temp + used >= lay.max_temps) throw std::logic_error("out of VM temp cells (raise MAX_TEMPS of the mechanism)");
+        VmEntry part;
+        part.tgt = lay.temp(first_temp + used++);
+        part.phase = 0;
+        part.keep_order = false;
+        part.upd.assign(tail_terms.begin() + lo, tail_terms.begin() + std::min(n, lo + S));
+        combine.push_back({part.tgt, lay.one(), lay.minus_one()});
+        parts.push_back(std::move(part));
+      }
+      E.upd.insert(E.upd.begin(), combine.begin(), combine.end());
+    } else {
+      E.upd.insert(E.upd.begin(), tail_terms.begin(), tail_terms.end());
+    }
+    rows.push_back(std::move(E));
   }
-  return out;
+  if (temps_used) *temps_used = used;
+  parts.insert(parts.end(), std::make_move_iterator(rows.begin()), std::make_move_iterator(rows.end()));
+  return parts;
 }
 
 TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay) {
@@ -706,10 +739,13 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   }
   S.solve = build_vm_program(solve_entries(m, lay), lay, nt);
   {
-    std::vector<VmEntry> fwd = solve_head_fwd_entries(m, lay, S.tail.h), bwd = solve_head_bwd_entries(m, lay, S.tail.h);
-    // forward sweep only: measured on MI355X the split pays there (tail rows carry up to 42 head-column terms); in the
-    // backward sweep the extra rounds it creates cost more than the shorter critical rows save
+    std::vector<VmEntry> fwd = solve_head_fwd_entries(m, lay, S.tail.h);
+    // forward: long head-column dot products of the tail rows cut into partial sums (tail rows carry up to 42 terms)
     S.n_temps = split_long_entries(fwd, lay, 6, 0);
+    static const int bwd_split = std::getenv("MISTRA_DIAG_BWD_SPLIT") ? std::atoi(std::getenv("MISTRA_DIAG_BWD_SPLIT")) : 8;
+    int bwd_temps = 0;
+    std::vector<VmEntry> bwd = solve_head_bwd_entries(m, lay, S.tail.h, bwd_split, S.n_temps, &bwd_temps);
+    S.n_temps += bwd_temps;
     S.solve_head_fwd = build_vm_program(std::move(fwd), lay, nt);
     S.solve_head_bwd = build_vm_program(std::move(bwd), lay, nt);
   }

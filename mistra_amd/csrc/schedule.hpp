@@ -183,7 +183,8 @@ ScaleProgram build_scale_program(const std::vector<std::pair<int, int>>& pairs, 
 int split_long_entries(std::vector<VmEntry>& entries, const VmLayout& lay, int threshold, int first_temp);
 std::vector<VmEntry> solve_entries(const MechTables& m, const VmLayout& lay);
 std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, const VmLayout& lay, int h);
-std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, const VmLayout& lay, int h);
+std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, const VmLayout& lay, int h, int split_over = 0, int first_temp = 0,
+                                            int* temps_used = nullptr);
 TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay);
 GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,
                                const std::vector<int>& slot_of_output, int nq, int nt, uint32_t src_base_bytes,
