@@ -741,8 +741,9 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   {
     std::vector<VmEntry> fwd = solve_head_fwd_entries(m, lay, S.tail.h);
     // forward: long head-column dot products of the tail rows cut into partial sums (tail rows carry up to 42 terms)
-    S.n_temps = split_long_entries(fwd, lay, 6, 0);
-    static const int bwd_split = std::getenv("MISTRA_DIAG_BWD_SPLIT") ? std::atoi(std::getenv("MISTRA_DIAG_BWD_SPLIT")) : 8;
+    static const int fwd_split = std::getenv("MISTRA_DIAG_FWD_SPLIT") ? std::atoi(std::getenv("MISTRA_DIAG_FWD_SPLIT")) : 6;
+    S.n_temps = split_long_entries(fwd, lay, fwd_split, 0);
+    static const int bwd_split = std::getenv("MISTRA_DIAG_BWD_SPLIT") ? std::atoi(std::getenv("MISTRA_DIAG_BWD_SPLIT")) : 4;
     int bwd_temps = 0;
     std::vector<VmEntry> bwd = solve_head_bwd_entries(m, lay, S.tail.h, bwd_split, S.n_temps, &bwd_temps);
     S.n_temps += bwd_temps;
