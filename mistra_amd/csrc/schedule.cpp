@@ -194,6 +194,37 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
       chunks.push_back({ru[i], i, j - i});
       i = j;
     }
+    // smooth: an entry that will not be final for many rounds (a tail-block cell of the LU collects ~100 updates from
+    // the head pivots) need not take each burst of updates in the round it becomes possible — one lane would walk ten
+    // records while the other waves wait at the barrier with one or two.  Bursts are paid out at a steady rate over the
+    // rounds up to the entry's last burst, the backlog carried forward: same updates, same order, same arithmetic, and
+    // nothing is final later than before (the entry's last chunk stays where it was).
+    {
+      static const int smooth = std::getenv("MISTRA_DIAG_SMOOTH") ? std::atoi(std::getenv("MISTRA_DIAG_SMOOTH")) : 1;
+      int last_burst = -1;
+      for (size_t k = 0; k + 1 < chunks.size(); k++)
+        if (chunks[k].count >= 2 * VM_UPD_PER_REC) last_burst = (int)k;
+      if (smooth && E.keep_order && last_burst >= 1) {
+        int total = 0;
+        for (int k = 0; k <= last_burst; k++) total += chunks[(size_t)k].count;
+        const int r0 = chunks[0].round, r1 = chunks[(size_t)last_burst].round;
+        int per = (total + (r1 - r0)) / (r1 - r0 + 1);               // updates per round over [r0, r1]
+        per = std::max(2 * VM_UPD_PER_REC, (per + VM_UPD_PER_REC - 1) / VM_UPD_PER_REC * VM_UPD_PER_REC);
+        std::vector<Chunk> out;
+        int next_first = 0, k = 0, avail = 0;                        // avail: updates ready but not yet paid out
+        for (int r = r0; r <= r1; r++) {
+          while (k <= last_burst && chunks[(size_t)k].round <= r) avail += chunks[(size_t)k++].count;
+          const int pay = r == r1 ? avail : std::min(avail, per);
+          if (pay > 0) {
+            out.push_back({r, next_first, pay});
+            next_first += pay;
+            avail -= pay;
+          }
+        }
+        for (size_t kk = (size_t)last_burst + 1; kk < chunks.size(); kk++) out.push_back(chunks[kk]);
+        chunks.swap(out);
+      }
+    }
     // merge forward: a chunk may run later, together with the entry's next chunk (same order, fewer headers).
     // The entry's last chunk decides when the entry is final, so it only grows up to one record.
     std::vector<Chunk> merged;
