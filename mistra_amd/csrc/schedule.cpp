@@ -272,6 +272,32 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
     auto nrec = [](const Item& it) { return std::max(1, (it.count + VM_UPD_PER_REC - 1) / VM_UPD_PER_REC); };
     std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return nrec(a) > nrec(b); });
     std::vector<int> lane = deal(items, entries, nt);
+    // The record that publishes a pivot's reciprocal carries an IEEE division (~150 cycles of dependent work) on top of its
+    // row; every other wave then waits for it at the barrier.  Where the waves of a round do not all have the same number
+    // of rows, that record goes to a wave with fewer: it swaps lanes with an equally long item there (no lane's row count
+    // changes), and the division runs while the fuller waves walk their extra row.
+    {
+      static const bool no_rcp_move = std::getenv("MISTRA_DIAG_NO_RCP_MOVE") != nullptr;     // A/B diagnostic
+      std::vector<int> lane_rows((size_t)nt, 0);
+      for (size_t k = 0; k < items.size(); k++) lane_rows[(size_t)lane[k]] += nrec(items[k]);
+      const int nw = nt / 64;
+      std::vector<int> wave_rows((size_t)nw, 0);
+      for (int t = 0; t < nt; t++) wave_rows[(size_t)(t / 64)] = std::max(wave_rows[(size_t)(t / 64)], lane_rows[(size_t)t]);
+      for (size_t k = 0; k < items.size() && !no_rcp_move; k++) {
+        const Item& it = items[k];
+        if (!(it.final && entries[(size_t)it.entry].rcp >= 0)) continue;
+        const int w_from = lane[k] / 64;
+        int w_to = w_from;
+        for (int w = 0; w < nw; w++)
+          if (wave_rows[(size_t)w] > 0 && wave_rows[(size_t)w] < wave_rows[(size_t)w_to]) w_to = w;
+        if (w_to == w_from) continue;
+        for (size_t j = 0; j < items.size(); j++)            // an equally long item in the emptier wave that publishes nothing
+          if (lane[j] / 64 == w_to && nrec(items[j]) == nrec(it) && !(items[j].final && entries[(size_t)items[j].entry].rcp >= 0)) {
+            std::swap(lane[k], lane[j]);
+            break;
+          }
+      }
+    }
     std::vector<std::vector<uint32_t>> prog((size_t)nt);     // VM_REC_WORDS words per record
     for (size_t k = 0; k < items.size(); k++) {
       const Item& it = items[k];
