@@ -101,6 +101,8 @@ struct MechState {
   GsBufs vdot, jvs;
   VmBufs lu, solve_head_fwd, solve_head_bwd;
   DevBuf<uint32_t> tail_fwd, tail_bwd, lu_scale;
+  DevBuf<uint16_t> dense_tile, dense_schur;
+  DevBuf<uint32_t> dense_rows;
   int lu_scale_slots = 0;
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
@@ -113,6 +115,7 @@ struct MechState {
     consts.release(); fun_fac.release(); jac_fac.release(); jvs_pos.release(); zero_pos.release(); diag_pos.release();
     vdot.release(); jvs.release(); lu.release(); solve_head_fwd.release(); solve_head_bwd.release();
     tail_fwd.release(); tail_bwd.release(); lu_scale.release();
+    dense_tile.release(); dense_schur.release(); dense_rows.release();
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release();
     if (one_dev) (void)hipFree(one_dev);
     if (one_host) (void)hipHostFree(one_host);
@@ -147,8 +150,8 @@ int default_nt(int mech) {
 }
 
 template <class MT>
-bool traits_match(const MechTables& t, int n_jnz, int tail_regs, bool scale_pass) {
-  return tail_regs == MT::TAIL_REGS && scale_pass == MT::SCALE_PASS && t.nvar == MT::NVAR && t.nfix == MT::NFIX && t.nreact == MT::NREACT && t.nnz == MT::NNZ && t.nb == MT::NB &&
+bool traits_match(const MechTables& t, int n_jnz, int tail_regs, bool scale_pass, const DenseTail& dense) {
+  return dense.nd == MT::DENSE_ND && dense.kb == MT::DENSE_KB && tail_regs == MT::TAIL_REGS && scale_pass == MT::SCALE_PASS && t.nvar == MT::NVAR && t.nfix == MT::NFIX && t.nreact == MT::NREACT && t.nnz == MT::NNZ && t.nb == MT::NB &&
          t.nconst == MT::NCONST && n_jnz == MT::NJNZ;
 }
 
@@ -167,13 +170,14 @@ int setup_mech(int mech) {
   KernelSchedule K;
   try {
     const int max_temps = mech == MISTRA_MECH_GAS ? GasTraits::MAX_TEMPS : mech == MISTRA_MECH_AER ? AerTraits::MAX_TEMPS : TotTraits::MAX_TEMPS;
-    K = build_kernel_schedule(S.tab, S.nt, ab_base, max_temps);
+    const DenseConfig dc = dense_config(S.tab);
+    K = build_kernel_schedule(S.tab, S.nt, ab_base, max_temps, dc.nd, dc.kb);
   } catch (const std::exception& ex) {
     return fail(std::string("schedule compiler: ") + ex.what());
   }
-  bool ok = mech == MISTRA_MECH_GAS   ? traits_match<GasTraits>(S.tab, K.n_jnz, K.tail.regs, K.lu_scale.nslots > 0)
-            : mech == MISTRA_MECH_AER ? traits_match<AerTraits>(S.tab, K.n_jnz, K.tail.regs, K.lu_scale.nslots > 0)
-                                      : traits_match<TotTraits>(S.tab, K.n_jnz, K.tail.regs, K.lu_scale.nslots > 0);
+  bool ok = mech == MISTRA_MECH_GAS   ? traits_match<GasTraits>(S.tab, K.n_jnz, K.tail.regs, K.lu_scale.nslots > 0, K.dense)
+            : mech == MISTRA_MECH_AER ? traits_match<AerTraits>(S.tab, K.n_jnz, K.tail.regs, K.lu_scale.nslots > 0, K.dense)
+                                      : traits_match<TotTraits>(S.tab, K.n_jnz, K.tail.regs, K.lu_scale.nslots > 0, K.dense);
   if (!ok) return fail(std::string(kMechName[mech]) + ": mechanism table does not match the compiled kernel sizes");
   S.text = std::string(kMechName[mech]) + ": " + describe(K);
   S.n_temps = K.n_temps;
@@ -191,6 +195,9 @@ int setup_mech(int mech) {
   HIP_TRY(S.tail_fwd.upload(K.tail.fwd));
   HIP_TRY(S.tail_bwd.upload(K.tail.bwd));
   HIP_TRY(S.lu_scale.upload(K.lu_scale.recs));
+  HIP_TRY(S.dense_tile.upload(K.dense.tile_cells));
+  HIP_TRY(S.dense_schur.upload(K.dense.schur_cells));
+  HIP_TRY(S.dense_rows.upload(K.dense.row_info));
   S.lu_scale_slots = K.lu_scale.nslots;
   S.ready = true;
   return 0;
@@ -218,6 +225,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
   a.solve_head_fwd = S.solve_head_fwd.dev(); a.solve_head_bwd = S.solve_head_bwd.dev();
   a.tail = TailDev{S.tail_fwd.p, S.tail_bwd.p};
   a.lu_scale = ScaleDev{S.lu_scale.p, S.lu_scale_slots, S.lu_scale_slots + VM_LOOKAHEAD_ROWS};
+  a.dense = DenseDev{S.dense_tile.p, S.dense_schur.p, S.dense_rows.p};
   return a;
 }
 
@@ -303,20 +311,20 @@ int mistra_chem_integrate(int mech, int ncell, const double* var_in, const doubl
   DevBuf<unsigned long long> prof;
   const bool profile = std::getenv("MISTRA_CHEM_PROFILE") != nullptr;
   if (profile) {
-    HIP_TRY(prof.reserve(nc * 12));
+    HIP_TRY(prof.reserve(nc * kProfSlots));
     a.prof = prof.p;
   }
   if (int rc = launch(mech, a, nullptr)) return rc;
   HIP_TRY(hipDeviceSynchronize());
   if (profile) {
-    std::vector<unsigned long long> h(nc * 12);
-    HIP_TRY(hipMemcpy(h.data(), prof.p, nc * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum[12] = {0};
+    std::vector<unsigned long long> h(nc * kProfSlots);
+    HIP_TRY(hipMemcpy(h.data(), prof.p, nc * kProfSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum[kProfSlots] = {0};
     for (size_t c = 0; c < nc; c++)
-      for (int k = 0; k < 12; k++) sum[k] += (double)h[c * 12 + k];
-    const char* names[12] = {"fun", "jac", "prepare", "lu", "solve(rest)", "norm", "other", "total", "solve_head_fwd", "solve_tail", "solve_head_bwd", "lu_scale"};
+      for (int k = 0; k < kProfSlots; k++) sum[k] += (double)h[c * kProfSlots + k];
+    const char* names[kProfSlots] = {"fun", "jac", "prepare", "lu", "solve(rest)", "norm", "other", "total", "solve_head_fwd", "solve_tail", "solve_head_bwd", "lu_scale", "lu_dense", "-", "-", "-"};
     std::fprintf(stderr, "[mistra_chem profile] %s, %zu cells, mean shader-clock ticks per cell:", kMechName[mech], nc);
-    for (int k = 0; k < 12; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
+    for (int k = 0; k < 13; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
     std::fprintf(stderr, "\n");
     prof.release();
   }

@@ -4,6 +4,8 @@
 
 namespace mistra {
 
+constexpr int kProfSlots = 16;   // phase counters of the profiling kernel variant
+
 struct VmDev {                 // LDS VM program in device memory (see schedule.hpp)
   const uint32_t* wave_base;   // [NW]         first record row of each wave's stream
   const uint16_t* blk_n;       // [nrounds*NW] record rows per (round, wave)
@@ -28,6 +30,12 @@ struct TailDev {               // tail chain of the triangular solves (schedule.
   const uint32_t* bwd;         // same, columns descending
 };
 
+struct DenseDev {              // dense tail block (schedule.hpp: DenseTail); null pointers where the mechanism has none
+  const uint16_t* tile_cells;  // [(w*64 + lane)*8 + q*4 + r]
+  const uint16_t* schur_cells; // [((k*8 + w)*64 + lane)*4 + {L, U(J0), U(J0+1), R}]
+  const uint32_t* row_info;    // [row][4]: first M cell of the row inside the block, absent-column mask lo / hi, 0
+};
+
 struct KernelArgs {
   // per-cell data, cell-major (one cell's VAR / FIX / RCONST contiguous, as COMMON /GDATA_x/ holds them)
   const double* var_in;        // [ncell][NVAR]
@@ -37,7 +45,7 @@ struct KernelArgs {
   int32_t* ierr;               // [ncell]         1 = success, <0 = ros_ErrorMsg code (gas.f:1474)
   int32_t* stats;              // [ncell][8]      Nfun,Njac,Nstp,Nacc,Nrej,Ndec,Nsol,Nsng  (COMMON /Statistics/)
   double* texit_hexit;         // [ncell][2] or null: what INTEGRATE_x leaves in TIN and STEPMIN
-  unsigned long long* prof;    // [ncell][12] or null: shader-clock cycles per phase (diagnostics, see capi.cpp)
+  unsigned long long* prof;    // [ncell][kProfSlots] or null: shader-clock cycles per phase (diagnostics, see capi.cpp)
   double tin, tout;
   int32_t ncell;
   int32_t n_temps;             // partial-sum cells the solve programs use (zeroed per solve)
@@ -52,6 +60,7 @@ struct KernelArgs {
   VmDev lu, solve_head_fwd, solve_head_bwd;
   ScaleDev lu_scale;
   TailDev tail;
+  DenseDev dense;
 };
 
 }  // namespace mistra

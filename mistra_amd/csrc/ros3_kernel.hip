@@ -307,9 +307,12 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
 }
 
-// FORWARD = false: the vector has been forward-swept already (stage 1: inside the LU program), only the backward chain runs
-template <int R, bool FORWARD, bool LOW>
+// FWD_FROM: first 64-row block of the forward chain.  0: the whole forward chain; R: none (the vector has been
+// forward-swept already — stage 1, inside the LU program); 1 of R = 2: only the columns of the dense tail block, whose
+// rows the LU program leaves without exactly those terms (schedule.cpp: lu_entries, dense_h)
+template <int R, int FWD_FROM, bool LOW>
 __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t xb, uint32_t rb, int lane) {
+  constexpr bool FORWARD = FWD_FROM < R;
   constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
   double x[R], rd[R];
 #pragma unroll
@@ -329,7 +332,7 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
   double opa[4][R], opb[4][R];
   // ---- forward: for every tail column q ascending:  x(i) -= L(i,q) * x(q)  for the tail rows i > q
   if constexpr (FORWARD) {
-    gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.fwd)) + lane;
+    gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.fwd)) + lane + FWD_FROM * 16 * 64;      // 16 groups of 4 columns per block
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     vm_ring_load<LOW, 0>(tp); vm_ring_load<LOW, 1>(tp + 64); vm_ring_load<LOW, 2>(tp + 128); vm_ring_load<LOW, 3>(tp + 192);
     vm_ring_load<LOW, 4>(tp + 256); vm_ring_load<LOW, 5>(tp + 320); vm_ring_load<LOW, 6>(tp + 384); vm_ring_load<LOW, 7>(tp + 448);
@@ -340,7 +343,7 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
       MISTRA_TAIL_OPERANDS(opa, first)
     }
 #pragma unroll
-    for (int rq = 0; rq < R; rq++) {
+    for (int rq = FWD_FROM; rq < R; rq++) {
       for (int gb = 0; gb < 16; gb += kRingSlots) {
 #define MISTRA_TAIL_FWD(K, CUR, NXT)                                                    \
         {                                                                               \
@@ -482,6 +485,229 @@ __device__ __attribute__((noinline)) void scale_run(const ScaleDev P, int wave, 
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // drain the look-ahead loads before returning
 }
 
+// ---- dense tail block (schedule.hpp: DenseTail): the last 64 rows and columns of Ghimj, factorised in registers.
+//      Tile (I, J) of the 4x4 grid of 16x16 tiles sits in wave 2I + (J>>1) as accumulator q = J&1 of
+//      v_mfma_f64_16x16x4_f64: lane l, element r = row (l>>4) + 4r, column l&15 (cdna_hip_programming.md §3, verified by
+//      tools/ubench).  Measured there: 64 cycles per MFMA and wave, the two waves of a SIMD overlapping fully; ~7 cycles per
+//      dependent f64 operation, 72 for the IEEE reciprocal, ~30 for a same-wave LDS write -> read (which is why the
+//      eliminating wave passes pivot rows lane to lane through LDS: v_readlane into an SGPR and back costs ~60).
+#ifdef MISTRA_DIAG_STAMPS      // diagnostic builds only (tools/diag_dense.sh): cycles of wave 0 per section of dense_lu, summed over calls
+__device__ unsigned long long g_dense_stamps[16];
+#define MISTRA_STAMP(var) const unsigned long long var = clock64();
+#define MISTRA_STAMP_ADD(slot, expr) if (threadIdx.x == 0) atomicAdd(&g_dense_stamps[slot], (unsigned long long)(expr));
+#else
+#define MISTRA_STAMP(var)
+#define MISTRA_STAMP_ADD(slot, expr)
+#endif
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f64x4 lds_f64x4;
+__device__ __forceinline__ f64x4 lds_ld4(uint32_t addr) { return *(const lds_f64x4*)(uintptr_t)addr; }
+__device__ __forceinline__ void lds_st4(uint32_t addr, f64x4 v) { *(lds_f64x4*)(uintptr_t)addr = v; }
+
+// One panel of four pivots, 4P .. 4P+3 of the block.
+//   1. the owners of block column K = P/4 and block row K put the panel's four columns / rows into LDS: PL[row][4], PU[col][4]
+//   2. wave 0 eliminates inside the panel, lane = row for PL and lane = column for PU, pivot by pivot in the order of
+//      KppDecomp_x (gas.f:6160-6171); stores the finished L(i,j), U'(j,c) = U(j,c)*R(j), U(j,j), R(j) to their Ghimj slots;
+//      leaves -L and U in the panel buffers with the rows / columns up to the panel's last pivot set to zero
+//   3. every tile that still has open rows and columns takes the rank-4 update with one MFMA
+// The two panel buffers alternate, so that step 1 of the next panel can start while slower waves are still in step 3.
+// P is a run-time value (the sixteen panels are ONE loop body: unrolled, the block's factorisation was 39 KB of
+// straight-line code executed once per decomposition, and instruction fetch, not arithmetic, set its pace); the tile
+// registers a panel needs are picked with selects on wave-uniform conditions.
+template <class MT, int NT>
+__device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const u32x4 ri, const int P, const int wave, const int lane) {
+  const int K = P >> 2, S = P & 3, J0P = 4 * P, K2 = (J0P + 4) >> 4;
+  constexpr uint32_t NNZ = MT::NNZ, NVAR = MT::NVAR, H = NVAR - 64;
+  constexpr uint32_t PB = 8u * (uint32_t)LdsLayout<MT, NT>::PANEL, BC = PB + 8192u;
+  const uint32_t PL = PB + (uint32_t)(P & 1) * 4096u, PU = PL + 2048u;
+  const int I = wave >> 1, J0 = 2 * (wave & 1);
+  const uint32_t lrow = (uint32_t)(lane >> 4), lcol = (uint32_t)(lane & 15);
+  MISTRA_STAMP(ta)
+  // (the two tiles are two named values and every choice among their registers is a select on a wave-uniform condition:
+  //  an array indexed by K or S would be put in scratch memory, a global-memory round trip per access)
+  if (I >= K && (wave & 1) == (K >> 1)) {
+    const bool odd = K & 1;
+    const double t0 = odd ? T1[0] : T0[0], t1 = odd ? T1[1] : T0[1], t2 = odd ? T1[2] : T0[2], t3 = odd ? T1[3] : T0[3];
+    if ((int)(lcol >> 2) == S) {
+      const uint32_t at = PL + 8u * ((16u * I + lrow) * 4u + (lcol & 3u));
+      lds_st(at, t0); lds_st(at + 128u, t1); lds_st(at + 256u, t2); lds_st(at + 384u, t3);
+    }
+  }
+  if (I == K) {
+    if (J0 >= K) lds_st(PU + 8u * ((16u * J0 + lcol) * 4u + lrow), S == 0 ? T0[0] : S == 1 ? T0[1] : S == 2 ? T0[2] : T0[3]);
+    if (J0 + 1 >= K) lds_st(PU + 8u * ((16u * (J0 + 1) + lcol) * 4u + lrow), S == 0 ? T1[0] : S == 1 ? T1[1] : S == 2 ? T1[2] : T1[3]);
+  }
+  lds_barrier();
+  MISTRA_STAMP(tb)
+  if (wave == 0) {
+    // A lone wave issues one instruction every 4-7 cycles whatever it is: this block is kept to the eliminations themselves.
+    // Per pivot: row 4P+k of U and column 4P+k of the still unscaled L go to LDS, every lane reads back the four entries
+    // that belong to the panel's pivots (two 16-byte reads each): the pivot, its row's entries above the later pivots'
+    // columns, its column's entries in the later pivots' rows.
+    f64x4 a = lds_ld4(PL + 32u * lane), b = lds_ld4(PU + 32u * lane);
+    f64x4 rcp;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      lds_st(BC + 8u * lane, b[k]);
+      lds_st(BC + 512u + 8u * lane, a[k]);
+      const f64x4 brow = lds_ld4(BC + 8u * J0P), acol = lds_ld4(BC + 512u + 8u * J0P);
+      rcp[k] = 1.0 / brow[k];
+      a[k] = a[k] * rcp[k];
+#pragma unroll
+      for (int k2 = k + 1; k2 < 4; k2++) {
+        const double lm = acol[k2] * rcp[k];
+        a[k2] = __builtin_fma(-a[k], brow[k2], a[k2]);
+        b[k2] = __builtin_fma(-lm, b[k], b[k2]);
+      }
+    }
+    lds_st4(PL + 32u * lane, a);      // L(H+lane, H+4P+k) for lane > 4P+k
+    lds_st4(PU + 32u * lane, b);      // U(H+4P+k, H+lane) for lane >= 4P+k
+    if (lane == 0) lds_st4(BC + 1024u, rcp);
+  }
+  MISTRA_STAMP(tc)
+  lds_barrier();
+  MISTRA_STAMP(td)
+  if (I >= K2) {      // (nothing is left open after the last panels: K2 = 4)
+    // rows and columns up to the panel's last pivot are finished: their operand is an exact zero, whatever the buffers hold there
+    const double aop = (int)(16u * I + lcol) >= J0P + 4 ? -lds_ld(PL + 8u * ((16u * I + lcol) * 4u + lrow)) : 0.0;
+    if (J0 >= K2) {
+      const double bop = (int)(16u * J0 + lcol) >= J0P + 4 ? lds_ld(PU + 8u * ((16u * J0 + lcol) * 4u + lrow)) : 0.0;
+      T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, T0, 0, 0, 0);
+    }
+    if (J0 + 1 >= K2) {
+      const double bop = (int)(16u * (J0 + 1) + lcol) >= J0P + 4 ? lds_ld(PU + 8u * ((16u * (J0 + 1) + lcol) * 4u + lrow)) : 0.0;
+      T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, T1, 0, 0, 0);
+    }
+  }
+  // The finished entries go to their Ghimj slots, for the solves: two otherwise idle waves do that while wave 0 is in the
+  // next panel (this panel's buffers are rewritten two panels on, behind two barriers that these waves take part in).
+  // A row's slots inside the block are contiguous, columns ascending: the slot of (row, c) is first(row) + c - (absent
+  // columns below c); ri = {first, absent mask lo, hi} of row H+lane, the pivot rows' values come over by v_readlane.
+  if (wave == 1 || wave == 2) {
+    const f64x4 rcp = lds_ld4(BC + 1024u);
+    const uint64_t my_mask = (uint64_t)ri.y | ((uint64_t)ri.z << 32), below_me = (1ull << lane) - 1ull;
+    if (wave == 1) {
+      const f64x4 a = lds_ld4(PL + 32u * lane);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int jp = J0P + k;
+        const uint32_t lcell = ri.x + (uint32_t)jp - (uint32_t)__builtin_popcountll(my_mask & ((1ull << jp) - 1ull));
+        if (lane > jp && !((my_mask >> jp) & 1ull)) lds_st(8u * lcell, a[k]);                              // L(H+lane, H+jp)
+      }
+      if (lane >= J0P && lane < J0P + 4) {                                                                  // R(k) = 1/U(k,k)
+        const int k = lane - J0P;
+        lds_st(8u * (NNZ + NVAR + 4u + H + (uint32_t)lane), k == 0 ? rcp[0] : k == 1 ? rcp[1] : k == 2 ? rcp[2] : rcp[3]);
+      }
+    } else {
+      const f64x4 b = lds_ld4(PU + 32u * lane);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int jp = J0P + k;
+        const uint32_t pfirst = (uint32_t)__builtin_amdgcn_readlane((int)ri.x, jp);
+        const uint64_t pmask = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ri.y, jp) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ri.z, jp) << 32);
+        const uint32_t ucell = pfirst + (uint32_t)lane - (uint32_t)__builtin_popcountll(pmask & below_me);
+        if (lane >= jp && !((pmask >> lane) & 1ull)) lds_st(8u * ucell, lane == jp ? b[k] : b[k] * rcp[k]);   // U'(H+jp, H+lane), the diagonal unscaled
+      }
+    }
+  }
+  MISTRA_STAMP(te)
+  MISTRA_STAMP_ADD(2, tb - ta) MISTRA_STAMP_ADD(3, tc - tb) MISTRA_STAMP_ADD(4, td - tc) MISTRA_STAMP_ADD(5, te - td) MISTRA_STAMP_ADD(8, 1)
+}
+
+// KppDecomp_x for a mechanism with the dense tail block: LU program (head pivots) -> scaling pass -> Schur steps ->
+// the block's own factorisation.  One function, so that the cell tables of the dense part are fetched BEFORE the LU
+// program runs: a global load issued here, in the middle of a cell's step, waits thousands of cycles behind the table
+// streams of every other workgroup (measured: 4.6k cycles in front of the first MFMA, ~0.9k per panel for a table row).
+template <class MT, int NT>
+__device__ __attribute__((noinline)) void lu_with_dense_tail(const uint32_t* lu_wave_base, const uint32_t* lu_recs, int lu_rounds,
+                                                             const uint32_t* scale_recs, int scale_slots, const uint16_t* tile_cells,
+                                                             const uint16_t* schur_cells, const uint32_t* row_info, int lane) {
+  // (scalar arguments: the three descriptor structs by value no longer fit the argument registers and would come over the stack)
+  const VmDev lu{lu_wave_base, nullptr, lu_recs, lu_rounds};
+  const ScaleDev scale{scale_recs, scale_slots, scale_slots + kRingSlots * 2};
+  const DenseDev D{tile_cells, schur_cells, row_info};
+  static_assert(NT == 512 && MT::DENSE_ND == 64, "eight waves, two 16x16 tiles each");
+  constexpr int KB = MT::DENSE_KB;
+  constexpr uint32_t ZERO = 8u * (uint32_t)(MT::NNZ + MT::NVAR);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifndef MISTRA_DIAG_LATE_LOADS
+  u32x2 sc[KB];
+#pragma unroll
+  for (int k = 0; k < KB; k++) sc[k] = G_(reinterpret_cast<const u32x2*>(D.schur_cells))[(k * 8 + wave) * 64 + lane];
+  const u32x4 tc = G_(reinterpret_cast<const u32x4*>(D.tile_cells))[wave * 64 + lane];
+  const u32x4 ri = G_(reinterpret_cast<const u32x4*>(D.row_info))[lane];
+#endif
+#ifdef MISTRA_DIAG_STAMPS
+  MISTRA_STAMP(tl0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MISTRA_STAMP(tl1)
+#endif
+#ifndef MISTRA_DIAG_CALLER_RUNS_VM
+  vm_run<NT>(lu, wave, lane);
+#endif
+#ifdef MISTRA_DIAG_STAMPS
+  MISTRA_STAMP(tl2)
+#endif
+#ifndef MISTRA_DIAG_CALLER_RUNS_VM
+  scale_run<NT, MT::RING_LOW>(scale, wave, lane);      // L(k,j) *= R(j); rows of the solves' tail chain: U(i,c) *= R(i)
+#endif
+#ifdef MISTRA_DIAG_LATE_LOADS
+  u32x2 sc[KB];
+#pragma unroll
+  for (int k = 0; k < KB; k++) sc[k] = G_(reinterpret_cast<const u32x2*>(D.schur_cells))[(k * 8 + wave) * 64 + lane];
+  const u32x4 tc = G_(reinterpret_cast<const u32x4*>(D.tile_cells))[wave * 64 + lane];
+  const u32x4 ri = G_(reinterpret_cast<const u32x4*>(D.row_info))[lane];
+#endif
+  lds_barrier();
+  MISTRA_STAMP(t0)
+#ifdef MISTRA_DIAG_STAMPS
+  MISTRA_STAMP_ADD(6, tl1 - tl0) MISTRA_STAMP_ADD(7, tl2 - tl1) MISTRA_STAMP_ADD(10, t0 - tl2)
+#endif
+  // ---- the block's slots as the LU program and the scaling pass leave them -> tiles
+  f64x4 T0, T1;
+  T0[0] = lds_ld(8u * (tc.x & 0xFFFFu)); T0[1] = lds_ld(8u * (tc.x >> 16)); T0[2] = lds_ld(8u * (tc.y & 0xFFFFu)); T0[3] = lds_ld(8u * (tc.y >> 16));
+  T1[0] = lds_ld(8u * (tc.z & 0xFFFFu)); T1[1] = lds_ld(8u * (tc.z >> 16)); T1[2] = lds_ld(8u * (tc.w & 0xFFFFu)); T1[3] = lds_ld(8u * (tc.w >> 16));
+  // ---- Schur steps: pivots jm .. h-1, four per MFMA, ascending
+#pragma unroll
+  for (int k = 0; k < KB; k++) {
+    const double wl = lds_ld(8u * (sc[k].x & 0xFFFFu));
+    const double u0 = lds_ld(8u * (sc[k].x >> 16)), u1 = lds_ld(8u * (sc[k].y & 0xFFFFu));
+    T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-wl, u0, T0, 0, 0, 0);
+    T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-wl, u1, T1, 0, 0, 0);
+  }
+  MISTRA_STAMP(t1)
+  lds_barrier();      // both waves of a block row have read the unscaled slots
+  {                   // L = W * R(j) for the solves; the two waves of a block row share the work (steps k even / k odd)
+    static_assert(KB % 2 == 0, "the two waves of a block row take every other Schur step");
+    const uint32_t pick = (wave & 1) ? 0xFFFFFFFFu : 0u;
+#define MISTRA_LSCALE_AT(K2_) (8u * ((((sc[K2_ + 1].x & pick) | (sc[K2_].x & ~pick))) & 0xFFFFu))
+#define MISTRA_LSCALE_R(K2_) (8u * ((((sc[K2_ + 1].y & pick) | (sc[K2_].y & ~pick))) >> 16))
+    double v0 = lds_ld(MISTRA_LSCALE_AT(0)) * lds_ld(MISTRA_LSCALE_R(0)), v1 = lds_ld(MISTRA_LSCALE_AT(2)) * lds_ld(MISTRA_LSCALE_R(2));
+    double v2 = lds_ld(MISTRA_LSCALE_AT(4)) * lds_ld(MISTRA_LSCALE_R(4)), v3 = lds_ld(MISTRA_LSCALE_AT(6)) * lds_ld(MISTRA_LSCALE_R(6));
+    double v4 = lds_ld(MISTRA_LSCALE_AT(8)) * lds_ld(MISTRA_LSCALE_R(8)), v5 = lds_ld(MISTRA_LSCALE_AT(10)) * lds_ld(MISTRA_LSCALE_R(10));
+    double v6 = lds_ld(MISTRA_LSCALE_AT(12)) * lds_ld(MISTRA_LSCALE_R(12));
+    static_assert(KB == 14, "seven pairs of Schur steps are written out here");
+    if (MISTRA_LSCALE_AT(0) != ZERO) lds_st(MISTRA_LSCALE_AT(0), v0);
+    if (MISTRA_LSCALE_AT(2) != ZERO) lds_st(MISTRA_LSCALE_AT(2), v1);
+    if (MISTRA_LSCALE_AT(4) != ZERO) lds_st(MISTRA_LSCALE_AT(4), v2);
+    if (MISTRA_LSCALE_AT(6) != ZERO) lds_st(MISTRA_LSCALE_AT(6), v3);
+    if (MISTRA_LSCALE_AT(8) != ZERO) lds_st(MISTRA_LSCALE_AT(8), v4);
+    if (MISTRA_LSCALE_AT(10) != ZERO) lds_st(MISTRA_LSCALE_AT(10), v5);
+    if (MISTRA_LSCALE_AT(12) != ZERO) lds_st(MISTRA_LSCALE_AT(12), v6);
+#undef MISTRA_LSCALE_AT
+#undef MISTRA_LSCALE_R
+  }
+  MISTRA_STAMP(t2)
+  MISTRA_STAMP_ADD(0, t1 - t0) MISTRA_STAMP_ADD(1, t2 - t1) MISTRA_STAMP_ADD(9, 1)
+  // ---- the block's own factorisation
+#ifndef MISTRA_DIAG_DENSE_PANELS      // timing diagnostics only (tools/diag_dense.sh): a library built with fewer panels computes garbage
+#define MISTRA_DIAG_DENSE_PANELS 16
+#endif
+#pragma unroll 1
+  for (int P = 0; P < MISTRA_DIAG_DENSE_PANELS; P++) dense_panel<MT, NT>(T0, T1, ri, P, wave, lane);
+}
+
 }  // namespace
 
 template <class MT, int NT, bool PROF>
@@ -545,8 +771,8 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   }
 
   // optional phase timing (diagnostics only): cycles of wave 0 between phase boundaries, summed per cell
-  constexpr bool profiling = PROF;       // a compile-time variant: twelve 64-bit counters are not carried by the product kernel
-  unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = profiling ? clock64() : 0ull;
+  constexpr bool profiling = PROF;       // a compile-time variant: sixteen 64-bit counters are not carried by the product kernel
+  unsigned long long pc[kProfSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = profiling ? clock64() : 0ull;
   const unsigned long long t_begin = t_last;
   auto lap = [&](int slot) {
     if constexpr (profiling) {
@@ -660,11 +886,11 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       vm_run<NT>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
       lap(8);
       if (wave == 0)                                                                         // tail chain, one wave
-        tail_solve<MT::TAIL_REGS, true, MT::RING_LOW>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
+        tail_solve<MT::TAIL_REGS, 0, MT::RING_LOW>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
     } else {
       lap(6);
-      if (wave == 0)
-        tail_solve<MT::TAIL_REGS, false, MT::RING_LOW>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
+      if (wave == 0)      // with the dense tail block the forward chain still has the block's own columns to do
+        tail_solve<MT::TAIL_REGS, MT::DENSE_ND ? MT::TAIL_REGS - 1 : MT::TAIL_REGS, MT::RING_LOW>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
     }
     lds_barrier();
     lap(9);
@@ -751,12 +977,26 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
             if (nconsecutive <= 5) H = H * 0.5;
             else { ierr = -8; break; }
           } else {
-            vm_run<NT>(a.lu, wave, lane);
-            if constexpr (MT::SCALE_PASS) {      // else the scaling is the LU program's last round
+            if constexpr (MT::DENSE_ND > 0) {
+              static_assert(MT::SCALE_PASS, "the Schur steps read what the scaling pass leaves");
+#ifdef MISTRA_DIAG_CALLER_RUNS_VM
+              vm_run<NT>(a.lu, wave, lane);
               lap(3);
-              scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);      // L(k,j) *= R(j); tail block: U(i,c) *= R(i)
+              scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);
               lds_barrier();
               lap(11);
+#endif
+              lu_with_dense_tail<MT, NT>(a.lu.wave_base, a.lu.recs, a.lu.nrounds, a.lu_scale.recs, a.lu_scale.nslots, a.dense.tile_cells,
+                                         a.dense.schur_cells, a.dense.row_info, lane);
+              lds_barrier();
+            } else {
+              vm_run<NT>(a.lu, wave, lane);
+              if constexpr (MT::SCALE_PASS) {      // else the scaling is the LU program's last round
+                lap(3);
+                scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);      // L(k,j) *= R(j); tail block: U(i,c) *= R(i)
+                lds_barrier();
+                lap(11);
+              }
             }
             lap(3);
           }
@@ -839,7 +1079,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     if constexpr (profiling) {
       lap(6);
       pc[7] = clock64() - t_begin;
-      for (int k = 0; k < 12; k++) GM_(a.prof)[(size_t)cell * 12 + k] = pc[k];
+      for (int k = 0; k < kProfSlots; k++) GM_(a.prof)[(size_t)cell * kProfSlots + k] = pc[k];
     }
     if (a.texit_hexit) {
       GM_(a.texit_hexit)[(size_t)cell * 2] = T;
@@ -867,6 +1107,17 @@ hipError_t launch_ros3(const KernelArgs& a, hipStream_t stream) {
   else hipLaunchKernelGGL(kern, dim3((unsigned)a.ncell), dim3(NT), lds_bytes, stream, a);
   return hipGetLastError();
 }
+
+#ifdef MISTRA_DIAG_STAMPS
+extern "C" int mistra_diag_dense_stamps(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dense_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_dense_stamps), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 
 template hipError_t launch_ros3<GasTraits, 128>(const KernelArgs&, hipStream_t);
 template hipError_t launch_ros3<AerTraits, 512>(const KernelArgs&, hipStream_t);

@@ -3,7 +3,8 @@
 // NB / NJNZ are counted from Jac_SP_x (number of B products / of JVS slots that are not `= 0`), NCONST from the
 // factor literals (1.0 padding + the 2 of squared reactants); TAIL_REGS*64 = rows of the solve's tail chain
 // (schedule.cpp: build_tail_solve); MAX_TEMPS = partial-sum cells reserved for the head sweeps of the solves
-// (schedule.cpp: split_long_entries).  The host checks the loaded table against these.
+// (schedule.cpp: split_long_entries); DENSE_ND / DENSE_KB = rows of the dense tail block held in MFMA accumulator tiles and
+// its rank-4 Schur steps (schedule.hpp: DenseTail, dense_config).  The host checks the loaded table against these.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -11,9 +12,9 @@
 
 namespace mistra {
 
-struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 16, WAVES_PER_SIMD = 4; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
-struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2, MAX_TEMPS = 192, WAVES_PER_SIMD = 4; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
-struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2, MAX_TEMPS = 768, WAVES_PER_SIMD = 2; static constexpr bool RING_LOW = false, SCALE_PASS = true; };
+struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 16, WAVES_PER_SIMD = 4, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
+struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2, MAX_TEMPS = 192, WAVES_PER_SIMD = 4, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
+struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2, MAX_TEMPS = 768, WAVES_PER_SIMD = 2, DENSE_ND = 64, DENSE_KB = 14; static constexpr bool RING_LOW = false, SCALE_PASS = true; };
 
 constexpr int round_up2(int x) { return (x + 1) & ~1; }
 constexpr int max_i(int a, int b) { return a > b ? a : b; }
@@ -28,6 +29,11 @@ struct LdsLayout {
   static constexpr int RED = AB + round_up2(AB_TRASH + 1);                             // per-wave partial sums
   static constexpr int FLAGS = RED + 32;
   static constexpr int TOTAL = FLAGS + 2;
+  // dense_lu's panel buffers live in the A/B product array, which nothing reads between Jac_SP and the next Fun:
+  // two buffers of [64][4] panel columns + [64][4] panel rows, two 64-entry broadcast rows of the eliminating wave
+  static constexpr int PANEL = AB;
+  static constexpr int PANEL_CELLS = 2 * 2 * 64 * 4 + 2 * 64 + 4;      // (+ the panel's four pivot reciprocals)
+  static_assert(MT::DENSE_ND == 0 || PANEL_CELLS <= AB_TRASH, "panel buffers must fit the product array");
   static_assert(TOTAL * 8 <= 160 * 1024, "cell state does not fit the 160 KiB LDS of a gfx950 CU");
   static_assert(NT % 64 == 0 && NT <= 1024 && NT / 64 <= 32, "workgroup size");
 };

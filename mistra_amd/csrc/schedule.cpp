@@ -402,8 +402,9 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
 // scales the strictly-upper entries of the tail block by their ROW's pivot reciprocal, U'(i,c) = U(i,c)*R(i) for
 // i >= tail_h: the tail chain's backward sweep then runs on a unit-diagonal triangle (schedule.hpp: TailSolve).
 std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool with_rhs, int tail_h,
-                                std::vector<std::pair<int, int>>* scale_pairs) {
+                                std::vector<std::pair<int, int>>* scale_pairs, int dense_h, int dense_jm) {
   const int n = m.nvar;
+  const int dh = dense_h >= 0 ? dense_h : n, djm = dense_h >= 0 ? dense_jm : n;     // dense block [dh, n), Schur pivots [djm, dh)
   std::vector<VmEntry> out((size_t)m.nnz);
   std::vector<int> where((size_t)n, -1);    // column -> slot in the current row
   for (int k = 0; k < n; k++) {
@@ -412,13 +413,14 @@ std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool w
       VmEntry& E = out[(size_t)p];
       E.tgt = p;
       E.phase = 0;
-      if (m.icol[p] == k) E.rcp = lay.rdiag(k);
+      if (m.icol[p] == k && k < dh) E.rcp = lay.rdiag(k);      // the dense block's pivots are published by dense_lu
     }
     for (int pl = m.crow[k]; pl < m.diag[k]; pl++) {
       int j = m.icol[pl];
       for (int pu = m.diag[j] + 1; pu < m.crow[j + 1]; pu++) {
         int t = where[(size_t)m.icol[pu]];
         if (t < 0) throw std::logic_error("LU pattern is not closed under fill-in");
+        if (k >= dh && m.icol[pu] >= dh && j >= djm) continue;   // a slot of the dense block, a pivot dense_lu applies
         out[(size_t)t].upd.push_back({pl, lay.rdiag(j), pu});
       }
     }
@@ -430,8 +432,9 @@ std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool w
       VmEntry E;
       E.tgt = lay.xs(i);
       E.phase = 0;
-      for (int p = m.crow[i]; p < m.diag[i]; p++) E.upd.push_back({p, lay.rdiag(m.icol[p]), lay.xs(m.icol[p])});
-      out.push_back(std::move(E));
+      for (int p = m.crow[i]; p < m.diag[i]; p++)
+        if (m.icol[p] < dh) E.upd.push_back({p, lay.rdiag(m.icol[p]), lay.xs(m.icol[p])});      // columns >= dh: the tail chain
+      if (!E.upd.empty()) out.push_back(std::move(E));
     }
   auto scale = [&](int tgt, int aux) {
     if (scale_pairs) {
@@ -445,9 +448,10 @@ std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool w
     out.push_back(std::move(E));
   };
   for (int k = 0; k < n; k++)
-    for (int p = m.crow[k]; p < m.diag[k]; p++) scale(p, lay.rdiag(m.icol[p]));
+    for (int p = m.crow[k]; p < m.diag[k]; p++)
+      if (m.icol[p] < dh && !(k >= dh && m.icol[p] >= djm)) scale(p, lay.rdiag(m.icol[p]));     // (dense_lu's Schur steps scale theirs)
   if (tail_h >= 0)
-    for (int k = tail_h; k < n; k++)
+    for (int k = tail_h; k < dh; k++)                        // (rows of the dense block: dense_lu stores them scaled)
       for (int p = m.diag[k] + 1; p < m.crow[k + 1]; p++) scale(p, lay.rdiag(k));
   return out;
 }
@@ -578,10 +582,10 @@ std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, const VmLayout&
   return parts;
 }
 
-TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay) {
+TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay, int regs) {
   TailSolve T;
   const int n = m.nvar, zero_slot = lay.zero();
-  T.regs = n > 128 + 64 ? 2 : 1;           // 128-row tail where the mechanism is big enough to leave a head
+  T.regs = regs > 0 ? regs : n > 128 + 64 ? 2 : 1;           // 128-row tail where the mechanism is big enough to leave a head
   T.m = 64 * T.regs;
   if (T.m > n) throw std::invalid_argument("mechanism smaller than one wave");
   T.h = n - T.m;
@@ -605,6 +609,68 @@ TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay) {
     }
   }
   return T;
+}
+
+// Cell tables of the dense tail block (schedule.hpp: DenseTail).  Tile element (l, r) of tile (I, J): row 16I + (l>>4) + 4r,
+// column 16J + (l&15) of D — the C/D layout of v_mfma_f64_16x16x4_f64; A operand lane l: row l&15, k = l>>4; B operand
+// lane l: k = l>>4, column l&15.
+DenseTail build_dense_tail(const MechTables& m, const VmLayout& lay, int nd, int kb) {
+  DenseTail D;
+  const int n = m.nvar;
+  if (nd != 64) throw std::invalid_argument("the dense tail block is 64 rows (8 waves x 2 tiles of 16x16)");
+  D.nd = nd;
+  D.h = n - nd;
+  D.kb = kb;
+  D.jm = D.h - 4 * kb;
+  if (D.jm < 0) throw std::invalid_argument("more Schur steps than pivots");
+  if (lay.size() > 0xFFFF) throw std::invalid_argument("dense tail tables need 16-bit M cells");
+  auto cell = [&](int row, int col) -> int {        // Ghimj slot of (row, col), -1 if not in the pattern
+    for (int p = m.crow[row]; p < m.crow[row + 1]; p++)
+      if (m.icol[p] == col) return p;
+    return -1;
+  };
+  const uint16_t zero = (uint16_t)lay.zero();
+  D.tile_cells.assign((size_t)8 * 2 * 4 * 64, zero);
+  for (int w = 0; w < 8; w++)
+    for (int q = 0; q < 2; q++)
+      for (int r = 0; r < 4; r++)
+        for (int l = 0; l < 64; l++) {
+          const int I = w >> 1, J = 2 * (w & 1) + q;
+          const int c = cell(D.h + 16 * I + (l >> 4) + 4 * r, D.h + 16 * J + (l & 15));
+          if (c >= 0) D.tile_cells[((size_t)w * 64 + l) * 8 + q * 4 + r] = (uint16_t)c;
+        }
+  D.schur_cells.assign((size_t)std::max(kb, 1) * 8 * 64 * 4, zero);
+  for (int k = 0; k < kb; k++)
+    for (int w = 0; w < 8; w++)
+      for (int l = 0; l < 64; l++) {
+        const int I = w >> 1, j = D.jm + 4 * k + (l >> 4);
+        uint16_t* out = &D.schur_cells[(((size_t)k * 8 + w) * 64 + l) * 4];
+        int c = cell(D.h + 16 * I + (l & 15), j);
+        if (c >= 0) out[0] = (uint16_t)c;
+        for (int q = 0; q < 2; q++) {
+          c = cell(j, D.h + 16 * (2 * (w & 1) + q) + (l & 15));
+          if (c >= 0) out[1 + q] = (uint16_t)c;
+        }
+        out[3] = (uint16_t)lay.rdiag(j);
+      }
+  // the finished factors go back to their slots: the block's part of a CSR row is contiguous, columns ascending
+  D.row_info.assign((size_t)nd * 4, 0u);
+  for (int i = 0; i < nd; i++) {
+    int first = -1, seen = 0;
+    uint64_t mask = 0;
+    for (int c = 0; c < nd; c++) {
+      const int p = cell(D.h + i, D.h + c);
+      if (p < 0) { mask |= 1ull << c; continue; }
+      if (first < 0) first = p;
+      if (p != first + seen) throw std::logic_error("dense tail: a row's slots inside the block are not contiguous");
+      seen++;
+    }
+    if (first < 0) throw std::logic_error("dense tail: empty row");
+    D.row_info[(size_t)i * 4] = (uint32_t)first;
+    D.row_info[(size_t)i * 4 + 1] = (uint32_t)mask;
+    D.row_info[(size_t)i * 4 + 2] = (uint32_t)(mask >> 32);
+  }
+  return D;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -699,7 +765,7 @@ ScaleProgram build_scale_program(const std::vector<std::pair<int, int>>& pairs, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes, int max_temps) {
+KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes, int max_temps, int dense_nd, int dense_kb) {
   if (nt % 64 != 0 || nt <= 0 || nt > 1024) throw std::invalid_argument("nt must be a multiple of 64 in (0,1024]");
   if (VmLayout{m.nnz, m.nvar, max_temps}.size() * 8 > 160 * 1024) throw std::invalid_argument("mechanism too large for the LDS VM");
   if (m.nx() > 0xFFFF || m.nb >= 0xFFFF || m.nreact > 0xFFFF) throw std::invalid_argument("mechanism too large");
@@ -780,14 +846,21 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   S.diag_pos.assign((size_t)S.spt * nt, POS_NONE);
   for (int s = 0; s < m.nvar; s++) S.diag_pos[(size_t)s] = (uint16_t)m.diag[(size_t)s];
 
-  S.tail = build_tail_solve(m, lay);
+  if (dense_nd > 0) {
+    if (nt < 512) throw std::invalid_argument("the dense tail block needs eight waves");
+    S.dense = build_dense_tail(m, lay, dense_nd, dense_kb);
+  }
+  S.tail = build_tail_solve(m, lay);      // (the tail chain of the solves may reach further up than the dense block)
+  // the Schur steps multiply UNSCALED L slots with ROW-SCALED U slots: their pivots must be rows of the solves' tail chain
+  if (dense_nd > 0 && S.tail.h > S.dense.jm) throw std::logic_error("the solves' tail chain must cover the dense block and its Schur pivots");
+  const int dh = dense_nd > 0 ? S.dense.h : -1, djm = dense_nd > 0 ? S.dense.jm : -1;
   {
     // the scaling gets its own pass where there is enough of it (tot: 22 cells per thread, +2.7 %); for the small
     // mechanisms the extra pass's start-up costs more than the VM rows it replaces (gas -1.8 %, aer -0.6 %, measured)
     std::vector<std::pair<int, int>> pairs;
-    (void)lu_entries(m, lay, true, S.tail.h, &pairs);
-    if ((int)pairs.size() >= 16 * nt) {
-      S.lu = build_vm_program(lu_entries(m, lay, true, S.tail.h, &pairs), lay, nt);
+    (void)lu_entries(m, lay, true, S.tail.h, &pairs, dh, djm);
+    if ((int)pairs.size() >= 16 * nt || dense_nd > 0) {     // (dense_lu reads scaled multipliers: always after a scaling pass)
+      S.lu = build_vm_program(lu_entries(m, lay, true, S.tail.h, &pairs, dh, djm), lay, nt);
       pairs.resize(pairs.size() / 2);         // lu_entries appended the same list a second time
       S.lu_scale = build_scale_program(pairs, lay, nt);
     } else {
@@ -814,12 +887,12 @@ std::string describe(const KernelSchedule& s) {
   char buf[2048];
   std::snprintf(buf, sizeof buf,
                 "nt=%d spt=%d rpt=%d jpt=%d zpt=%d | vdot: %lld terms, %lld wave-rows | jvs: %lld terms, %lld wave-rows | "
-                "LU: %d rounds, %lld updates in %lld items / %lld records, %lld wave-rows, critical %lld, %lld LDS cycles | "
+                "LU: %d rounds, %lld updates in %lld items / %lld records, %lld wave-rows, critical %lld, %lld LDS cycles; dense tail block %d rows, %d rank-4 Schur steps | "
                 "solve: tail %d rows in registers of one wave; head fwd %d rounds / %lld rows critical, head bwd %d rounds / %lld rows "
                 "critical, %d partial-sum cells (whole solve as one VM program: %d rounds, %lld updates, %lld records, critical %lld)",
                 s.nt, s.spt, s.rpt, s.jpt, s.zpt, (long long)s.vdot.n_terms, (long long)s.vdot.wave_rows,
                 (long long)s.jvs.n_terms, (long long)s.jvs.wave_rows, s.lu.nrounds, (long long)s.lu.n_updates,
-                (long long)s.lu.n_items, (long long)s.lu.n_records, (long long)s.lu.wave_rows, (long long)s.lu.crit_rows, (long long)s.lu.lds_cycles,
+                (long long)s.lu.n_items, (long long)s.lu.n_records, (long long)s.lu.wave_rows, (long long)s.lu.crit_rows, (long long)s.lu.lds_cycles, s.dense.nd, s.dense.kb,
                 s.tail.m, s.solve_head_fwd.nrounds, (long long)s.solve_head_fwd.crit_rows, s.solve_head_bwd.nrounds,
                 (long long)s.solve_head_bwd.crit_rows, s.n_temps, s.solve.nrounds, (long long)s.solve.n_updates, (long long)s.solve.n_records,
                 (long long)s.solve.crit_rows);

@@ -150,6 +150,41 @@ struct ScaleProgram {
   int64_t n_pairs = 0;
 };
 
+// Dense tail block.  The last nd rows and columns of the LU pattern (the gas-phase species every aqueous bin couples to)
+// are a completely filled square once the fill-in is there (tot: 4089 of 4096 slots): ~40 % of KppDecomp_x's updates land
+// in it from the pivots just before it, another ~40 % are its own factorisation.  The kernel holds that block D in
+// REGISTERS, as 16x16 accumulator tiles of v_mfma_f64_16x16x4_f64 (lane l, register r of a tile: row (l>>4)+4r, column
+// l&15), two tiles per wave on eight waves (wave w: block row w>>1, block columns 2(w&1), 2(w&1)+1), and works on it in
+// rank-4 steps (ros3_kernel.hip: dense_lu):
+//   * pivots [jm, h), four at a time ("Schur steps"): D -= W(:,j..j+3) * U'(j..j+3,:), operands gathered from their Ghimj
+//     slots by the cell tables below: W the still unscaled L slots (the step also leaves L = W*R(j) in them), U' the
+//     row-scaled U slots the scaling pass has left in the rows of the solves' tail chain (TailSolve).  Pivots below jm
+//     reach D through the LU program as before (they touch few slots).
+//   * D's own factorisation in panels of four pivots: the tile owners publish the panel's four columns and rows in LDS,
+//     ONE wave eliminates inside the panel (lane = row for the L part, lane = column for the U part), everybody applies
+//     the rank-4 update with one MFMA per tile.
+// Every slot of D still receives its updates in ascending pivot order, as KppDecomp_x applies them (gas.f:6160-6171);
+// inside an MFMA the four products are accumulated with fused multiply-adds.  Slots that are not in the sparsity pattern
+// read as zero and stay zero.  The finished factors go back to their Ghimj slots in the form the solves expect:
+// L(i,j) multipliers, U'(i,c) = U(i,c)*R(i) row-scaled, R(i) = 1/U(i,i) published (schedule.hpp: TailSolve).
+struct DenseTail {
+  int nd = 0, h = 0, jm = 0, kb = 0;            // D = rows/columns [h, h+nd), nd = 64; kb = (h - jm)/4 Schur steps
+  std::vector<uint16_t> tile_cells;             // [(w*64 + lane)*8 + q*4 + r]  M cell of the tile element, the 0.0 cell if absent
+  std::vector<uint16_t> schur_cells;            // [(k*8 + w)*64 + lane][4]  M cells of: L(h+16I+(l&15), jm+4k+(l>>4)),
+                                                //   U(jm+4k+(l>>4), h+16J+(l&15)) for J = 2(w&1), 2(w&1)+1, R(jm+4k+(l>>4))
+  std::vector<uint32_t> row_info;               // [row 0..63][4]  where the finished factors go: {M cell of the row's first slot inside the
+                                                //   block, absent-columns mask lo, hi, 0}; the slot of (row, c) is first + c - popcount(mask below c)
+  int cell(int row, int c) const {              // (host mirror of the kernel's arithmetic) M cell of D(row, c), -1 if absent
+    const uint64_t mask = (uint64_t)row_info[(size_t)row * 4 + 1] | ((uint64_t)row_info[(size_t)row * 4 + 2] << 32);
+    if ((mask >> c) & 1) return -1;
+    return (int)row_info[(size_t)row * 4] + c - __builtin_popcountll(mask & ((1ull << c) - 1));
+  }
+};
+
+// which mechanisms the product runs with the dense tail block (the kernel's traits, ros3_kernel.hpp, must agree)
+struct DenseConfig { int nd, kb; };
+inline DenseConfig dense_config(const MechTables& m) { return m.nvar == 417 ? DenseConfig{64, 14} : DenseConfig{0, 0}; }
+
 struct KernelSchedule {
   int nt = 0, nw = 0;
   int spt = 0;   // species per thread          s = q*nt + t
@@ -172,25 +207,31 @@ struct KernelSchedule {
   VmProgram solve_head_fwd, solve_head_bwd;     // head rows (+ head-column part of tail rows) around the tail chain
   int n_temps = 0;                              // temp cells the two head programs use (zeroed by the kernel per solve)
   TailSolve tail;
+  DenseTail dense;                              // nd = 0: the mechanism runs without the dense tail block
 };
 
 VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 2);
 // with_rhs: also forward-sweep the vector held in XS while factorising (rows of an appended right-hand-side column)
 // scale_pairs: where to put the (tgt, aux) pairs of the final scaling; nullptr = keep them as a last phase of VM entries
+// dense_h >= 0: rows/columns [dense_h, n) are the dense tail block (DenseTail): the program leaves out the updates of
+// its slots by pivots >= dense_jm, its pivots' reciprocals and every scaling that involves them.
 std::vector<VmEntry> lu_entries(const MechTables& m, const VmLayout& lay, bool with_rhs, int tail_h = -1,
-                                std::vector<std::pair<int, int>>* scale_pairs = nullptr);
+                                std::vector<std::pair<int, int>>* scale_pairs = nullptr, int dense_h = -1, int dense_jm = -1);
+DenseTail build_dense_tail(const MechTables& m, const VmLayout& lay, int nd, int kb);
 ScaleProgram build_scale_program(const std::vector<std::pair<int, int>>& pairs, const VmLayout& lay, int nt);
 int split_long_entries(std::vector<VmEntry>& entries, const VmLayout& lay, int threshold, int first_temp);
 std::vector<VmEntry> solve_entries(const MechTables& m, const VmLayout& lay);
 std::vector<VmEntry> solve_head_fwd_entries(const MechTables& m, const VmLayout& lay, int h);
 std::vector<VmEntry> solve_head_bwd_entries(const MechTables& m, const VmLayout& lay, int h, int split_over = 0, int first_temp = 0,
                                             int* temps_used = nullptr);
-TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay);
+TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay, int regs = 0);      // regs = 0: by mechanism size
 GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, double>>>& outputs,
                                const std::vector<int>& slot_of_output, int nq, int nt, uint32_t src_base_bytes,
                                uint32_t zero_cell_bytes);
 // ab_base_bytes: LDS byte address of the A/B product array the gather-sum tables point into (ros3_kernel.hpp: LdsLayout)
-KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes, int max_temps);
+// dense_nd = 64 with dense_kb Schur steps: the mechanism's last 64 rows are factorised as a dense block (DenseTail)
+KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes, int max_temps, int dense_nd = 0,
+                                     int dense_kb = 0);
 std::string describe(const KernelSchedule& s);
 
 }  // namespace mistra

@@ -129,10 +129,15 @@ static void run_gsum(const GsumProgram& P, const std::vector<double>& src, uint3
 
 // The kernel's solve: head forward (VM) -> tail chain forward/backward (one wave, registers) -> head backward (VM).
 // The tail loops below mirror tail_solve of ros3_kernel.hip statement by statement.
-static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, const VmLayout& lay, bool forward = true) {
+// head_forward = false: the vector went through the LU program (stage 1).  With the dense tail block only its head-column
+// terms are in by then, so the tail chain still runs its forward half (ros3_kernel.hip: solve, swept).
+static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, const VmLayout& lay, bool head_forward = true) {
   const int nnz = lay.nnz;
-  int rc = forward ? run_vm(s.solve_head_fwd, M, lay.trash()) : 0;
+  int rc = head_forward ? run_vm(s.solve_head_fwd, M, lay.trash()) : 0;
   if (rc) return rc;
+  // columns the tail chain's forward half starts from: all of them; none; or, after the LU program of a mechanism with the
+  // dense tail block, the block's own columns (its rows lack exactly those terms)
+  const int q_first = head_forward ? 0 : s.dense.nd > 0 ? s.dense.h - s.tail.h : s.tail.m;
   const TailSolve& T = s.tail;
   const int R = T.regs, m = T.m;
   std::vector<double> x((size_t)R * 64), rd((size_t)R * 64);
@@ -144,7 +149,7 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
     uint32_t w = tab[((size_t)(pos / 4) * 64 + lane) * 4 + pos % 4];
     return (int)(r == 0 ? (w & 0xFFFFu) : (w >> 16));
   };
-  for (int q = 0; forward && q < m; q++) {
+  for (int q = q_first; q < m; q++) {
     const int rq = q / 64, lq = q % 64;
     const double xq = x[(size_t)rq * 64 + lq];
     for (int r = rq; r < R; r++)
@@ -168,6 +173,78 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
   return run_vm(s.solve_head_bwd, M, lay.trash());
 }
 
+// The dense tail block (schedule.hpp: DenseTail) as dense_lu of ros3_kernel.hip works on it: same tables, same tile and
+// operand layouts, same order of operations (an MFMA = four fused multiply-adds in k order per element).
+static void run_dense(const DenseTail& D, std::vector<double>& M, const VmLayout& lay) {
+  static double T[8][2][4][64];
+  for (int w = 0; w < 8; w++)
+    for (int q = 0; q < 2; q++)
+      for (int r = 0; r < 4; r++)
+        for (int l = 0; l < 64; l++) T[w][q][r][l] = M[D.tile_cells[((size_t)w * 64 + l) * 8 + q * 4 + r]];
+  auto sc = [&](int k, int w, int l, int which) { return (size_t)D.schur_cells[(((size_t)k * 8 + w) * 64 + l) * 4 + which]; };
+  for (int k = 0; k < D.kb; k++) {
+    for (int w = 0; w < 8; w++)
+      for (int q = 0; q < 2; q++)
+        for (int r = 0; r < 4; r++)
+          for (int l = 0; l < 64; l++) {
+            const int row = (l >> 4) + 4 * r, col = l & 15;
+            double acc = T[w][q][r][l];
+            for (int kk = 0; kk < 4; kk++) acc = std::fma(-M[sc(k, w, row + 16 * kk, 0)], M[sc(k, w, 16 * kk + col, 1 + q)], acc);
+            T[w][q][r][l] = acc;
+          }
+    for (int w = 0; w < 8; w += 2)          // the even wave of a block row leaves the multipliers L = W*R in the slots
+      for (int l = 0; l < 64; l++)
+        if (sc(k, w, l, 0) != (size_t)lay.zero()) M[sc(k, w, l, 0)] = M[sc(k, w, l, 0)] * M[sc(k, w, l, 3)];
+  }
+  static double PL[64][4], PU[64][4];
+  for (int p = 0; p < D.nd / 4; p++) {
+    const int K = p >> 2, s = p & 3, j0 = 4 * p;
+    for (int I = K; I < 4; I++)             // the panel's four columns, from the tiles of block column K
+      for (int r = 0; r < 4; r++)
+        for (int l = 0; l < 64; l++)
+          if (((l & 15) >> 2) == s) PL[16 * I + 4 * r + (l >> 4)][l & 3] = T[2 * I + (K >> 1)][K & 1][r][l];
+    for (int J = K; J < 4; J++)             // its four rows, from the tiles of block row K
+      for (int l = 0; l < 64; l++) PU[16 * J + (l & 15)][l >> 4] = T[2 * K + (J >> 1)][J & 1][s][l];
+    double a[64][4], b[64][4], R[4], dg[4];
+    for (int l = 0; l < 64; l++)
+      for (int k = 0; k < 4; k++) { a[l][k] = PL[l][k]; b[l][k] = PU[l][k]; }
+    for (int k = 0; k < 4; k++) {
+      const int jp = j0 + k;
+      dg[k] = b[jp][k];
+      R[k] = 1.0 / dg[k];
+      for (int l = 0; l < 64; l++) a[l][k] = a[l][k] * R[k];
+      for (int k2 = k + 1; k2 < 4; k2++) {
+        const double u = b[j0 + k2][k], lm = a[j0 + k2][k];
+        for (int l = 0; l < 64; l++) {
+          a[l][k2] = std::fma(-a[l][k], u, a[l][k2]);
+          b[l][k2] = std::fma(-lm, b[l][k], b[l][k2]);
+        }
+      }
+    }
+    for (int l = 0; l < 64; l++)
+      for (int k = 0; k < 4; k++) {
+        const int jp = j0 + k;
+        if (l > jp && D.cell(l, jp) >= 0) M[(size_t)D.cell(l, jp)] = a[l][k];                     // L(h+l, h+jp)
+        if (l >= jp && D.cell(jp, l) >= 0) M[(size_t)D.cell(jp, l)] = l == jp ? dg[k] : b[l][k] * R[k];   // U'(h+jp, h+l)
+        PL[l][k] = l >= j0 + 4 ? -a[l][k] : 0.0;
+        PU[l][k] = l >= j0 + 4 ? b[l][k] : 0.0;
+      }
+    for (int k = 0; k < 4; k++) M[(size_t)lay.rdiag(D.h + j0 + k)] = R[k];
+    const int K2 = (j0 + 4) >> 4;
+    for (int w = 0; w < 8; w++)
+      for (int q = 0; q < 2; q++) {
+        const int I = w >> 1, J = 2 * (w & 1) + q;
+        if (I < K2 || J < K2) continue;
+        for (int r = 0; r < 4; r++)
+          for (int l = 0; l < 64; l++) {
+            double acc = T[w][q][r][l];
+            for (int kk = 0; kk < 4; kk++) acc = std::fma(PL[16 * I + (l >> 4) + 4 * r][kk], PU[16 * J + (l & 15)][kk], acc);
+            T[w][q][r][l] = acc;
+          }
+      }
+  }
+}
+
 extern "C" {
 
 void* emu_create(const char* mech_path, int nt) {
@@ -175,7 +252,8 @@ void* emu_create(const char* mech_path, int nt) {
   std::string err;
   if (!e->m.load(mech_path, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); delete e; return nullptr; }
   try {
-    e->s = build_kernel_schedule(e->m, nt, 8u * (uint32_t)(e->lay().size() + 1000), Emu::kMaxTemps);   // any base will do here
+    const DenseConfig dc = nt >= 512 ? dense_config(e->m) : DenseConfig{0, 0};      // as the product configures the mechanism
+    e->s = build_kernel_schedule(e->m, nt, 8u * (uint32_t)(e->lay().size() + 1000), Emu::kMaxTemps, dc.nd, dc.kb);   // any base will do here
   } catch (const std::exception& ex) {
     std::fprintf(stderr, "schedule: %s\n", ex.what());
     delete e;
@@ -185,6 +263,8 @@ void* emu_create(const char* mech_path, int nt) {
   return e;
 }
 void emu_destroy(void* h) { delete (Emu*)h; }
+int emu_tail_h(void* h) { return ((Emu*)h)->s.tail.h; }
+int emu_dense_nd(void* h) { return ((Emu*)h)->s.dense.nd; }
 const char* emu_describe(void* h) { return ((Emu*)h)->text.c_str(); }
 
 // KppDecomp on G (nnz doubles, in place) through the LU program; R (nvar) receives the pivot reciprocals the program
@@ -221,6 +301,7 @@ int emu_lu(void* h, double* G, double* R, double* X) {
             M[tgt] = M[tgt] * M[aux];
           }
   }
+  if (e->s.dense.nd > 0) run_dense(e->s.dense, M, e->lay());
   std::memcpy(G, M.data(), sizeof(double) * e->m.nnz);
   if (R) std::memcpy(R, M.data() + e->lay().rdiag(), sizeof(double) * e->m.nvar);
   if (X) std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);

@@ -25,6 +25,8 @@ def emu():
     lib.emu_create.argtypes = [C.c_char_p, C.c_int]
     lib.emu_describe.restype = C.c_char_p
     lib.emu_describe.argtypes = [C.c_void_p]
+    lib.emu_tail_h.argtypes = [C.c_void_p]
+    lib.emu_dense_nd.argtypes = [C.c_void_p]
     lib.emu_lu.argtypes = [C.c_void_p, dp, dp, dp]
     lib.emu_solve_backward.argtypes = [C.c_void_p, dp, dp]
     lib.emu_solve.argtypes = [C.c_void_p, dp, dp]
@@ -74,7 +76,7 @@ def test_programs_match_oracle(emu, mech, nt, golden, oracles):
         rowmax = np.array([np.abs(lu_ref[t.crow[k]:t.crow[k + 1]]).max() for k in range(o.nvar)])
         scale = np.repeat(rowmax, np.diff(t.crow))
         # the program leaves the tail block's upper triangle row-scaled, U'(i,c) = U(i,c)*R(i) (schedule.hpp: TailSolve)
-        tail_h = o.nvar - (128 if o.nvar > 192 else 64)
+        tail_h = emu.emu_tail_h(h)
         G_un = G.copy()
         for k in range(tail_h, o.nvar):
             G_un[t.diag[k] + 1:t.crow[k + 1]] *= G[t.diag[k]]
@@ -98,11 +100,13 @@ def test_programs_match_oracle(emu, mech, nt, golden, oracles):
 
 
 def test_round_structure_tot(emu):
-    """The eager schedule keeps the critical path short: ~165 LU rounds / ~170 solve rounds for tot."""
+    """The eager schedule keeps the critical path short.  With the last 64 rows factorised as a dense block in registers
+    (schedule.hpp: DenseTail) the LU program is left with the ~25 rounds of the head pivots."""
     h = emu.emu_create(os.path.join(REPO, "mistra_amd", "mech", "tot.mech").encode(), 512)
     crit = np.zeros(512, np.int32)
     tot = np.zeros(512, np.int32)
     n_lu = emu.emu_round_profile(h, 0, crit.ctypes.data_as(ip), tot.ctypes.data_as(ip), 512)
-    assert 60 < n_lu < 140 and crit[:n_lu].sum() < 1500
+    assert emu.emu_dense_nd(h) == 64
+    assert 15 < n_lu < 40 and crit[:n_lu].sum() < 200
     n_sv = emu.emu_round_profile(h, 1, crit.ctypes.data_as(ip), tot.ctypes.data_as(ip), 512)
     assert 100 < n_sv < 200 and crit[:n_sv].sum() < 800

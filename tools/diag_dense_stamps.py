@@ -1,0 +1,18 @@
+"""Diagnostic: where wave 0 spends its cycles inside dense_lu (library built by `tools/diag_dense.sh stamps`)."""
+import ctypes as C, os, sys
+REPO = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
+sys.path.insert(0, REPO)
+os.environ['MISTRA_CHEM_LIB'] = os.path.join(REPO, 'mistra_amd', 'lib', os.environ.get('DIAG_LIB', 'libdiag_stamps.so'))
+import numpy as np
+from mistra_amd import chem
+from mistra_amd.workload import make_batch
+chem.init(0)
+var, fix, rconst = make_batch('tot', 0, 512, 'cpu')
+res = chem.integrate('tot', var.numpy(), fix.numpy(), rconst.numpy())
+out = (C.c_ulonglong * 16)()
+assert chem.lib().mistra_diag_dense_stamps(out, 1) == 0
+calls, panels = out[9], out[8]
+names = {6: 'table loads land', 7: 'LU program (VM)', 10: 'scaling pass', 0: 'load+schur', 1: 'scale L', 2: 'publish+barrier', 3: 'chain (wave 0)', 4: 'barrier 2', 5: 'mfma update'}
+print('dense_lu calls', calls, 'panels', panels)
+for k, n in names.items():
+    print('%-18s %8.0f cycles per call' % (n, out[k] / calls), '' if k in (0, 1, 6, 7, 10) else '(%.0f per panel)' % (out[k] / panels))
