@@ -101,7 +101,6 @@ struct MechState {
   GsBufs vdot, jvs;
   VmBufs lu, solve_head_fwd, solve_head_bwd;
   DevBuf<uint32_t> tail_fwd, tail_bwd, lu_scale;
-  DevBuf<uint16_t> dense_tile, dense_schur;
   DevBuf<uint32_t> dense_rows;
   int lu_scale_slots = 0;
   // staging for the host-buffer entry point (grow-only)
@@ -115,7 +114,7 @@ struct MechState {
     consts.release(); fun_fac.release(); jac_fac.release(); jvs_pos.release(); zero_pos.release(); diag_pos.release();
     vdot.release(); jvs.release(); lu.release(); solve_head_fwd.release(); solve_head_bwd.release();
     tail_fwd.release(); tail_bwd.release(); lu_scale.release();
-    dense_tile.release(); dense_schur.release(); dense_rows.release();
+    dense_rows.release();
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release();
     if (one_dev) (void)hipFree(one_dev);
     if (one_host) (void)hipHostFree(one_host);
@@ -195,8 +194,6 @@ int setup_mech(int mech) {
   HIP_TRY(S.tail_fwd.upload(K.tail.fwd));
   HIP_TRY(S.tail_bwd.upload(K.tail.bwd));
   HIP_TRY(S.lu_scale.upload(K.lu_scale.recs));
-  HIP_TRY(S.dense_tile.upload(K.dense.tile_cells));
-  HIP_TRY(S.dense_schur.upload(K.dense.schur_cells));
   HIP_TRY(S.dense_rows.upload(K.dense.row_info));
   S.lu_scale_slots = K.lu_scale.nslots;
   S.ready = true;
@@ -225,7 +222,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
   a.solve_head_fwd = S.solve_head_fwd.dev(); a.solve_head_bwd = S.solve_head_bwd.dev();
   a.tail = TailDev{S.tail_fwd.p, S.tail_bwd.p};
   a.lu_scale = ScaleDev{S.lu_scale.p, S.lu_scale_slots, S.lu_scale_slots + VM_LOOKAHEAD_ROWS};
-  a.dense = DenseDev{S.dense_tile.p, S.dense_schur.p, S.dense_rows.p};
+  a.dense = DenseDev{S.dense_rows.p};
   return a;
 }
 

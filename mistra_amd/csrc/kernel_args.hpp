@@ -30,10 +30,8 @@ struct TailDev {               // tail chain of the triangular solves (schedule.
   const uint32_t* bwd;         // same, columns descending
 };
 
-struct DenseDev {              // dense tail block (schedule.hpp: DenseTail); null pointers where the mechanism has none
-  const uint16_t* tile_cells;  // [(w*64 + lane)*8 + q*4 + r]
-  const uint16_t* schur_cells; // [((k*8 + w)*64 + lane)*4 + {L, U(J0), U(J0+1), R}]
-  const uint32_t* row_info;    // [row][4]: first M cell of the row inside the block, absent-column mask lo / hi, 0
+struct DenseDev {              // dense tail block (schedule.hpp: DenseTail); null where the mechanism has none
+  const uint32_t* row_info;    // [192][4]: first M cell of a row's column range, absent-column mask lo / hi, 0
 };
 
 struct KernelArgs {

@@ -505,21 +505,32 @@ typedef __attribute__((address_space(3))) f64x4 lds_f64x4;
 __device__ __forceinline__ f64x4 lds_ld4(uint32_t addr) { return *(const lds_f64x4*)(uintptr_t)addr; }
 __device__ __forceinline__ void lds_st4(uint32_t addr, f64x4 v) { *(lds_f64x4*)(uintptr_t)addr = v; }
 
+// Ghimj slot (LDS byte address) of column c of a row's column range, from the row's table entry {first, absent lo, absent hi}
+// (schedule.hpp: DenseTail); an absent entry reads as the 0.0 cell `zero`.
+__device__ __forceinline__ uint32_t dense_slot(const u32x4 info, const uint32_t c, const uint32_t zero) {
+  const uint64_t absent = (uint64_t)info.y | ((uint64_t)info.z << 32);
+  const uint32_t idx = info.x + c - (uint32_t)__builtin_popcountll(absent & ((1ull << c) - 1ull));
+  return ((absent >> c) & 1ull) ? zero : 8u * idx;
+}
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+__device__ __forceinline__ u32x4 lds_ldu4(uint32_t addr) { return *(const lds_u32x4*)(uintptr_t)addr; }
+
 // One panel of four pivots, 4P .. 4P+3 of the block.
 //   1. the owners of block column K = P/4 and block row K put the panel's four columns / rows into LDS: PL[row][4], PU[col][4]
 //   2. wave 0 eliminates inside the panel, lane = row for PL and lane = column for PU, pivot by pivot in the order of
-//      KppDecomp_x (gas.f:6160-6171); stores the finished L(i,j), U'(j,c) = U(j,c)*R(j), U(j,j), R(j) to their Ghimj slots;
-//      leaves -L and U in the panel buffers with the rows / columns up to the panel's last pivot set to zero
-//   3. every tile that still has open rows and columns takes the rank-4 update with one MFMA
+//      KppDecomp_x (gas.f:6160-6171), and leaves L, U and the pivots' reciprocals in the panel buffers
+//   3. every tile that still has open rows and columns takes the rank-4 update with one MFMA (rows and columns up to the
+//      panel's last pivot enter as exact zeros); two otherwise idle waves store the finished L(i,j), U'(j,c) = U(j,c)*R(j),
+//      U(j,j), R(j) to their Ghimj slots, for the solves
 // The two panel buffers alternate, so that step 1 of the next panel can start while slower waves are still in step 3.
 // P is a run-time value (the sixteen panels are ONE loop body: unrolled, the block's factorisation was 39 KB of
 // straight-line code executed once per decomposition, and instruction fetch, not arithmetic, set its pace); the tile
 // registers a panel needs are picked with selects on wave-uniform conditions.
 template <class MT, int NT>
-__device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const u32x4 ri, const int P, const int wave, const int lane) {
+__device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const int P, const int wave, const int lane) {
   const int K = P >> 2, S = P & 3, J0P = 4 * P, K2 = (J0P + 4) >> 4;
-  constexpr uint32_t NNZ = MT::NNZ, NVAR = MT::NVAR, H = NVAR - 64;
-  constexpr uint32_t PB = 8u * (uint32_t)LdsLayout<MT, NT>::PANEL, BC = PB + 8192u;
+  constexpr uint32_t NNZ = MT::NNZ, NVAR = MT::NVAR, H = NVAR - 64, ZERO = 8u * (NNZ + NVAR);
+  constexpr uint32_t PB = 8u * (uint32_t)LdsLayout<MT, NT>::PANEL, BC = PB + 8192u, INFO = 8u * (uint32_t)LdsLayout<MT, NT>::DINFO;
   const uint32_t PL = PB + (uint32_t)(P & 1) * 4096u, PU = PL + 2048u;
   const int I = wave >> 1, J0 = 2 * (wave & 1);
   const uint32_t lrow = (uint32_t)(lane >> 4), lcol = (uint32_t)(lane & 15);
@@ -580,20 +591,17 @@ __device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const u32x4 ri
       T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, T1, 0, 0, 0);
     }
   }
-  // The finished entries go to their Ghimj slots, for the solves: two otherwise idle waves do that while wave 0 is in the
-  // next panel (this panel's buffers are rewritten two panels on, behind two barriers that these waves take part in).
-  // A row's slots inside the block are contiguous, columns ascending: the slot of (row, c) is first(row) + c - (absent
-  // columns below c); ri = {first, absent mask lo, hi} of row H+lane, the pivot rows' values come over by v_readlane.
+  // The finished entries go to their Ghimj slots: waves 1 and 2 do that while wave 0 is in the next panel (this panel's
+  // buffers are rewritten two panels on, behind two barriers that these waves take part in).
   if (wave == 1 || wave == 2) {
     const f64x4 rcp = lds_ld4(BC + 1024u);
-    const uint64_t my_mask = (uint64_t)ri.y | ((uint64_t)ri.z << 32), below_me = (1ull << lane) - 1ull;
     if (wave == 1) {
       const f64x4 a = lds_ld4(PL + 32u * lane);
+      const u32x4 mine = lds_ldu4(INFO + 16u * lane);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int jp = J0P + k;
-        const uint32_t lcell = ri.x + (uint32_t)jp - (uint32_t)__builtin_popcountll(my_mask & ((1ull << jp) - 1ull));
-        if (lane > jp && !((my_mask >> jp) & 1ull)) lds_st(8u * lcell, a[k]);                              // L(H+lane, H+jp)
+        const uint32_t at = dense_slot(mine, (uint32_t)(J0P + k), ZERO);
+        if (lane > J0P + k && at != ZERO) lds_st(at, a[k]);                                                // L(H+lane, H+4P+k)
       }
       if (lane >= J0P && lane < J0P + 4) {                                                                  // R(k) = 1/U(k,k)
         const int k = lane - J0P;
@@ -603,11 +611,8 @@ __device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const u32x4 ri
       const f64x4 b = lds_ld4(PU + 32u * lane);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int jp = J0P + k;
-        const uint32_t pfirst = (uint32_t)__builtin_amdgcn_readlane((int)ri.x, jp);
-        const uint64_t pmask = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ri.y, jp) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ri.z, jp) << 32);
-        const uint32_t ucell = pfirst + (uint32_t)lane - (uint32_t)__builtin_popcountll(pmask & below_me);
-        if (lane >= jp && !((pmask >> lane) & 1ull)) lds_st(8u * ucell, lane == jp ? b[k] : b[k] * rcp[k]);   // U'(H+jp, H+lane), the diagonal unscaled
+        const uint32_t at = dense_slot(lds_ldu4(INFO + 16u * (uint32_t)(J0P + k)), (uint32_t)lane, ZERO);
+        if (lane >= J0P + k && at != ZERO) lds_st(at, lane == J0P + k ? b[k] : b[k] * rcp[k]);             // U'(H+4P+k, H+lane), the diagonal unscaled
       }
     }
   }
@@ -615,64 +620,34 @@ __device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const u32x4 ri
   MISTRA_STAMP_ADD(2, tb - ta) MISTRA_STAMP_ADD(3, tc - tb) MISTRA_STAMP_ADD(4, td - tc) MISTRA_STAMP_ADD(5, te - td) MISTRA_STAMP_ADD(8, 1)
 }
 
-// KppDecomp_x for a mechanism with the dense tail block: LU program (head pivots) -> scaling pass -> Schur steps ->
-// the block's own factorisation.  One function, so that the cell tables of the dense part are fetched BEFORE the LU
-// program runs: a global load issued here, in the middle of a cell's step, waits thousands of cycles behind the table
-// streams of every other workgroup (measured: 4.6k cycles in front of the first MFMA, ~0.9k per panel for a table row).
+// The dense tail block after the LU program and the scaling pass: Schur steps, then the block's own factorisation.  Every
+// Ghimj slot it touches is found by arithmetic on the row table in LDS: a global load issued here, in the middle of a cell's
+// step, waits behind the table streams of the whole chip (measured: 13 000 cycles in front of the first MFMA).
 template <class MT, int NT>
-__device__ __attribute__((noinline)) void lu_with_dense_tail(const uint32_t* lu_wave_base, const uint32_t* lu_recs, int lu_rounds,
-                                                             const uint32_t* scale_recs, int scale_slots, const uint16_t* tile_cells,
-                                                             const uint16_t* schur_cells, const uint32_t* row_info, int lane) {
-  // (scalar arguments: the three descriptor structs by value no longer fit the argument registers and would come over the stack)
-  const VmDev lu{lu_wave_base, nullptr, lu_recs, lu_rounds};
-  const ScaleDev scale{scale_recs, scale_slots, scale_slots + kRingSlots * 2};
-  const DenseDev D{tile_cells, schur_cells, row_info};
+__device__ __attribute__((noinline)) void dense_lu(int lane) {
   static_assert(NT == 512 && MT::DENSE_ND == 64, "eight waves, two 16x16 tiles each");
   constexpr int KB = MT::DENSE_KB;
-  constexpr uint32_t ZERO = 8u * (uint32_t)(MT::NNZ + MT::NVAR);
+  constexpr uint32_t NNZ = MT::NNZ, NVAR = MT::NVAR, H = NVAR - 64, JM = H - 4 * KB, ZERO = 8u * (NNZ + NVAR);
+  constexpr uint32_t INFO = 8u * (uint32_t)LdsLayout<MT, NT>::DINFO, RDIAG = 8u * (NNZ + NVAR + 4u);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#ifndef MISTRA_DIAG_LATE_LOADS
-  u32x2 sc[KB];
-#pragma unroll
-  for (int k = 0; k < KB; k++) sc[k] = G_(reinterpret_cast<const u32x2*>(D.schur_cells))[(k * 8 + wave) * 64 + lane];
-  const u32x4 tc = G_(reinterpret_cast<const u32x4*>(D.tile_cells))[wave * 64 + lane];
-  const u32x4 ri = G_(reinterpret_cast<const u32x4*>(D.row_info))[lane];
-#endif
-#ifdef MISTRA_DIAG_STAMPS
-  MISTRA_STAMP(tl0)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  MISTRA_STAMP(tl1)
-#endif
-#ifndef MISTRA_DIAG_CALLER_RUNS_VM
-  vm_run<NT>(lu, wave, lane);
-#endif
-#ifdef MISTRA_DIAG_STAMPS
-  MISTRA_STAMP(tl2)
-#endif
-#ifndef MISTRA_DIAG_CALLER_RUNS_VM
-  scale_run<NT, MT::RING_LOW>(scale, wave, lane);      // L(k,j) *= R(j); rows of the solves' tail chain: U(i,c) *= R(i)
-#endif
-#ifdef MISTRA_DIAG_LATE_LOADS
-  u32x2 sc[KB];
-#pragma unroll
-  for (int k = 0; k < KB; k++) sc[k] = G_(reinterpret_cast<const u32x2*>(D.schur_cells))[(k * 8 + wave) * 64 + lane];
-  const u32x4 tc = G_(reinterpret_cast<const u32x4*>(D.tile_cells))[wave * 64 + lane];
-  const u32x4 ri = G_(reinterpret_cast<const u32x4*>(D.row_info))[lane];
-#endif
-  lds_barrier();
+  const uint32_t I = (uint32_t)(wave >> 1), J0 = 2u * (uint32_t)(wave & 1), lrow = (uint32_t)(lane >> 4), lcol = (uint32_t)(lane & 15);
   MISTRA_STAMP(t0)
-#ifdef MISTRA_DIAG_STAMPS
-  MISTRA_STAMP_ADD(6, tl1 - tl0) MISTRA_STAMP_ADD(7, tl2 - tl1) MISTRA_STAMP_ADD(10, t0 - tl2)
-#endif
   // ---- the block's slots as the LU program and the scaling pass leave them -> tiles
   f64x4 T0, T1;
-  T0[0] = lds_ld(8u * (tc.x & 0xFFFFu)); T0[1] = lds_ld(8u * (tc.x >> 16)); T0[2] = lds_ld(8u * (tc.y & 0xFFFFu)); T0[3] = lds_ld(8u * (tc.y >> 16));
-  T1[0] = lds_ld(8u * (tc.z & 0xFFFFu)); T1[1] = lds_ld(8u * (tc.z >> 16)); T1[2] = lds_ld(8u * (tc.w & 0xFFFFu)); T1[3] = lds_ld(8u * (tc.w >> 16));
-  // ---- Schur steps: pivots jm .. h-1, four per MFMA, ascending
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const u32x4 info = lds_ldu4(INFO + 16u * (16u * I + lrow + 4u * r));
+    T0[r] = lds_ld(dense_slot(info, 16u * J0 + lcol, ZERO));
+    T1[r] = lds_ld(dense_slot(info, 16u * J0 + 16u + lcol, ZERO));
+  }
+  // ---- Schur steps: pivots jm .. h-1, four per MFMA, ascending: D -= W * U' with W the still unscaled L slots of the
+  //      block's rows and U' the row-scaled U slots of the pivots' rows (schedule.hpp: DenseTail)
+  const u32x4 lrow_info = lds_ldu4(INFO + 16u * (64u + 16u * I + lcol));      // A operand: row 16I + (lane&15), k = lane>>4
 #pragma unroll
   for (int k = 0; k < KB; k++) {
-    const double wl = lds_ld(8u * (sc[k].x & 0xFFFFu));
-    const double u0 = lds_ld(8u * (sc[k].x >> 16)), u1 = lds_ld(8u * (sc[k].y & 0xFFFFu));
+    const u32x4 urow_info = lds_ldu4(INFO + 16u * (128u + 4u * k + lrow));     // B operand: k = lane>>4, column 16J + (lane&15)
+    const double wl = lds_ld(dense_slot(lrow_info, 4u * k + lrow, ZERO));
+    const double u0 = lds_ld(dense_slot(urow_info, 16u * J0 + lcol, ZERO)), u1 = lds_ld(dense_slot(urow_info, 16u * J0 + 16u + lcol, ZERO));
     T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-wl, u0, T0, 0, 0, 0);
     T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-wl, u1, T1, 0, 0, 0);
   }
@@ -680,23 +655,17 @@ __device__ __attribute__((noinline)) void lu_with_dense_tail(const uint32_t* lu_
   lds_barrier();      // both waves of a block row have read the unscaled slots
   {                   // L = W * R(j) for the solves; the two waves of a block row share the work (steps k even / k odd)
     static_assert(KB % 2 == 0, "the two waves of a block row take every other Schur step");
-    const uint32_t pick = (wave & 1) ? 0xFFFFFFFFu : 0u;
-#define MISTRA_LSCALE_AT(K2_) (8u * ((((sc[K2_ + 1].x & pick) | (sc[K2_].x & ~pick))) & 0xFFFFu))
-#define MISTRA_LSCALE_R(K2_) (8u * ((((sc[K2_ + 1].y & pick) | (sc[K2_].y & ~pick))) >> 16))
-    double v0 = lds_ld(MISTRA_LSCALE_AT(0)) * lds_ld(MISTRA_LSCALE_R(0)), v1 = lds_ld(MISTRA_LSCALE_AT(2)) * lds_ld(MISTRA_LSCALE_R(2));
-    double v2 = lds_ld(MISTRA_LSCALE_AT(4)) * lds_ld(MISTRA_LSCALE_R(4)), v3 = lds_ld(MISTRA_LSCALE_AT(6)) * lds_ld(MISTRA_LSCALE_R(6));
-    double v4 = lds_ld(MISTRA_LSCALE_AT(8)) * lds_ld(MISTRA_LSCALE_R(8)), v5 = lds_ld(MISTRA_LSCALE_AT(10)) * lds_ld(MISTRA_LSCALE_R(10));
-    double v6 = lds_ld(MISTRA_LSCALE_AT(12)) * lds_ld(MISTRA_LSCALE_R(12));
-    static_assert(KB == 14, "seven pairs of Schur steps are written out here");
-    if (MISTRA_LSCALE_AT(0) != ZERO) lds_st(MISTRA_LSCALE_AT(0), v0);
-    if (MISTRA_LSCALE_AT(2) != ZERO) lds_st(MISTRA_LSCALE_AT(2), v1);
-    if (MISTRA_LSCALE_AT(4) != ZERO) lds_st(MISTRA_LSCALE_AT(4), v2);
-    if (MISTRA_LSCALE_AT(6) != ZERO) lds_st(MISTRA_LSCALE_AT(6), v3);
-    if (MISTRA_LSCALE_AT(8) != ZERO) lds_st(MISTRA_LSCALE_AT(8), v4);
-    if (MISTRA_LSCALE_AT(10) != ZERO) lds_st(MISTRA_LSCALE_AT(10), v5);
-    if (MISTRA_LSCALE_AT(12) != ZERO) lds_st(MISTRA_LSCALE_AT(12), v6);
-#undef MISTRA_LSCALE_AT
-#undef MISTRA_LSCALE_R
+    double v[KB / 2];
+    uint32_t at[KB / 2];
+#pragma unroll
+    for (int k2 = 0; k2 < KB / 2; k2++) {
+      const uint32_t c = 4u * (2u * k2 + (uint32_t)(wave & 1)) + lrow;
+      at[k2] = dense_slot(lrow_info, c, ZERO);
+      v[k2] = lds_ld(at[k2]) * lds_ld(RDIAG + 8u * (JM + c));
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < KB / 2; k2++)
+      if (at[k2] != ZERO) lds_st(at[k2], v[k2]);
   }
   MISTRA_STAMP(t2)
   MISTRA_STAMP_ADD(0, t1 - t0) MISTRA_STAMP_ADD(1, t2 - t1) MISTRA_STAMP_ADD(9, 1)
@@ -705,7 +674,7 @@ __device__ __attribute__((noinline)) void lu_with_dense_tail(const uint32_t* lu_
 #define MISTRA_DIAG_DENSE_PANELS 16
 #endif
 #pragma unroll 1
-  for (int P = 0; P < MISTRA_DIAG_DENSE_PANELS; P++) dense_panel<MT, NT>(T0, T1, ri, P, wave, lane);
+  for (int P = 0; P < MISTRA_DIAG_DENSE_PANELS; P++) dense_panel<MT, NT>(T0, T1, P, wave, lane);
 }
 
 }  // namespace
@@ -764,6 +733,9 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   for (int q = 0; q < 3 * RPT; q++) jfac[q] = G_(a.jac_fac)[q * NT + t];
   if (t < NFIX) X[NVAR + t] = G_(a.fix)[(size_t)cell * NFIX + t];
   if (t < NCONST) X[NVAR + NFIX + t] = G_(a.consts)[t];
+  if constexpr (MT::DENSE_ND > 0) {      // the dense tail block's row table stays in LDS for the whole call
+    if (t < 192) *(lds_u32x4*)(uintptr_t)(8u * (uint32_t)L::DINFO + 16u * (uint32_t)t) = G_(reinterpret_cast<const u32x4*>(a.dense.row_info))[t];
+  }
   if (t == 0) {   // the VM's constant cells: 0.0 (padding update slots), 1.0 (neutral factor), -1.0 (partial-sum combine)
     M[NNZ + NVAR] = 0.0;
     M[NNZ + NVAR + 1] = 1.0;
@@ -977,26 +949,19 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
             if (nconsecutive <= 5) H = H * 0.5;
             else { ierr = -8; break; }
           } else {
-            if constexpr (MT::DENSE_ND > 0) {
-              static_assert(MT::SCALE_PASS, "the Schur steps read what the scaling pass leaves");
-#ifdef MISTRA_DIAG_CALLER_RUNS_VM
-              vm_run<NT>(a.lu, wave, lane);
+            vm_run<NT>(a.lu, wave, lane);
+            if constexpr (MT::SCALE_PASS) {      // else the scaling is the LU program's last round
               lap(3);
-              scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);
+              scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);      // L(k,j) *= R(j); tail block: U(i,c) *= R(i)
               lds_barrier();
               lap(11);
-#endif
-              lu_with_dense_tail<MT, NT>(a.lu.wave_base, a.lu.recs, a.lu.nrounds, a.lu_scale.recs, a.lu_scale.nslots, a.dense.tile_cells,
-                                         a.dense.schur_cells, a.dense.row_info, lane);
+            }
+            if constexpr (MT::DENSE_ND > 0) {
+              static_assert(MT::SCALE_PASS, "the Schur steps read what the scaling pass leaves");
+              lap(3);
+              dense_lu<MT, NT>(lane);
               lds_barrier();
-            } else {
-              vm_run<NT>(a.lu, wave, lane);
-              if constexpr (MT::SCALE_PASS) {      // else the scaling is the LU program's last round
-                lap(3);
-                scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);      // L(k,j) *= R(j); tail block: U(i,c) *= R(i)
-                lds_barrier();
-                lap(11);
-              }
+              lap(12);
             }
             lap(3);
           }

@@ -28,7 +28,8 @@ struct LdsLayout {
   static constexpr int AB_TRASH = max_i(MT::NREACT, MT::NB);                           // spare cell: products no reaction owns land here
   static constexpr int RED = AB + round_up2(AB_TRASH + 1);                             // per-wave partial sums
   static constexpr int FLAGS = RED + 32;
-  static constexpr int TOTAL = FLAGS + 2;
+  static constexpr int DINFO = FLAGS + 2;                                               // dense tail block: row table, 192 x 16 bytes (schedule.hpp: DenseTail)
+  static constexpr int TOTAL = DINFO + (MT::DENSE_ND > 0 ? 192 * 2 : 0);
   // dense_lu's panel buffers live in the A/B product array, which nothing reads between Jac_SP and the next Fun:
   // two buffers of [64][4] panel columns + [64][4] panel rows, two 64-entry broadcast rows of the eliminating wave
   static constexpr int PANEL = AB;

@@ -611,9 +611,7 @@ TailSolve build_tail_solve(const MechTables& m, const VmLayout& lay, int regs) {
   return T;
 }
 
-// Cell tables of the dense tail block (schedule.hpp: DenseTail).  Tile element (l, r) of tile (I, J): row 16I + (l>>4) + 4r,
-// column 16J + (l&15) of D — the C/D layout of v_mfma_f64_16x16x4_f64; A operand lane l: row l&15, k = l>>4; B operand
-// lane l: k = l>>4, column l&15.
+// Row tables of the dense tail block (schedule.hpp: DenseTail).
 DenseTail build_dense_tail(const MechTables& m, const VmLayout& lay, int nd, int kb) {
   DenseTail D;
   const int n = m.nvar;
@@ -622,54 +620,32 @@ DenseTail build_dense_tail(const MechTables& m, const VmLayout& lay, int nd, int
   D.h = n - nd;
   D.kb = kb;
   D.jm = D.h - 4 * kb;
-  if (D.jm < 0) throw std::invalid_argument("more Schur steps than pivots");
-  if (lay.size() > 0xFFFF) throw std::invalid_argument("dense tail tables need 16-bit M cells");
-  auto cell = [&](int row, int col) -> int {        // Ghimj slot of (row, col), -1 if not in the pattern
-    for (int p = m.crow[row]; p < m.crow[row + 1]; p++)
-      if (m.icol[p] == col) return p;
-    return -1;
-  };
-  const uint16_t zero = (uint16_t)lay.zero();
-  D.tile_cells.assign((size_t)8 * 2 * 4 * 64, zero);
-  for (int w = 0; w < 8; w++)
-    for (int q = 0; q < 2; q++)
-      for (int r = 0; r < 4; r++)
-        for (int l = 0; l < 64; l++) {
-          const int I = w >> 1, J = 2 * (w & 1) + q;
-          const int c = cell(D.h + 16 * I + (l >> 4) + 4 * r, D.h + 16 * J + (l & 15));
-          if (c >= 0) D.tile_cells[((size_t)w * 64 + l) * 8 + q * 4 + r] = (uint16_t)c;
-        }
-  D.schur_cells.assign((size_t)std::max(kb, 1) * 8 * 64 * 4, zero);
-  for (int k = 0; k < kb; k++)
-    for (int w = 0; w < 8; w++)
-      for (int l = 0; l < 64; l++) {
-        const int I = w >> 1, j = D.jm + 4 * k + (l >> 4);
-        uint16_t* out = &D.schur_cells[(((size_t)k * 8 + w) * 64 + l) * 4];
-        int c = cell(D.h + 16 * I + (l & 15), j);
-        if (c >= 0) out[0] = (uint16_t)c;
-        for (int q = 0; q < 2; q++) {
-          c = cell(j, D.h + 16 * (2 * (w & 1) + q) + (l & 15));
-          if (c >= 0) out[1 + q] = (uint16_t)c;
-        }
-        out[3] = (uint16_t)lay.rdiag(j);
-      }
-  // the finished factors go back to their slots: the block's part of a CSR row is contiguous, columns ascending
-  D.row_info.assign((size_t)nd * 4, 0u);
-  for (int i = 0; i < nd; i++) {
+  if (D.jm < 0 || kb < 0) throw std::invalid_argument("more Schur steps than pivots");
+  if (D.info_rows() > DenseTail::kInfoRowsMax) throw std::invalid_argument("too many Schur steps for the LDS row table");
+  (void)lay;
+  D.row_info.assign((size_t)DenseTail::kInfoRowsMax * 4, 0u);
+  auto describe_range = [&](int g, int row, int c0, int c1) {        // slots of `row` with columns in [c0, c1)
     int first = -1, seen = 0;
-    uint64_t mask = 0;
-    for (int c = 0; c < nd; c++) {
-      const int p = cell(D.h + i, D.h + c);
-      if (p < 0) { mask |= 1ull << c; continue; }
-      if (first < 0) first = p;
-      if (p != first + seen) throw std::logic_error("dense tail: a row's slots inside the block are not contiguous");
+    uint64_t absent = 0;
+    for (int c = c0; c < c1; c++) {
+      int slot = -1;
+      for (int p = m.crow[row]; p < m.crow[row + 1]; p++)
+        if (m.icol[p] == c) slot = p;
+      if (slot < 0) { absent |= 1ull << (c - c0); continue; }
+      if (first < 0) first = slot;
+      if (slot != first + seen) throw std::logic_error("dense tail: a row's slots inside a column range are not contiguous");
       seen++;
     }
-    if (first < 0) throw std::logic_error("dense tail: empty row");
-    D.row_info[(size_t)i * 4] = (uint32_t)first;
-    D.row_info[(size_t)i * 4 + 1] = (uint32_t)mask;
-    D.row_info[(size_t)i * 4 + 2] = (uint32_t)(mask >> 32);
+    for (int c = c1 - c0; c < 64; c++) absent |= 1ull << c;
+    D.row_info[(size_t)g * 4] = (uint32_t)std::max(first, 0);
+    D.row_info[(size_t)g * 4 + 1] = (uint32_t)absent;
+    D.row_info[(size_t)g * 4 + 2] = (uint32_t)(absent >> 32);
+  };
+  for (int i = 0; i < nd; i++) {
+    describe_range(i, D.h + i, D.h, n);
+    describe_range(64 + i, D.h + i, D.jm, D.h);
   }
+  for (int r = 0; r < 4 * kb; r++) describe_range(128 + r, D.jm + r, D.h, n);
   return D;
 }
 

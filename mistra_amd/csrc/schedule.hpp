@@ -169,15 +169,20 @@ struct ScaleProgram {
 // L(i,j) multipliers, U'(i,c) = U(i,c)*R(i) row-scaled, R(i) = 1/U(i,i) published (schedule.hpp: TailSolve).
 struct DenseTail {
   int nd = 0, h = 0, jm = 0, kb = 0;            // D = rows/columns [h, h+nd), nd = 64; kb = (h - jm)/4 Schur steps
-  std::vector<uint16_t> tile_cells;             // [(w*64 + lane)*8 + q*4 + r]  M cell of the tile element, the 0.0 cell if absent
-  std::vector<uint16_t> schur_cells;            // [(k*8 + w)*64 + lane][4]  M cells of: L(h+16I+(l&15), jm+4k+(l>>4)),
-                                                //   U(jm+4k+(l>>4), h+16J+(l&15)) for J = 2(w&1), 2(w&1)+1, R(jm+4k+(l>>4))
-  std::vector<uint32_t> row_info;               // [row 0..63][4]  where the finished factors go: {M cell of the row's first slot inside the
-                                                //   block, absent-columns mask lo, hi, 0}; the slot of (row, c) is first + c - popcount(mask below c)
-  int cell(int row, int c) const {              // (host mirror of the kernel's arithmetic) M cell of D(row, c), -1 if absent
-    const uint64_t mask = (uint64_t)row_info[(size_t)row * 4 + 1] | ((uint64_t)row_info[(size_t)row * 4 + 2] << 32);
+  // Where the block's entries and the Schur steps' operands live in Ghimj.  A CSR row keeps its columns ascending, so
+  // the slots of one row inside a column range are contiguous: the slot of (row, range column c) is
+  //     first + c - popcount(absent & ((1 << c) - 1)),   absent bit c set = not in the pattern (reads as the 0.0 cell).
+  // row_info[g][4] = {first, absent lo, absent hi, 0}; the kernel keeps the table in LDS (2.9 KB) for the whole call:
+  //   g = i         (i < 64)       row h+i, columns [h, n)      the block itself
+  //   g = 64 + i    (i < 64)       row h+i, columns [jm, h)     L operands of the Schur steps
+  //   g = 128 + r   (r < 4 kb)     row jm+r, columns [h, n)     U operands of the Schur steps
+  std::vector<uint32_t> row_info;
+  static constexpr int kInfoRowsMax = 192;
+  int info_rows() const { return 128 + 4 * kb; }
+  int cell(int g, int c) const {                // (host mirror of the kernel's arithmetic) M cell, -1 if absent
+    const uint64_t mask = (uint64_t)row_info[(size_t)g * 4 + 1] | ((uint64_t)row_info[(size_t)g * 4 + 2] << 32);
     if ((mask >> c) & 1) return -1;
-    return (int)row_info[(size_t)row * 4] + c - __builtin_popcountll(mask & ((1ull << c) - 1));
+    return (int)row_info[(size_t)g * 4] + c - __builtin_popcountll(mask & ((1ull << c) - 1));
   }
 };
 

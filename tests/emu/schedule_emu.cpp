@@ -177,24 +177,24 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
 // operand layouts, same order of operations (an MFMA = four fused multiply-adds in k order per element).
 static void run_dense(const DenseTail& D, std::vector<double>& M, const VmLayout& lay) {
   static double T[8][2][4][64];
+  auto at = [&](int g, int c) { const int p = D.cell(g, c); return (size_t)(p < 0 ? lay.zero() : p); };
   for (int w = 0; w < 8; w++)
     for (int q = 0; q < 2; q++)
       for (int r = 0; r < 4; r++)
-        for (int l = 0; l < 64; l++) T[w][q][r][l] = M[D.tile_cells[((size_t)w * 64 + l) * 8 + q * 4 + r]];
-  auto sc = [&](int k, int w, int l, int which) { return (size_t)D.schur_cells[(((size_t)k * 8 + w) * 64 + l) * 4 + which]; };
+        for (int l = 0; l < 64; l++) T[w][q][r][l] = M[at(16 * (w >> 1) + (l >> 4) + 4 * r, 16 * (2 * (w & 1) + q) + (l & 15))];
   for (int k = 0; k < D.kb; k++) {
     for (int w = 0; w < 8; w++)
       for (int q = 0; q < 2; q++)
         for (int r = 0; r < 4; r++)
           for (int l = 0; l < 64; l++) {
-            const int row = (l >> 4) + 4 * r, col = l & 15;
+            const int row = 16 * (w >> 1) + (l >> 4) + 4 * r, col = 16 * (2 * (w & 1) + q) + (l & 15);
             double acc = T[w][q][r][l];
-            for (int kk = 0; kk < 4; kk++) acc = std::fma(-M[sc(k, w, row + 16 * kk, 0)], M[sc(k, w, 16 * kk + col, 1 + q)], acc);
+            for (int kk = 0; kk < 4; kk++) acc = std::fma(-M[at(64 + row, 4 * k + kk)], M[at(128 + 4 * k + kk, col)], acc);
             T[w][q][r][l] = acc;
           }
-    for (int w = 0; w < 8; w += 2)          // the even wave of a block row leaves the multipliers L = W*R in the slots
-      for (int l = 0; l < 64; l++)
-        if (sc(k, w, l, 0) != (size_t)lay.zero()) M[sc(k, w, l, 0)] = M[sc(k, w, l, 0)] * M[sc(k, w, l, 3)];
+    for (int i = 0; i < 64; i++)            // the step leaves the multipliers L = W*R in the slots
+      for (int kk = 0; kk < 4; kk++)
+        if (D.cell(64 + i, 4 * k + kk) >= 0) M[at(64 + i, 4 * k + kk)] = M[at(64 + i, 4 * k + kk)] * M[(size_t)lay.rdiag(D.jm + 4 * k + kk)];
   }
   static double PL[64][4], PU[64][4];
   for (int p = 0; p < D.nd / 4; p++) {
