@@ -54,6 +54,9 @@ def build_lib(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
     if force or _stale(LIB, objs):
+        # the look-ahead rings of ros3_kernel.hip sit in registers the compiler does not know are busy: no library is linked
+        # from a kernel object in which a ring-using function's own registers reach its ring (raises)
+        ring_register_report()
         cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
@@ -79,6 +82,7 @@ def ring_register_report(isa_path=None):
     starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_ZN6mistra.*:", l)]
     starts.append((len(lines), "end"))
     report = {}
+    ring_users = set()
     for (i, name), (j, _) in zip(starts, starts[1:]):
         in_asm, hi = False, 0
         for l in lines[i:j]:
@@ -86,17 +90,22 @@ def ring_register_report(isa_path=None):
                 in_asm = True
             elif "ASMEND" in l:
                 in_asm = False
+            elif in_asm and re.search(r"global_load_dwordx4 v\[(96|192):\d+\], v\[\d+:\d+\], off", l):
+                ring_users.add(name)         # the function issues ring loads (vm_ring_load) itself; (vm_run's own ring is
+                                             # loaded and consumed inside ONE asm statement that lists it as clobbered)
             elif "Folded Spill" in l or "Folded Reload" in l:
                 pass    # prologue / epilogue saves of callee-saved ring blocks: before the first ring load, after the drain
             elif not in_asm and not l.strip().startswith((";", ".")):
                 for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", l):
                     hi = max(hi, int(m.group(1) or m.group(3)))
         report[name] = hi
-        low = re.search(r"(gsum_run|tail_solve)I.*Lb([01])E+[A-Z]", name)       # last template argument: ring placement LOW
+        low = re.search(r"(gsum_run|tail_solve|scale_run)I.*Lb([01])E+[A-Z]", name)       # last template argument: ring placement LOW
         if low:
             limit = 96 if low.group(2) == "1" else 192
             if hi >= limit:
                 raise RuntimeError("%s: the compiler allocates v%d, inside the look-ahead ring's register blocks (v%d..)" % (name, hi, limit))
+        elif name in ring_users and "ros3_integrate_kernel" not in name:
+            raise RuntimeError("%s issues look-ahead ring loads but is not covered by the register check" % name)
     return report
 
 

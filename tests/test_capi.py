@@ -69,6 +69,6 @@ def test_lookahead_ring_registers_are_out_of_the_compilers_reach():
     generated gfx950 assembly).  Cross-compiles, no GPU needed."""
     from mistra_amd.build import ring_register_report
     rep = ring_register_report()          # raises if a function's own registers reach its ring
-    dev = {k: v for k, v in rep.items() if "gsum_run" in k or "tail_solve" in k}
-    assert len(dev) >= 8, rep
+    dev = {k: v for k, v in rep.items() if "gsum_run" in k or "tail_solve" in k or "scale_run" in k}
+    assert len(dev) >= 9, rep
     assert max(dev.values()) < 96, dev    # today all of them stay clear even of the low placement
