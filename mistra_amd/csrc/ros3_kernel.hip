@@ -352,7 +352,7 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
           MISTRA_TAIL_OPERANDS(NXT, nxt)                                                \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const double xq = readlane_f64(x[rq], 4 * (gb + K) + c);                    \
-            _Pragma("unroll") for (int r = rq; r < R; r++) x[r] = x[r] - CUR[c][r] * xq; \
+            _Pragma("unroll") for (int r = rq; r < R; r++) x[r] = __builtin_fma(-CUR[c][r], xq, x[r]); \
           }                                                                             \
           MISTRA_TAIL_PIN                                                               \
         }
@@ -389,7 +389,7 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
           MISTRA_TAIL_OPERANDS(NXT, nxt)                                                \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const double xq = readlane_f64(x[rq], 63 - (4 * (gb + K) + c));             \
-            _Pragma("unroll") for (int r = 0; r <= rq; r++) x[r] = x[r] - CUR[c][r] * xq; \
+            _Pragma("unroll") for (int r = 0; r <= rq; r++) x[r] = __builtin_fma(-CUR[c][r], xq, x[r]); \
           }                                                                             \
           MISTRA_TAIL_PIN                                                               \
         }
@@ -515,19 +515,61 @@ __device__ __forceinline__ uint32_t dense_slot(const u32x4 info, const uint32_t 
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 __device__ __forceinline__ u32x4 lds_ldu4(uint32_t addr) { return *(const lds_u32x4*)(uintptr_t)addr; }
 
+// The finished entries of panel P go from the panel buffers to their Ghimj slots: waves 1 and 3 the L columns (two pivots
+// each; wave 1 also the pivots' reciprocals), waves 2 and 5 the (row-scaled) U rows — waves that sit on other SIMDs than
+// wave 0.  Runs while wave 0 eliminates inside panel P+1: the buffers of panel P are rewritten by panel P+2, two barriers
+// later.
+__device__ __forceinline__ bool dense_is_storer(const int wave) { return wave == 1 || wave == 2 || wave == 3 || wave == 5; }
+template <class MT, int NT>
+__device__ __forceinline__ void dense_store_panel(const int P, const int wave, const int lane) {
+  constexpr uint32_t NNZ = MT::NNZ, NVAR = MT::NVAR, H = NVAR - 64, ZERO = 8u * (NNZ + NVAR);
+  constexpr uint32_t PB = 8u * (uint32_t)LdsLayout<MT, NT>::PANEL, BC = PB + 8192u, INFO = 8u * (uint32_t)LdsLayout<MT, NT>::DINFO;
+  const uint32_t PL = PB + (uint32_t)(P & 1) * 4096u, PU = PL + 2048u;
+  const int J0P = 4 * P, khalf = (wave == 3 || wave == 5) ? 2 : 0;
+  const f64x4 rcp = lds_ld4(BC + 1024u + 32u * (uint32_t)(P & 1));
+  if (wave & 1) {
+    if (wave != 5) {
+      const f64x4 a = lds_ld4(PL + 32u * lane);
+      const u32x4 mine = lds_ldu4(INFO + 16u * lane);
+      const double a0 = khalf ? a[2] : a[0], a1 = khalf ? a[3] : a[1];
+      const uint32_t at0 = dense_slot(mine, (uint32_t)(J0P + khalf), ZERO), at1 = dense_slot(mine, (uint32_t)(J0P + khalf + 1), ZERO);
+      if (lane > J0P + khalf && at0 != ZERO) lds_st(at0, a0);                                               // L(H+lane, H+4P+k)
+      if (lane > J0P + khalf + 1 && at1 != ZERO) lds_st(at1, a1);
+      if (wave == 1 && lane >= J0P && lane < J0P + 4) {                                                     // R(k) = 1/U(k,k)
+        const int k = lane - J0P;
+        lds_st(8u * (NNZ + NVAR + 4u + H + (uint32_t)lane), k == 0 ? rcp[0] : k == 1 ? rcp[1] : k == 2 ? rcp[2] : rcp[3]);
+      }
+      return;
+    }
+  }
+  {
+    const f64x4 b = lds_ld4(PU + 32u * lane);
+    const double b0 = khalf ? b[2] : b[0], b1 = khalf ? b[3] : b[1], r0 = khalf ? rcp[2] : rcp[0], r1 = khalf ? rcp[3] : rcp[1];
+    const uint32_t at0 = dense_slot(lds_ldu4(INFO + 16u * (uint32_t)(J0P + khalf)), (uint32_t)lane, ZERO);
+    const uint32_t at1 = dense_slot(lds_ldu4(INFO + 16u * (uint32_t)(J0P + khalf + 1)), (uint32_t)lane, ZERO);
+    if (lane >= J0P + khalf && at0 != ZERO) lds_st(at0, lane == J0P + khalf ? b0 : b0 * r0);               // U'(H+4P+k, H+lane), the diagonal unscaled
+    if (lane >= J0P + khalf + 1 && at1 != ZERO) lds_st(at1, lane == J0P + khalf + 1 ? b1 : b1 * r1);
+  }
+}
+
 // One panel of four pivots, 4P .. 4P+3 of the block.
 //   1. the owners of block column K = P/4 and block row K put the panel's four columns / rows into LDS: PL[row][4], PU[col][4]
 //   2. wave 0 eliminates inside the panel, lane = row for PL and lane = column for PU, pivot by pivot in the order of
 //      KppDecomp_x (gas.f:6160-6171), and leaves L, U and the pivots' reciprocals in the panel buffers
 //   3. every tile that still has open rows and columns takes the rank-4 update with one MFMA (rows and columns up to the
-//      panel's last pivot enter as exact zeros); two otherwise idle waves store the finished L(i,j), U'(j,c) = U(j,c)*R(j),
-//      U(j,j), R(j) to their Ghimj slots, for the solves
+//      panel's last pivot enter as exact zeros)
+// During step 2 of the NEXT panel two otherwise idle waves store the finished L(i,j), U'(j,c) = U(j,c)*R(j), U(j,j), R(j)
+// to their Ghimj slots, for the solves (dense_store_panel)
 // The two panel buffers alternate, so that step 1 of the next panel can start while slower waves are still in step 3.
 // P is a run-time value (the sixteen panels are ONE loop body: unrolled, the block's factorisation was 39 KB of
 // straight-line code executed once per decomposition, and instruction fetch, not arithmetic, set its pace); the tile
 // registers a panel needs are picked with selects on wave-uniform conditions.
 template <class MT, int NT>
-__device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const int P, const int wave, const int lane) {
+__device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const int P, const int wave, const int lane
+#ifdef MISTRA_DIAG_STAMPS
+                                            , unsigned long long (&acc)[5]
+#endif
+) {
   const int K = P >> 2, S = P & 3, J0P = 4 * P, K2 = (J0P + 4) >> 4;
   constexpr uint32_t NNZ = MT::NNZ, NVAR = MT::NVAR, H = NVAR - 64, ZERO = 8u * (NNZ + NVAR);
   constexpr uint32_t PB = 8u * (uint32_t)LdsLayout<MT, NT>::PANEL, BC = PB + 8192u, INFO = 8u * (uint32_t)LdsLayout<MT, NT>::DINFO;
@@ -553,28 +595,46 @@ __device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const int P, c
   MISTRA_STAMP(tb)
   if (wave == 0) {
     // A lone wave issues one instruction every 4-7 cycles whatever it is: this block is kept to the eliminations themselves.
-    // Per pivot: row 4P+k of U and column 4P+k of the still unscaled L go to LDS, every lane reads back the four entries
-    // that belong to the panel's pivots (two 16-byte reads each): the pivot, its row's entries above the later pivots'
-    // columns, its column's entries in the later pivots' rows.
+    // The panel's 4x4 diagonal block is read by EVERY lane (uniform addresses: broadcast reads) and factorised redundantly in
+    // every lane: the dependent chain  pivot -> reciprocal -> multipliers -> next pivot  then runs in registers, without the
+    // LDS round trip per pivot that handing rows from lane to lane would cost (~1000 -> ~500 cycles per panel).  The lanes'
+    // own panel entries (lane = row: a, lane = column: b) take the same operations with the same operands: where they
+    // coincide with the block's entries the values are bit-identical.
     f64x4 a = lds_ld4(PL + 32u * lane), b = lds_ld4(PU + 32u * lane);
+    const f64x4 c0 = lds_ld4(PU + 32u * (uint32_t)J0P), c1 = lds_ld4(PU + 32u * (uint32_t)(J0P + 1));      // column j of the block: rows 0..3
+    const f64x4 c2 = lds_ld4(PU + 32u * (uint32_t)(J0P + 2)), c3 = lds_ld4(PU + 32u * (uint32_t)(J0P + 3));
     f64x4 rcp;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      lds_st(BC + 8u * lane, b[k]);
-      lds_st(BC + 512u + 8u * lane, a[k]);
-      const f64x4 brow = lds_ld4(BC + 8u * J0P), acol = lds_ld4(BC + 512u + 8u * J0P);
-      rcp[k] = 1.0 / brow[k];
-      a[k] = a[k] * rcp[k];
-#pragma unroll
-      for (int k2 = k + 1; k2 < 4; k2++) {
-        const double lm = acol[k2] * rcp[k];
-        a[k2] = __builtin_fma(-a[k], brow[k2], a[k2]);
-        b[k2] = __builtin_fma(-lm, b[k], b[k2]);
-      }
-    }
+    rcp[0] = 1.0 / c0[0];
+    const double l10 = c0[1] * rcp[0], l20 = c0[2] * rcp[0], l30 = c0[3] * rcp[0];
+    const double u01 = c1[0], u02 = c2[0], u03 = c3[0];
+    const double d11 = __builtin_fma(-l10, u01, c1[1]), d12 = __builtin_fma(-l10, u02, c2[1]), d13 = __builtin_fma(-l10, u03, c3[1]);
+    double d21 = __builtin_fma(-l20, u01, c1[2]), d22 = __builtin_fma(-l20, u02, c2[2]), d23 = __builtin_fma(-l20, u03, c3[2]);
+    double d31 = __builtin_fma(-l30, u01, c1[3]), d32 = __builtin_fma(-l30, u02, c2[3]), d33 = __builtin_fma(-l30, u03, c3[3]);
+    rcp[1] = 1.0 / d11;
+    const double l21 = d21 * rcp[1], l31 = d31 * rcp[1];
+    d22 = __builtin_fma(-l21, d12, d22); d23 = __builtin_fma(-l21, d13, d23);
+    d32 = __builtin_fma(-l31, d12, d32); d33 = __builtin_fma(-l31, d13, d33);
+    rcp[2] = 1.0 / d22;
+    const double l32 = d32 * rcp[2];
+    d33 = __builtin_fma(-l32, d23, d33);
+    rcp[3] = 1.0 / d33;
+    // lane = row: L(i, 4P+k) = (entry - earlier multipliers times the pivot rows' entries) * R(k), columns ascending
+    a[0] = a[0] * rcp[0];
+    a[1] = __builtin_fma(-a[0], u01, a[1]); a[2] = __builtin_fma(-a[0], u02, a[2]); a[3] = __builtin_fma(-a[0], u03, a[3]);
+    a[1] = a[1] * rcp[1];
+    a[2] = __builtin_fma(-a[1], d12, a[2]); a[3] = __builtin_fma(-a[1], d13, a[3]);
+    a[2] = a[2] * rcp[2];
+    a[3] = __builtin_fma(-a[2], d23, a[3]);
+    a[3] = a[3] * rcp[3];
+    // lane = column: U(4P+k, c) = entry - the row's multipliers times the earlier pivot rows, pivots ascending
+    b[1] = __builtin_fma(-l10, b[0], b[1]); b[2] = __builtin_fma(-l20, b[0], b[2]); b[3] = __builtin_fma(-l30, b[0], b[3]);
+    b[2] = __builtin_fma(-l21, b[1], b[2]); b[3] = __builtin_fma(-l31, b[1], b[3]);
+    b[3] = __builtin_fma(-l32, b[2], b[3]);
     lds_st4(PL + 32u * lane, a);      // L(H+lane, H+4P+k) for lane > 4P+k
     lds_st4(PU + 32u * lane, b);      // U(H+4P+k, H+lane) for lane >= 4P+k
-    if (lane == 0) lds_st4(BC + 1024u, rcp);
+    if (lane == 0) lds_st4(BC + 1024u + 32u * (uint32_t)(P & 1), rcp);
+  } else if (dense_is_storer(wave) && P > 0) {
+    dense_store_panel<MT, NT>(P - 1, wave, lane);      // while wave 0 eliminates: the previous panel's entries go to their Ghimj slots
   }
   MISTRA_STAMP(tc)
   lds_barrier();
@@ -591,33 +651,10 @@ __device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const int P, c
       T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, T1, 0, 0, 0);
     }
   }
-  // The finished entries go to their Ghimj slots: waves 1 and 2 do that while wave 0 is in the next panel (this panel's
-  // buffers are rewritten two panels on, behind two barriers that these waves take part in).
-  if (wave == 1 || wave == 2) {
-    const f64x4 rcp = lds_ld4(BC + 1024u);
-    if (wave == 1) {
-      const f64x4 a = lds_ld4(PL + 32u * lane);
-      const u32x4 mine = lds_ldu4(INFO + 16u * lane);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t at = dense_slot(mine, (uint32_t)(J0P + k), ZERO);
-        if (lane > J0P + k && at != ZERO) lds_st(at, a[k]);                                                // L(H+lane, H+4P+k)
-      }
-      if (lane >= J0P && lane < J0P + 4) {                                                                  // R(k) = 1/U(k,k)
-        const int k = lane - J0P;
-        lds_st(8u * (NNZ + NVAR + 4u + H + (uint32_t)lane), k == 0 ? rcp[0] : k == 1 ? rcp[1] : k == 2 ? rcp[2] : rcp[3]);
-      }
-    } else {
-      const f64x4 b = lds_ld4(PU + 32u * lane);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t at = dense_slot(lds_ldu4(INFO + 16u * (uint32_t)(J0P + k)), (uint32_t)lane, ZERO);
-        if (lane >= J0P + k && at != ZERO) lds_st(at, lane == J0P + k ? b[k] : b[k] * rcp[k]);             // U'(H+4P+k, H+lane), the diagonal unscaled
-      }
-    }
-  }
   MISTRA_STAMP(te)
-  MISTRA_STAMP_ADD(2, tb - ta) MISTRA_STAMP_ADD(3, tc - tb) MISTRA_STAMP_ADD(4, td - tc) MISTRA_STAMP_ADD(5, te - td) MISTRA_STAMP_ADD(8, 1)
+#ifdef MISTRA_DIAG_STAMPS
+  acc[0] += tb - ta; acc[1] += tc - tb; acc[2] += td - tc; acc[3] += te - td; acc[4] += 1;
+#endif
 }
 
 // The dense tail block after the LU program and the scaling pass: Schur steps, then the block's own factorisation.  Every
@@ -643,10 +680,12 @@ __device__ __attribute__((noinline)) void dense_lu(int lane) {
   // ---- Schur steps: pivots jm .. h-1, four per MFMA, ascending: D -= W * U' with W the still unscaled L slots of the
   //      block's rows and U' the row-scaled U slots of the pivots' rows (schedule.hpp: DenseTail)
   const u32x4 lrow_info = lds_ldu4(INFO + 16u * (64u + 16u * I + lcol));      // A operand: row 16I + (lane&15), k = lane>>4
+  uint32_t wslot[KB];
 #pragma unroll
   for (int k = 0; k < KB; k++) {
     const u32x4 urow_info = lds_ldu4(INFO + 16u * (128u + 4u * k + lrow));     // B operand: k = lane>>4, column 16J + (lane&15)
-    const double wl = lds_ld(dense_slot(lrow_info, 4u * k + lrow, ZERO));
+    wslot[k] = dense_slot(lrow_info, 4u * k + lrow, ZERO);
+    const double wl = lds_ld(wslot[k]);
     const double u0 = lds_ld(dense_slot(urow_info, 16u * J0 + lcol, ZERO)), u1 = lds_ld(dense_slot(urow_info, 16u * J0 + 16u + lcol, ZERO));
     T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-wl, u0, T0, 0, 0, 0);
     T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-wl, u1, T1, 0, 0, 0);
@@ -657,11 +696,11 @@ __device__ __attribute__((noinline)) void dense_lu(int lane) {
     static_assert(KB % 2 == 0, "the two waves of a block row take every other Schur step");
     double v[KB / 2];
     uint32_t at[KB / 2];
+    const uint32_t odd = (uint32_t)(wave & 1), pick = odd ? 0xFFFFFFFFu : 0u;      // (bit selects: an array element picked by a run-time condition would put the array in scratch memory)
 #pragma unroll
     for (int k2 = 0; k2 < KB / 2; k2++) {
-      const uint32_t c = 4u * (2u * k2 + (uint32_t)(wave & 1)) + lrow;
-      at[k2] = dense_slot(lrow_info, c, ZERO);
-      v[k2] = lds_ld(at[k2]) * lds_ld(RDIAG + 8u * (JM + c));
+      at[k2] = (wslot[2 * k2 + 1] & pick) | (wslot[2 * k2] & ~pick);
+      v[k2] = lds_ld(at[k2]) * lds_ld(RDIAG + 8u * (JM + 4u * (2u * k2 + odd) + lrow));
     }
 #pragma unroll
     for (int k2 = 0; k2 < KB / 2; k2++)
@@ -673,8 +712,23 @@ __device__ __attribute__((noinline)) void dense_lu(int lane) {
 #ifndef MISTRA_DIAG_DENSE_PANELS      // timing diagnostics only (tools/diag_dense.sh): a library built with fewer panels computes garbage
 #define MISTRA_DIAG_DENSE_PANELS 16
 #endif
+#ifdef MISTRA_DIAG_STAMPS
+  unsigned long long acc[5] = {0, 0, 0, 0, 0};
+  MISTRA_STAMP(tp0)
+#pragma unroll 1
+  for (int P = 0; P < MISTRA_DIAG_DENSE_PANELS; P++) dense_panel<MT, NT>(T0, T1, P, wave, lane, acc);
+  MISTRA_STAMP(tp1)
+  MISTRA_STAMP_ADD(2, acc[0]) MISTRA_STAMP_ADD(3, acc[1]) MISTRA_STAMP_ADD(4, acc[2]) MISTRA_STAMP_ADD(5, acc[3]) MISTRA_STAMP_ADD(8, acc[4]) MISTRA_STAMP_ADD(12, tp1 - tp0)
+#else
 #pragma unroll 1
   for (int P = 0; P < MISTRA_DIAG_DENSE_PANELS; P++) dense_panel<MT, NT>(T0, T1, P, wave, lane);
+#endif
+  if (dense_is_storer(wave)) dense_store_panel<MT, NT>(15, wave, lane);      // (behind the last panel's second barrier)
+#ifdef MISTRA_DIAG_STAMPS
+  lds_barrier();
+  MISTRA_STAMP(tz)
+  MISTRA_STAMP_ADD(11, tz - t0)
+#endif
 }
 
 }  // namespace

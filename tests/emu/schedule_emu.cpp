@@ -208,17 +208,26 @@ static void run_dense(const DenseTail& D, std::vector<double>& M, const VmLayout
     double a[64][4], b[64][4], R[4], dg[4];
     for (int l = 0; l < 64; l++)
       for (int k = 0; k < 4; k++) { a[l][k] = PL[l][k]; b[l][k] = PU[l][k]; }
-    for (int k = 0; k < 4; k++) {
-      const int jp = j0 + k;
-      dg[k] = b[jp][k];
-      R[k] = 1.0 / dg[k];
-      for (int l = 0; l < 64; l++) a[l][k] = a[l][k] * R[k];
-      for (int k2 = k + 1; k2 < 4; k2++) {
-        const double u = b[j0 + k2][k], lm = a[j0 + k2][k];
-        for (int l = 0; l < 64; l++) {
-          a[l][k2] = std::fma(-a[l][k], u, a[l][k2]);
-          b[l][k2] = std::fma(-lm, b[l][k], b[l][k2]);
+    {   // the kernel factorises the 4x4 diagonal block redundantly in every lane and applies it to the lanes' own entries:
+        // the same operations on the same operands as eliminating lane by lane
+      double d[4][4];
+      for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) d[r][c] = PU[j0 + c][r];
+      for (int k = 0; k < 4; k++) {
+        dg[k] = d[k][k];
+        R[k] = 1.0 / d[k][k];
+        for (int r = k + 1; r < 4; r++) {
+          d[r][k] = d[r][k] * R[k];
+          for (int c = k + 1; c < 4; c++) d[r][c] = std::fma(-d[r][k], d[k][c], d[r][c]);
         }
+      }
+      for (int l = 0; l < 64; l++) {
+        for (int k = 0; k < 4; k++) {
+          for (int k1 = 0; k1 < k; k1++) a[l][k] = std::fma(-a[l][k1], d[k1][k], a[l][k]);
+          a[l][k] = a[l][k] * R[k];
+        }
+        for (int k = 1; k < 4; k++)
+          for (int k1 = 0; k1 < k; k1++) b[l][k] = std::fma(-d[k][k1], b[l][k1], b[l][k]);
       }
     }
     for (int l = 0; l < 64; l++)
