@@ -8,7 +8,13 @@ directly in HBM).  `value` = cells integrated by all ranks / wall time, inputs r
     python bench.py [--gpus N] [--steps K] [--warmup W] [--cells-per-gpu C] [--mech tot]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment), this process starts that torch.distributed.run
+command itself as a child — before it has touched the GPU — relays rank 0's JSON line and exits with the child's code.
+
 Cells are independent, so ranks share nothing on the data path (no collective inside the timed region; weak scaling).
+The data path BASELINE.json's north_star names for a single-process caller — base states broadcast from rank 0, every rank
+integrating its shard, results gathered to rank 0 — is timed as a second leg at N > 1 and reported beside the headline
+value (`config.root_io_path`), never as `value`.
 Rank 0 at N=1 also times the CPU path on the host cores on a bounded sample of the same workload (`cpu_baseline`):
 the compiled reference itself (oracle/_ref/libmistra_ref.so, kind "reference") when it was built, else the plain-C
 restatement (oracle/kpp_ros3.c, kind "port").  The oracle is only ever the thing compared against / timed beside.
@@ -46,13 +52,25 @@ def _cpu_worker(job):
     return time.perf_counter() - t0, nstp
 
 
+def kernel_source_hash():
+    """Identifies the kernel a PMC pass was taken on: sha256 over the device code and the schedule compiler."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ros3_kernel.hip", "ros3_kernel.hpp", "kernel_args.hpp", "schedule.cpp", "schedule.hpp"):
+        h.update(open(os.path.join(REPO, "mistra_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(mech, ncell):
     """HBM bytes per launch from the most recent committed PMC pass (profiles/rNN_traffic.json), scaled to this launch's
-    cell count; None when no pass exists for the mechanism.  bench.py cannot collect PMC counters itself."""
+    cell count.  bench.py cannot collect PMC counters itself (they need their own rocprofv3 pass), so a pass is only used
+    while it was taken on THIS kernel: the file records the kernel source hash, and a stale or missing pass gives null."""
     import glob
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")), reverse=True):
         d = json.load(open(path))
         if d.get("mech") == mech:
+            if d.get("kernel_source_hash") != kernel_source_hash():
+                return None, os.path.basename(path) + " is stale (taken on another kernel): not used"
             return d["bytes_per_launch"] * ncell / d["cells"], os.path.basename(path)
     return None, None
 
@@ -66,12 +84,13 @@ def cpu_baseline(mech, budget_s=15.0):
     kind = "reference" if Reference.available() else "port"
     if kind == "port":
         build_oracle()
-    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    cores_available = len(os.sched_getaffinity(0))
+    cores = max(1, cores_available)          # every core this process may run on: the reference is serial, one process per core
     # calibrate on a few cells, then size the sample for ~budget_s seconds on all cores
     var, fix, rconst = (x.numpy() for x in make_batch(mech, 0, 4, "cpu"))
     dt, _ = _cpu_worker((kind, mech, var, fix, rconst))
     per_cell = dt / 4
-    ncell = int(max(cores, min(32768, budget_s * cores / max(per_cell, 1e-6))))
+    ncell = int(max(cores, min(262144, budget_s * cores / max(per_cell, 1e-6))))
     ncell -= ncell % cores
     var, fix, rconst = (x.numpy() for x in make_batch(mech, 0, ncell, "cpu"))
     share = ncell // cores
@@ -82,10 +101,83 @@ def cpu_baseline(mech, budget_s=15.0):
         res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
     nstp = sum(r[1] for r in res)
-    return {"value": ncell / wall, "unit": "chemistry-timesteps/s", "cores": cores, "kind": kind,
+    return {"value": ncell / wall, "unit": "chemistry-timesteps/s", "cores": cores, "cores_available": cores_available, "kind": kind,
             "sample": "%d cells of the same synthetic %s workload (cells 0..%d), %d processes x 1 thread, %.1f s wall, "
                       "%.1f internal steps/cell, %.0f timesteps/s/core" % (ncell, mech, ncell - 1, cores, wall,
                                                                          nstp / ncell, ncell / wall / cores)}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run the N ranks as a child torch.distributed.run (one process per GPU,
+    127.0.0.1 rendezvous on a free port) and pass its output through.  A child process, never an exec: this one stays a
+    plain Python process that has made no GPU call."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def root_io_leg(args, dist, dev, world, rank, engine, make_batch, shard):
+    """The data path of a single-process caller (north_star: "RCCL broadcast/gather over xGMI only for the embarrassingly-parallel
+    cell partition"): rank 0 holds the base states, broadcasts them, every rank builds and integrates its
+    shard, VAR_out / ierr / stats of all shards are gathered on rank 0.  Timed with the same barrier + synchronize + max over
+    ranks as the headline leg; returns whole-job timesteps/s including the collectives, or None at N = 1."""
+    import torch
+    from mistra_amd.workload import load_base
+    if world == 1:
+        return None
+    on_dev = args.backend == "nccl"
+    cdev = dev if on_dev else torch.device("cpu")
+    shapes = {"gas": (102, 3, 331), "aer": (257, 5, 979), "tot": (417, 7, 1627)}[args.mech]
+    if rank == 0:
+        base = [torch.as_tensor(x, dtype=torch.float64, device=cdev).contiguous() for x in load_base(args.mech)]
+        nbase = torch.tensor([base[0].shape[0]], dtype=torch.int64, device=cdev)
+    else:
+        nbase = torch.zeros(1, dtype=torch.int64, device=cdev)
+    total = args.cells_per_gpu * world
+    start, ncell = shard(total, rank, world)
+    engine.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.broadcast(nbase, 0)
+    if rank != 0:
+        base = [torch.empty((int(nbase.item()), n), dtype=torch.float64, device=cdev) for n in shapes]
+    for x in base:
+        dist.broadcast(x, 0)                      # ncclBroadcast of the base states (tables travel with the library itself)
+    var, fix, rconst = make_batch(args.mech, start, ncell, dev, base=[x.to(dev) for x in base])
+    out = torch.empty_like(var)
+    ierr = torch.empty(ncell, dtype=torch.int32, device=dev)
+    stats = torch.empty((ncell, 8), dtype=torch.int32, device=dev)
+    engine.integrate_into(args.mech, var, fix, rconst, out, ierr, stats)
+    engine.synchronize()
+    # gather to the root by direct sends (xGMI is point-to-point): every rank ships its block of results to rank 0
+    packed = torch.cat([out, ierr.double()[:, None], stats.double()], dim=1).contiguous().to(cdev)
+    if rank == 0:
+        gathered = [packed]
+        reqs = []
+        for r in range(1, world):
+            _, n_r = shard(total, r, world)
+            buf = torch.empty((n_r, packed.shape[1]), dtype=torch.float64, device=cdev)
+            gathered.append(buf)
+            reqs.append(dist.irecv(buf, src=r))
+        for q in reqs:
+            q.wait()
+        ok = int(sum(int((g[:, shapes[0]] == 1).sum().item()) for g in gathered))
+    else:
+        dist.send(packed, dst=0)
+        ok = 0
+    engine.synchronize()
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    return {"value": total / float(elapsed.item()), "unit": "chemistry-timesteps/s", "seconds": float(elapsed.item()),
+            "cells_ok_at_root": ok, "what": "broadcast of the base states from rank 0, shard generation, one integration per rank, "
+            "gather of VAR_out + ierr + stats to rank 0 by direct sends; one pass, collectives inside the clock"}
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -103,13 +195,12 @@ def main():
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (requires --backend gloo)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))          # nothing in this process has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -117,8 +208,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from mistra_amd import chem
-    from mistra_amd.workload import make_batch, shard
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
@@ -134,10 +223,50 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    line = rank_body(args, rank, world, dev, GpuEngine(local_rank))
+    if rank == 0:
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
 
+
+class GpuEngine:
+    """The product on one GPU: the HIP library through mistra_amd.chem, torch for memory, streams and events."""
+
+    def __init__(self, local_rank):
+        import torch
+        from mistra_amd import chem
+        self.torch, self.chem = torch, chem
+        chem.init(local_rank)
+
+    def integrate_into(self, mech, var, fix, rconst, out, ierr, stats):
+        self.chem.integrate_into(mech, var, fix, rconst, out, ierr, stats)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def event(self):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()       # same stream as the kernel (chem.integrate_into launches on torch's current stream)
+        return e
+
+    @staticmethod
+    def elapsed_ms(a, b):
+        return a.elapsed_time(b)
+
+
+def rank_body(args, rank, world, dev, engine):
+    """What one rank does (the process group, if any, is up): build its shard in place, warm up, time `steps` passes between
+    barrier + synchronize on both sides, reduce (max of the time, sums of the counters), run the root-I/O leg; returns the
+    JSON line on rank 0.  `engine` is the product (GpuEngine); tests/test_partition_gloo.py drives this same function on two
+    CPU ranks with a stand-in engine."""
+    import torch
+    import torch.distributed as dist
+    from mistra_amd.workload import make_batch, shard
     total_cells = args.cells_per_gpu * world
     start, ncell = shard(total_cells, rank, world)
-    chem.init(local_rank)
     var, fix, rconst = make_batch(args.mech, start, ncell, dev)
     out = torch.empty_like(var)
     ierr = torch.empty(ncell, dtype=torch.int32, device=dev)
@@ -148,20 +277,20 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        chem.integrate_into(args.mech, var, fix, rconst, out, ierr, stats)
-    torch.cuda.synchronize()
+        engine.integrate_into(args.mech, var, fix, rconst, out, ierr, stats)
+    engine.synchronize()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
+    ev = []
+    engine.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()       # same stream as the kernel (chem.integrate_into launches on torch's current stream)
-        chem.integrate_into(args.mech, var, fix, rconst, out, ierr, stats)
-        ev[k][1].record()
-    torch.cuda.synchronize()
+        e0 = engine.event()
+        engine.integrate_into(args.mech, var, fix, rconst, out, ierr, stats)
+        ev.append((e0, engine.event()))
+    engine.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    kernel_ms = sum(engine.elapsed_ms(a, b) for a, b in ev) / max(1, args.steps)
 
     cdev = dev if args.backend == "nccl" else torch.device("cpu")      # gloo reduces host tensors
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -173,30 +302,34 @@ def main():
     elapsed = float(t_el.item())
     nstp_total, nfail, cells_done = (float(x) for x in agg.tolist())
 
-    if rank == 0:
-        value = total_cells * args.steps / elapsed
-        steps_per_cell = nstp_total / cells_done
-        achieved = ncell * ALG_BYTES[args.mech] / (kernel_ms * 1e-3) / 1e9
-        flops = ncell * steps_per_cell * FLOP_PER_STEP[args.mech] / (kernel_ms * 1e-3)
-        traffic, traffic_src = measured_traffic(args.mech, ncell)
-        line = {
-            "metric": "chemistry-timesteps/sec (%s mechanism)" % args.mech, "value": value, "unit": "chemistry-timesteps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s mechanism, %d synthetic cells per GPU (%d total), INTEGRATE_%s(0,10 s), Ros3 rtol 1e-3; "
-                                   "perturbed captured BTZ96 cloud states" % (args.mech, args.cells_per_gpu, total_cells, args.mech[0]),
-                       "cells_per_gpu": args.cells_per_gpu, "mean_internal_steps_per_cell": steps_per_cell,
-                       "failed_cells": int(nfail), "parallelism": "cells sharded over %d GPU(s), no data-path collective" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "ros3_integrate_kernel", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_cell": ALG_BYTES[args.mech],
-                         "fp64_tflops": flops / 1e12, "fp64_frac_of_vector_peak": flops / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
-        }
-        if cpu is not None:
-            line["cpu_baseline"] = cpu
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    root_io = root_io_leg(args, dist, dev, world, rank, engine, make_batch, shard)
+    if rank != 0:
+        return None
+    value = total_cells * args.steps / elapsed
+    steps_per_cell = nstp_total / cells_done
+    achieved = ncell * ALG_BYTES[args.mech] / (kernel_ms * 1e-3) / 1e9
+    flops = ncell * steps_per_cell * FLOP_PER_STEP[args.mech] / (kernel_ms * 1e-3)
+    traffic, traffic_src = measured_traffic(args.mech, ncell)
+    return {
+        "metric": "chemistry-timesteps/sec (%s mechanism)" % args.mech, "value": value, "unit": "chemistry-timesteps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s mechanism, %d synthetic cells per GPU (%d total), INTEGRATE_%s(0,10 s), Ros3 rtol 1e-3; "
+                               "perturbed captured BTZ96 cloud states" % (args.mech, args.cells_per_gpu, total_cells, args.mech[0]),
+                   "cells_per_gpu": args.cells_per_gpu, "mean_internal_steps_per_cell": steps_per_cell,
+                   "failed_cells": int(nfail), "parallelism": "cells sharded over %d GPU(s), no data-path collective" % world,
+                   "root_io_path": root_io},
+        # `achieved` / `frac` are the contract's figures: ALGORITHMIC bytes over the kernel's time against the HBM roof.  The path
+        # is not HBM-bound: `limiter` says what the counters show instead, `traffic` what the memory side really
+        # moved per launch (schedule tables re-streamed through L2 by every workgroup), `fp64_*` the arithmetic rate.
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_rate_gbs": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9,
+                     "limiter": "latency of one dependency chain per CU (one tot cell owns a CU's LDS): waves parked at s_waitcnt / s_barrier",
+                     "kernel": "ros3_integrate_kernel", "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_cell": ALG_BYTES[args.mech],
+                     "fp64_tflops": flops / 1e12, "fp64_frac_of_vector_peak": flops / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
+    }
 
 
 if __name__ == "__main__":

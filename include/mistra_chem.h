@@ -35,6 +35,16 @@ extern "C" {
  * BLOCK DATA JACOBIAN_SPARSE_DATA_x, gas.f:6718 | aer.f:23480 | tot.f:44435); call once before anything else. */
 int mistra_chem_init(int device);
 
+/* The same on several GPUs of the node, for a single-process caller such as the reference's Fortran program (the model is
+ * serial, kpp.f90:4168): mistra_chem_integrate then cuts the batch into contiguous blocks of cells, one block and one host
+ * thread per device — the layer loop of kpp_driver (kpp.f90:4310-4470) carries nothing from one k to the next, so
+ * nothing is exchanged.  device_ids = NULL means devices 0 .. n_devices-1; the first one listed is the primary device
+ * (one-cell entry points, mistra_chem_describe).  Replaces a previous init. */
+int mistra_chem_init_devices(int n_devices, const int* device_ids);
+
+/* Number of devices the library is initialised on (0 before init). */
+int mistra_chem_device_count(void);
+
 /* Release device memory.  Safe to call more than once. */
 void mistra_chem_finalize(void);
 
@@ -47,8 +57,16 @@ int mistra_chem_dims(int mech, int* nvar, int* nfix, int* nreact, int* lu_nonzer
 int mistra_chem_integrate(int mech, int ncell, const double* var_in, const double* fix, const double* rconst,
                           double tin, double tout, double* var_out, int32_t* ierr, int32_t* stats);
 
-/* Same call on device-resident buffers (hipMalloc'ed or torch tensors on the selected device), asynchronous on
- * `hip_stream` (a hipStream_t; NULL = default stream).  d_ierr (ncell) and d_stats (ncell*8) are required;
+/* The same with what INTEGRATE_x leaves behind per cell besides VAR: t_h (ncell*3, may be NULL) receives, per cell, the exit
+ * time (-> TIN, gas.f:769), the last accepted step size (-> STEPMIN, gas.f:770) and the step size H when the integrator
+ * returned (the H of ros_ErrorMsg_x's message, gas.f:1506).  This is the call a batched kpp_driver makes: one per
+ * mechanism and 10-s step for all layers that run it. */
+int mistra_chem_integrate_ex(int mech, int ncell, const double* var_in, const double* fix, const double* rconst,
+                             double tin, double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h);
+
+/* Same call on device-resident buffers (hipMalloc'ed or torch tensors), asynchronous on `hip_stream` (a hipStream_t of
+ * that device; NULL = its default stream).  The call runs on the device the buffers live on, which must be one the
+ * library was initialised on.  d_ierr (ncell) and d_stats (ncell*8) are required;
  * d_texit_hexit (ncell*2: what INTEGRATE_x leaves in TIN and STEPMIN, gas.f:769-770) may be NULL. */
 int mistra_chem_integrate_device(int mech, int ncell, const double* d_var_in, const double* d_fix,
                                  const double* d_rconst, double tin, double tout, double* d_var_out,
@@ -60,6 +78,14 @@ int mistra_chem_integrate_device(int mech, int ncell, const double* d_var_in, co
  * is updated in place, *tin = exit time, STEPMIN = last step size, ATOL/RTOL are set as INTEGRATE_x sets them, and an
  * unsuccessful integration prints the reference's message.  The ISO_C_BINDING shim in shim/ passes the COMMON block. */
 int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tout);
+
+/* The same without the messages, for a caller that prints them itself as the reference does (the Fortran shim writes
+ * ros_ErrorMsg_x's and INTEGRATE_x's lines to unit 6, gas.f:1474-1509, 764-767): *ierr = IERR of Rosenbrock_x (1 = success),
+ * *t_err / *h_err = T and H when the integrator returned (the two numbers of ros_ErrorMsg_x's last line), *nsng = how
+ * often the decomposition met a zero pivot (the reference prints one warning per occurrence, gas.f:1456).  Any of the four
+ * may be NULL. */
+int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, double* tout, int32_t* ierr, double* t_err,
+                                        double* h_err, int32_t* nsng);
 
 /* Text of the last error on this thread ("" if none). */
 const char* mistra_chem_last_error(void);

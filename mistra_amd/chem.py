@@ -46,6 +46,9 @@ def lib():
                                   % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.mistra_chem_init.argtypes = [C.c_int]
+        L.mistra_chem_init_devices.argtypes = [C.c_int, _ip]
+        L.mistra_chem_integrate_ex.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip, _dp]
+        L.mistra_chem_integrate_common_status.argtypes = [C.c_int, C.c_void_p, _dp, _dp, _ip, _dp, _dp, _ip]
         L.mistra_chem_finalize.restype = None
         L.mistra_chem_dims.argtypes = [C.c_int, _ip, _ip, _ip, _ip]
         L.mistra_chem_integrate.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip]
@@ -65,11 +68,23 @@ def _check(rc):
 
 
 def init(device=0):
-    """Select the GPU, load mechanism tables and upload the kernel schedules (idempotent per device)."""
+    """Select the GPU, load mechanism tables and upload the kernel schedules (idempotent per device).  A device that
+    init_devices() already set up is left as it is."""
     global _inited_device
-    if _inited_device != device:
-        _check(lib().mistra_chem_init(int(device)))
-        _inited_device = device
+    if _inited_device is not None and (device == _inited_device or (isinstance(_inited_device, tuple) and device in _inited_device)):
+        return
+    _check(lib().mistra_chem_init(int(device)))
+    _inited_device = device
+
+
+def init_devices(devices):
+    """Several GPUs in one process (mistra_chem_init_devices): `devices` = a count or a list of HIP device indices.  Host-buffer
+    calls are then split into one block of cells per device; device-buffer calls run where their tensors live."""
+    global _inited_device
+    ids = list(range(devices)) if isinstance(devices, int) else [int(d) for d in devices]
+    arr = (C.c_int32 * len(ids))(*ids)
+    _check(lib().mistra_chem_init_devices(len(ids), arr))
+    _inited_device = tuple(ids)
 
 
 def finalize():
@@ -101,7 +116,8 @@ def integrate(mech, var, fix, rconst, tin=0.0, tout=10.0, device=None):
         is_torch = False
     if is_torch:
         return _integrate_torch(mid, name, var, fix, rconst, tin, tout)
-    init(0 if device is None else device)
+    if device is not None or _inited_device is None:      # host data: whatever device(s) the library already runs on
+        init(0 if device is None else device)
     v = np.ascontiguousarray(var, np.float64).reshape(-1, nvar)
     ncell = v.shape[0]
     f = np.ascontiguousarray(fix, np.float64).reshape(ncell, nfix)

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernel_args.hpp"
@@ -125,10 +126,29 @@ struct MechState {
   }
 };
 
+// One DeviceState per GPU the library was initialised on (mistra_chem_init: one; mistra_chem_init_devices: several).
+// Slot 0 is the primary device: the one-cell Fortran entry points and mistra_chem_describe use it.
+struct DeviceState {
+  int id = -1;
+  MechState mech[3];
+  bool lds_configured[3] = {false, false, false};     // hipFuncAttributeMaxDynamicSharedMemorySize is per device
+  void release() {
+    if (id >= 0) (void)hipSetDevice(id);
+    for (auto& m : mech) m.release();
+    for (bool& c : lds_configured) c = false;
+    id = -1;
+  }
+};
+
 std::mutex g_mu;
 bool g_inited = false;
-int g_device = -1;
-MechState g_mech[3];
+std::vector<DeviceState> g_devs;
+
+DeviceState* device_slot(int hip_device) {
+  for (auto& d : g_devs)
+    if (d.id == hip_device) return &d;
+  return nullptr;
+}
 
 std::string mech_dir() {
   if (const char* e = std::getenv("MISTRA_MECH_DIR")) return e;
@@ -142,11 +162,7 @@ std::string mech_dir() {
   return "mech";
 }
 
-int default_nt(int mech) {
-  const char* names[3] = {"MISTRA_NT_GAS", "MISTRA_NT_AER", "MISTRA_NT_TOT"};
-  if (const char* e = std::getenv(names[mech])) return std::atoi(e);
-  return mech == MISTRA_MECH_GAS ? 128 : 512;
-}
+int default_nt(int mech) { return mech == MISTRA_MECH_GAS ? 128 : 512; }      // the workgroup sizes ros3_kernel.hip instantiates
 
 template <class MT>
 bool traits_match(const MechTables& t, int n_jnz, int tail_regs, bool scale_pass, const DenseTail& dense) {
@@ -154,8 +170,8 @@ bool traits_match(const MechTables& t, int n_jnz, int tail_regs, bool scale_pass
          t.nconst == MT::NCONST && n_jnz == MT::NJNZ;
 }
 
-int setup_mech(int mech) {
-  MechState& S = g_mech[mech];
+int setup_mech(DeviceState& D, int mech) {
+  MechState& S = D.mech[mech];
   std::string err;
   if (!S.tab.load(mech_dir() + "/" + kMechName[mech] + ".mech", &err)) return fail(err);
   S.nt = default_nt(mech);
@@ -200,11 +216,11 @@ int setup_mech(int mech) {
   return 0;
 }
 
-int launch(int mech, const KernelArgs& a, hipStream_t stream) {
+int launch(DeviceState& D, int mech, const KernelArgs& a, hipStream_t stream) {
   hipError_t e = hipErrorInvalidValue;
-  if (mech == MISTRA_MECH_GAS) e = launch_ros3<GasTraits, 128>(a, stream);
-  else if (mech == MISTRA_MECH_AER) e = launch_ros3<AerTraits, 512>(a, stream);
-  else e = launch_ros3<TotTraits, 512>(a, stream);
+  if (mech == MISTRA_MECH_GAS) e = launch_ros3<GasTraits, 128>(a, stream, &D.lds_configured[mech]);
+  else if (mech == MISTRA_MECH_AER) e = launch_ros3<AerTraits, 512>(a, stream, &D.lds_configured[mech]);
+  else e = launch_ros3<TotTraits, 512>(a, stream, &D.lds_configured[mech]);
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
   return 0;
 }
@@ -213,12 +229,14 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* th) {
   KernelArgs a;
   a.var_in = var_in; a.fix = fix; a.rconst = rconst; a.var_out = var_out; a.ierr = ierr; a.stats = stats;
-  a.texit_hexit = th; a.prof = nullptr; a.n_temps = S.n_temps; a.tin = tin; a.tout = tout; a.ncell = ncell;
+  a.texit_hexit = th; a.h_last = nullptr; a.prof = nullptr; a.n_temps = S.n_temps; a.tin = tin; a.tout = tout; a.ncell = ncell;
   a.consts = S.consts.p; a.fun_fac = S.fun_fac.p; a.jac_fac = S.jac_fac.p; a.jvs_pos = S.jvs_pos.p;
   a.zero_pos = S.zero_pos.p; a.diag_pos = S.diag_pos.p;
   a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev();
-  if (const char* cut = std::getenv("MISTRA_DIAG_LU_ROUNDS"))      // timing diagnostic only (tools/profile_lu_rounds.py): results are garbage
+#ifdef MISTRA_DIAG_ENV      // diagnostic builds only (tools/diag_dense.sh env): never in the product library
+  if (const char* cut = std::getenv("MISTRA_DIAG_LU_ROUNDS"))      // timing diagnostic (tools/profile_lu_rounds.py): results are garbage
     a.lu.nrounds = std::max(1, std::min(a.lu.nrounds, std::atoi(cut)));
+#endif
   a.solve_head_fwd = S.solve_head_fwd.dev(); a.solve_head_bwd = S.solve_head_bwd.dev();
   a.tail = TailDev{S.tail_fwd.p, S.tail_bwd.p};
   a.lu_scale = ScaleDev{S.lu_scale.p, S.lu_scale_slots, S.lu_scale_slots + VM_LOOKAHEAD_ROWS};
@@ -229,7 +247,89 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
 int check_call(int mech, int ncell) {
   if (mech < 0 || mech > 2) return fail("unknown mechanism id");
   if (ncell < 0) return fail("negative cell count");
-  if (!g_inited || !g_mech[mech].ready) return fail("mistra_chem_init has not been called (or failed)");
+  if (!g_inited || g_devs.empty() || !g_devs[0].mech[mech].ready) return fail("mistra_chem_init has not been called (or failed)");
+  return 0;
+}
+
+int init_locked(int n, const int* ids) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return fail("no HIP device available (this library has no CPU path)");
+  if (n <= 0 || n > count) return fail("device count out of range");
+  std::vector<int> want((size_t)n);
+  for (int i = 0; i < n; i++) {
+    want[(size_t)i] = ids ? ids[i] : i;
+    if (want[(size_t)i] < 0 || want[(size_t)i] >= count) return fail("device index out of range");
+    for (int j = 0; j < i; j++)
+      if (want[(size_t)j] == want[(size_t)i]) return fail("a device is listed twice");
+  }
+  bool same = g_inited && g_devs.size() == want.size();
+  for (size_t i = 0; same && i < want.size(); i++) same = g_devs[i].id == want[i];
+  if (same) {
+    HIP_TRY(hipSetDevice(g_devs[0].id));
+    return 0;
+  }
+  for (auto& d : g_devs) d.release();
+  g_devs.clear();
+  g_devs.resize(want.size());
+  g_inited = false;
+  for (size_t i = 0; i < want.size(); i++) {
+    HIP_TRY(hipSetDevice(want[i]));
+    g_devs[i].id = want[i];
+    for (int mech = 0; mech < 3; mech++)
+      if (int rc = setup_mech(g_devs[i], mech)) return rc;
+  }
+  HIP_TRY(hipSetDevice(g_devs[0].id));      // the calling thread ends up on the primary device
+  g_inited = true;
+  return 0;
+}
+
+// one device's share of a host-buffer call: upload, integrate, download (synchronous on that device)
+int integrate_host_on(DeviceState& D, int mech, int ncell, const double* var_in, const double* fix, const double* rconst, double tin,
+                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h) {
+  HIP_TRY(hipSetDevice(D.id));
+  MechState& S = D.mech[mech];
+  const size_t nv = (size_t)kDims[mech][0], nf = (size_t)kDims[mech][1], nr = (size_t)kDims[mech][2], nc = (size_t)ncell;
+  HIP_TRY(S.s_var.reserve(nc * nv));
+  HIP_TRY(S.s_fix.reserve(nc * nf));
+  HIP_TRY(S.s_rct.reserve(nc * nr));
+  HIP_TRY(S.s_ierr.reserve(nc));
+  HIP_TRY(S.s_stats.reserve(nc * 8));
+  if (t_h) HIP_TRY(S.s_th.reserve(nc * 3));
+  HIP_TRY(hipMemcpy(S.s_var.p, var_in, nc * nv * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S.s_fix.p, fix, nc * nf * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S.s_rct.p, rconst, nc * nr * sizeof(double), hipMemcpyHostToDevice));
+  KernelArgs a = make_args(S, ncell, S.s_var.p, S.s_fix.p, S.s_rct.p, tin, tout, S.s_var.p, S.s_ierr.p, S.s_stats.p, t_h ? S.s_th.p : nullptr);
+  if (t_h) a.h_last = S.s_th.p + 2 * nc;
+  // diagnostics: MISTRA_CHEM_PROFILE=1 prints where wave 0 of the workgroups spent its cycles (mean over the cells of the call)
+  DevBuf<unsigned long long> prof;
+  const bool profile = std::getenv("MISTRA_CHEM_PROFILE") != nullptr;
+  if (profile) {
+    HIP_TRY(prof.reserve(nc * kProfSlots));
+    a.prof = prof.p;
+  }
+  if (int rc = launch(D, mech, a, nullptr)) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  if (profile) {
+    std::vector<unsigned long long> h(nc * kProfSlots);
+    HIP_TRY(hipMemcpy(h.data(), prof.p, nc * kProfSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum[kProfSlots] = {0};
+    for (size_t c = 0; c < nc; c++)
+      for (int k = 0; k < kProfSlots; k++) sum[k] += (double)h[c * kProfSlots + k];
+    const char* names[kProfSlots] = {"fun", "jac", "prepare", "lu", "solve(rest)", "norm", "other", "total", "solve_head_fwd", "solve_tail", "solve_head_bwd", "lu_scale", "lu_dense", "-", "-", "-"};
+    std::fprintf(stderr, "[mistra_chem profile] %s, %zu cells, mean shader-clock ticks per cell:", kMechName[mech], nc);
+    for (int k = 0; k < 13; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
+    std::fprintf(stderr, "\n");
+    prof.release();
+  }
+  HIP_TRY(hipMemcpy(var_out, S.s_var.p, nc * nv * sizeof(double), hipMemcpyDeviceToHost));
+  if (ierr) HIP_TRY(hipMemcpy(ierr, S.s_ierr.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (stats) HIP_TRY(hipMemcpy(stats, S.s_stats.p, nc * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (t_h) {      // device: [ncell][2] (T, Hexit) then [ncell] (H)  ->  caller: [ncell][3]
+    std::vector<double> h(nc * 3);
+    HIP_TRY(hipMemcpy(h.data(), S.s_th.p, nc * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < nc; c++) { t_h[3 * c] = h[2 * c]; t_h[3 * c + 1] = h[2 * c + 1]; t_h[3 * c + 2] = h[2 * nc + c]; }
+  }
   return 0;
 }
 
@@ -251,30 +351,27 @@ int mistra_chem_dims(int mech, int* nvar, int* nfix, int* nreact, int* lu_nonzer
 int mistra_chem_init(int device) {
   std::lock_guard<std::mutex> lock(g_mu);
   g_err.clear();
-  int count = 0;
-  hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count <= 0) return fail("no HIP device available (this library has no CPU path)");
-  if (device < 0 || device >= count) return fail("device index out of range");
-  HIP_TRY(hipSetDevice(device));
-  if (g_inited && g_device == device) return 0;
-  for (auto& m : g_mech) m.release();
-  g_device = device;
-  for (int mech = 0; mech < 3; mech++)
-    if (int rc = setup_mech(mech)) return rc;
-  g_inited = true;
-  return 0;
+  return init_locked(1, &device);
 }
+
+int mistra_chem_init_devices(int n_devices, const int* device_ids) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_err.clear();
+  return init_locked(n_devices, device_ids);
+}
+
+int mistra_chem_device_count(void) { return g_inited ? (int)g_devs.size() : 0; }
 
 void mistra_chem_finalize(void) {
   std::lock_guard<std::mutex> lock(g_mu);
-  for (auto& m : g_mech) m.release();
+  for (auto& d : g_devs) d.release();
+  g_devs.clear();
   g_inited = false;
-  g_device = -1;
 }
 
 const char* mistra_chem_describe(int mech) {
-  if (mech < 0 || mech > 2 || !g_mech[mech].ready) return "";
-  return g_mech[mech].text.c_str();
+  if (mech < 0 || mech > 2 || !g_inited || g_devs.empty() || !g_devs[0].mech[mech].ready) return "";
+  return g_devs[0].mech[mech].text.c_str();
 }
 
 int mistra_chem_integrate_device(int mech, int ncell, const double* d_var_in, const double* d_fix, const double* d_rconst,
@@ -283,55 +380,73 @@ int mistra_chem_integrate_device(int mech, int ncell, const double* d_var_in, co
   if (int rc = check_call(mech, ncell)) return rc;
   if (ncell == 0) return 0;
   if (!d_var_in || !d_fix || !d_rconst || !d_var_out || !d_ierr || !d_stats) return fail("null device pointer");
-  KernelArgs a = make_args(g_mech[mech], ncell, d_var_in, d_fix, d_rconst, tin, tout, d_var_out, d_ierr, d_stats, d_texit_hexit);
-  return launch(mech, a, static_cast<hipStream_t>(hip_stream));
+  // the buffers decide the device: the call runs where d_var_in lives, which must be one of the initialised devices
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, d_var_in) != hipSuccess) return fail("d_var_in is not a device pointer");
+  DeviceState* D = device_slot(attr.device);
+  if (!D) return fail("the buffers live on device " + std::to_string(attr.device) + ", which mistra_chem_init(_devices) did not set up");
+  HIP_TRY(hipSetDevice(D->id));
+  KernelArgs a = make_args(D->mech[mech], ncell, d_var_in, d_fix, d_rconst, tin, tout, d_var_out, d_ierr, d_stats, d_texit_hexit);
+  return launch(*D, mech, a, static_cast<hipStream_t>(hip_stream));
 }
 
 int mistra_chem_integrate(int mech, int ncell, const double* var_in, const double* fix, const double* rconst, double tin,
                           double tout, double* var_out, int32_t* ierr, int32_t* stats) {
+  return mistra_chem_integrate_ex(mech, ncell, var_in, fix, rconst, tin, tout, var_out, ierr, stats, nullptr);
+}
+
+int mistra_chem_integrate_ex(int mech, int ncell, const double* var_in, const double* fix, const double* rconst, double tin,
+                             double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h) {
   if (int rc = check_call(mech, ncell)) return rc;
   if (ncell == 0) return 0;
   if (!var_in || !fix || !rconst || !var_out) return fail("null host pointer");
   std::lock_guard<std::mutex> lock(g_mu);
-  MechState& S = g_mech[mech];
-  const size_t nv = (size_t)kDims[mech][0], nf = (size_t)kDims[mech][1], nr = (size_t)kDims[mech][2], nc = (size_t)ncell;
-  HIP_TRY(S.s_var.reserve(nc * nv));
-  HIP_TRY(S.s_fix.reserve(nc * nf));
-  HIP_TRY(S.s_rct.reserve(nc * nr));
-  HIP_TRY(S.s_ierr.reserve(nc));
-  HIP_TRY(S.s_stats.reserve(nc * 8));
-  HIP_TRY(hipMemcpy(S.s_var.p, var_in, nc * nv * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(S.s_fix.p, fix, nc * nf * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(S.s_rct.p, rconst, nc * nr * sizeof(double), hipMemcpyHostToDevice));
-  KernelArgs a = make_args(S, ncell, S.s_var.p, S.s_fix.p, S.s_rct.p, tin, tout, S.s_var.p, S.s_ierr.p, S.s_stats.p, nullptr);
-  // diagnostics: MISTRA_CHEM_PROFILE=1 prints where wave 0 of the workgroups spent its cycles (mean over the cells of the call)
-  DevBuf<unsigned long long> prof;
-  const bool profile = std::getenv("MISTRA_CHEM_PROFILE") != nullptr;
-  if (profile) {
-    HIP_TRY(prof.reserve(nc * kProfSlots));
-    a.prof = prof.p;
+  const size_t nv = (size_t)kDims[mech][0], nf = (size_t)kDims[mech][1], nr = (size_t)kDims[mech][2];
+  const int ndev = (int)g_devs.size();
+  if (ndev == 1 || ncell < 2 * ndev) {
+    int rc = integrate_host_on(g_devs[0], mech, ncell, var_in, fix, rconst, tin, tout, var_out, ierr, stats, t_h);
+    (void)hipSetDevice(g_devs[0].id);
+    return rc;
   }
-  if (int rc = launch(mech, a, nullptr)) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  if (profile) {
-    std::vector<unsigned long long> h(nc * kProfSlots);
-    HIP_TRY(hipMemcpy(h.data(), prof.p, nc * kProfSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum[kProfSlots] = {0};
-    for (size_t c = 0; c < nc; c++)
-      for (int k = 0; k < kProfSlots; k++) sum[k] += (double)h[c * kProfSlots + k];
-    const char* names[kProfSlots] = {"fun", "jac", "prepare", "lu", "solve(rest)", "norm", "other", "total", "solve_head_fwd", "solve_tail", "solve_head_bwd", "lu_scale", "lu_dense", "-", "-", "-"};
-    std::fprintf(stderr, "[mistra_chem profile] %s, %zu cells, mean shader-clock ticks per cell:", kMechName[mech], nc);
-    for (int k = 0; k < 13; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
-    std::fprintf(stderr, "\n");
-    prof.release();
+  // several devices: contiguous blocks of cells, one host thread per device (cells are independent, kpp.f90:4310-4470:
+  // nothing is exchanged, every device uploads, integrates and downloads its own block)
+  std::vector<int> rcs((size_t)ndev, 0);
+  std::vector<std::string> errs((size_t)ndev);
+  std::vector<std::thread> workers;
+  for (int d = 0; d < ndev; d++) {
+    const int per = ncell / ndev, rem = ncell % ndev;
+    const size_t start = (size_t)d * per + (size_t)std::min(d, rem);
+    const int count = per + (d < rem ? 1 : 0);
+    workers.emplace_back([=, &rcs, &errs]() {
+      rcs[(size_t)d] = integrate_host_on(g_devs[(size_t)d], mech, count, var_in + start * nv, fix + start * nf, rconst + start * nr, tin, tout,
+                                         var_out + start * nv, ierr ? ierr + start : nullptr, stats ? stats + start * 8 : nullptr, t_h ? t_h + start * 3 : nullptr);
+      if (rcs[(size_t)d]) errs[(size_t)d] = g_err;      // g_err is thread-local: carry the text to the caller's thread
+    });
   }
-  HIP_TRY(hipMemcpy(var_out, S.s_var.p, nc * nv * sizeof(double), hipMemcpyDeviceToHost));
-  if (ierr) HIP_TRY(hipMemcpy(ierr, S.s_ierr.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (stats) HIP_TRY(hipMemcpy(stats, S.s_stats.p, nc * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (auto& w : workers) w.join();
+  (void)hipSetDevice(g_devs[0].id);
+  for (int d = 0; d < ndev; d++)
+    if (rcs[(size_t)d]) return fail("device " + std::to_string(g_devs[(size_t)d].id) + ": " + errs[(size_t)d]);
   return 0;
 }
 
-int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tout) {
+// text of ros_ErrorMsg_x (gas.f:1474-1509) for an error code
+static const char* ros_error_text(int code) {
+  switch (code) {
+    case -1: return "--> Improper value for maximal no of steps";
+    case -2: return "--> Selected Rosenbrock method not implemented";
+    case -3: return "--> Hmin/Hmax/Hstart must be positive";
+    case -4: return "--> FacMin/FacMax/FacRej must be positive";
+    case -5: return "--> Improper tolerance values";
+    case -6: return "--> No of steps exceeds maximum bound";
+    case -7: return "--> Step size too small: T + 10*H = T or H < Roundoff";
+    case -8: return "--> Matrix is repeatedly singular";
+  }
+  return nullptr;
+}
+
+int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, double* tout, int32_t* ierr_out, double* t_err,
+                                        double* h_err, int32_t* nsng) {
   if (!g_inited) {   // the Fortran caller has no init hook: first use selects the device (env MISTRA_CHEM_DEVICE, default 0)
     const char* dev = std::getenv("MISTRA_CHEM_DEVICE");
     if (int rc = mistra_chem_init(dev ? std::atoi(dev) : 0)) return rc;
@@ -346,13 +461,15 @@ int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tou
   double* stepmin = rtol + nv;
   for (int i = 0; i < nv; i++) { rtol[i] = 1.0e-3; atol[i] = 1.0e-25; }   // INTEGRATE_x, gas.f:745-746
   int32_t ierr = 0;
-  MechState& S = g_mech[mech];
+  DeviceState& D = g_devs[0];
+  MechState& S = D.mech[mech];
   {
     // One call = one cell: what costs here is synchronisation, not bytes.  /GDATA_x/ holds C and RCONST back to back, so
     // the inputs go up in ONE copy from a pinned mirror and everything the kernel writes comes back in ONE, on a private
     // stream with a single wait (seven blocking calls before: 340 us per gas call, of which the kernel is a fraction).
     std::lock_guard<std::mutex> lock(g_mu);
-    const size_t n_in = (size_t)(nv + nf + nr), n_out = (size_t)nv + 2 + 5;       // out tail: 9 int32 in 5 doubles
+    HIP_TRY(hipSetDevice(D.id));
+    const size_t n_in = (size_t)(nv + nf + nr), n_out = (size_t)nv + 2 + 1 + 5;       // VAR | Texit Hexit | H at exit | 9 int32 in 5 doubles
     if (!S.one_dev) {
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&S.one_dev), (n_in + n_out) * sizeof(double)));
       HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S.one_host), (n_in + n_out) * sizeof(double), hipHostMallocDefault));
@@ -361,18 +478,39 @@ int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tou
     std::memcpy(S.one_host, c, n_in * sizeof(double));
     HIP_TRY(hipMemcpyAsync(S.one_dev, S.one_host, n_in * sizeof(double), hipMemcpyHostToDevice, S.one_stream));
     double* d_out = S.one_dev + n_in;
-    int32_t* d_stats = reinterpret_cast<int32_t*>(d_out + nv + 2);
+    int32_t* d_stats = reinterpret_cast<int32_t*>(d_out + nv + 3);
     KernelArgs a = make_args(S, 1, S.one_dev, S.one_dev + nv, S.one_dev + nv + nf, *tin, *tout, d_out, d_stats + 8, d_stats, d_out + nv);
-    if (int rc = launch(mech, a, S.one_stream)) return rc;
+    a.h_last = d_out + nv + 2;
+    if (int rc = launch(D, mech, a, S.one_stream)) return rc;
     double* h_out = S.one_host + n_in;
     HIP_TRY(hipMemcpyAsync(h_out, d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, S.one_stream));
     HIP_TRY(hipStreamSynchronize(S.one_stream));
     std::memcpy(c, h_out, (size_t)nv * sizeof(double));
-    std::memcpy(&ierr, reinterpret_cast<const int32_t*>(h_out + nv + 2) + 8, sizeof ierr);
-    if (ierr < 0)   // the reference prints and continues (gas.f:764-767)
-      std::printf(" Rosenbrock: Unsucessful step at T=%g (IERR=%d)\n", *tin, ierr);
+    const int32_t* st = reinterpret_cast<const int32_t*>(h_out + nv + 3);
+    std::memcpy(&ierr, st + 8, sizeof ierr);
+    if (ierr_out) *ierr_out = ierr;
+    if (nsng) *nsng = st[7];
+    if (t_err) *t_err = h_out[nv];         // T when the integrator returned
+    if (h_err) *h_err = h_out[nv + 2];     // H when the integrator returned (what ros_ErrorMsg_x prints)
     *tin = h_out[nv];          // TIN = RPAR(11), exit time
     *stepmin = h_out[nv + 1];  // STEPMIN = RPAR(12), last step
+  }
+  return 0;
+}
+
+int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tout) {
+  int32_t ierr = 1, nsng = 0;
+  double t_err = 0.0, h_err = 0.0;
+  const double tin_in = tin ? *tin : 0.0;
+  if (int rc = mistra_chem_integrate_common_status(mech, gdata, tin, tout, &ierr, &t_err, &h_err, &nsng)) return rc;
+  if (ierr < 0) {   // the reference prints and continues (ros_ErrorMsg_x gas.f:1474-1509, INTEGRATE_x gas.f:764-767);
+                    // a Fortran caller gets the same lines from unit 6 through shim/mistra_kpp_shim.f90
+    const char sfx = "gat"[mech];
+    std::printf(" Forced exit from Rosenbrock_%c due to the following error:\n", sfx);
+    if (const char* txt = ros_error_text(ierr)) std::printf(" %s\n", txt);
+    else std::printf("       Unknown Error code: %4d\n", ierr);
+    std::printf("        T=%15.7E and H=%15.7E\n", t_err, h_err);
+    std::printf(" Rosenbrock: Unsucessful step at T= %g  (IERR= %d )\n", tin_in, ierr);
   }
   return 0;
 }

@@ -43,6 +43,7 @@ struct KernelArgs {
   int32_t* ierr;               // [ncell]         1 = success, <0 = ros_ErrorMsg code (gas.f:1474)
   int32_t* stats;              // [ncell][8]      Nfun,Njac,Nstp,Nacc,Nrej,Ndec,Nsol,Nsng  (COMMON /Statistics/)
   double* texit_hexit;         // [ncell][2] or null: what INTEGRATE_x leaves in TIN and STEPMIN
+  double* h_last;              // [ncell] or null: the step size H when the integrator returned (ros_ErrorMsg_x prints it, gas.f:1506)
   unsigned long long* prof;    // [ncell][kProfSlots] or null: shader-clock cycles per phase (diagnostics, see capi.cpp)
   double tin, tout;
   int32_t ncell;

@@ -1104,14 +1104,15 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       GM_(a.texit_hexit)[(size_t)cell * 2] = T;
       GM_(a.texit_hexit)[(size_t)cell * 2 + 1] = Hexit;
     }
+    if (a.h_last) GM_(a.h_last)[cell] = H;
   }
 }
 
 // ---- launchers (one explicit instantiation per supported <mechanism, workgroup size>)
 template <class MT, int NT>
-hipError_t launch_ros3(const KernelArgs& a, hipStream_t stream) {
+hipError_t launch_ros3(const KernelArgs& a, hipStream_t stream, bool* lds_configured) {
   constexpr size_t lds_bytes = LdsLayout<MT, NT>::TOTAL * sizeof(double);
-  static bool configured = false;
+  bool& configured = *lds_configured;      // per device (capi.cpp: DeviceState): the attribute is a property of the device's code object
   auto kern = ros3_integrate_kernel<MT, NT, false>;
   auto kern_prof = ros3_integrate_kernel<MT, NT, true>;      // MISTRA_CHEM_PROFILE diagnostics (capi.cpp)
   if (!configured) {
@@ -1138,9 +1139,9 @@ extern "C" int mistra_diag_dense_stamps(unsigned long long* out16, int reset) {
 }
 #endif
 
-template hipError_t launch_ros3<GasTraits, 128>(const KernelArgs&, hipStream_t);
-template hipError_t launch_ros3<AerTraits, 512>(const KernelArgs&, hipStream_t);
-template hipError_t launch_ros3<TotTraits, 512>(const KernelArgs&, hipStream_t);
+template hipError_t launch_ros3<GasTraits, 128>(const KernelArgs&, hipStream_t, bool*);
+template hipError_t launch_ros3<AerTraits, 512>(const KernelArgs&, hipStream_t, bool*);
+template hipError_t launch_ros3<TotTraits, 512>(const KernelArgs&, hipStream_t, bool*);
 // (a 1024-thread tot variant was measured slower, and instantiating it caps the register budget of the shared
 //  non-inlined device functions at that of a 16-wave workgroup)
 

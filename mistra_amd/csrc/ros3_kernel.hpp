@@ -40,6 +40,6 @@ struct LdsLayout {
 };
 
 template <class MT, int NT>
-hipError_t launch_ros3(const KernelArgs& a, hipStream_t stream);
+hipError_t launch_ros3(const KernelArgs& a, hipStream_t stream, bool* lds_configured);
 
 }  // namespace mistra

@@ -14,6 +14,17 @@ namespace mistra {
 
 namespace {
 
+// Schedule-compiler switches for same-box A/B measurements.  They change the programs (and with them round-off), so the
+// product library does not read the environment: only a diagnostic build (-DMISTRA_DIAG_ENV, tools/diag_dense.sh env) does.
+inline const char* diag_env(const char* name) {
+#ifdef MISTRA_DIAG_ENV
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 struct Item {            // one chunk of one entry inside one round
   int entry;
   int first, count;      // range of entry.upd
@@ -59,7 +70,7 @@ int lds_pass_cycles(const int* cell64) {
 std::vector<int> deal(const std::vector<Item>& items, const std::vector<VmEntry>& entries, int nt) {
   const int n = (int)items.size();
   std::vector<int> lane((size_t)n);
-  static const bool plain_deal = std::getenv("MISTRA_DIAG_PLAIN_DEAL") != nullptr;   // A/B diagnostic: positions as sorted
+  static const bool plain_deal = diag_env("MISTRA_DIAG_PLAIN_DEAL") != nullptr;   // A/B diagnostic: positions as sorted
   const int waves_used = std::max(1, std::min(nt / 64, (n + 63) / 64));
   const int lanes = waves_used * 64, groups = lanes / 32;
   auto nrec = [](const Item& it) { return std::max(1, (it.count + VM_UPD_PER_REC - 1) / VM_UPD_PER_REC); };
@@ -200,7 +211,7 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
     // rounds up to the entry's last burst, the backlog carried forward: same updates, same order, same arithmetic, and
     // nothing is final later than before (the entry's last chunk stays where it was).
     {
-      static const int smooth = std::getenv("MISTRA_DIAG_SMOOTH") ? std::atoi(std::getenv("MISTRA_DIAG_SMOOTH")) : 1;
+      static const int smooth = diag_env("MISTRA_DIAG_SMOOTH") ? std::atoi(diag_env("MISTRA_DIAG_SMOOTH")) : 1;
       int last_burst = -1;
       for (size_t k = 0; k + 1 < chunks.size(); k++)
         if (chunks[k].count >= 2 * VM_UPD_PER_REC) last_burst = (int)k;
@@ -277,7 +288,7 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
     // of rows, that record goes to a wave with fewer: it swaps lanes with an equally long item there (no lane's row count
     // changes), and the division runs while the fuller waves walk their extra row.
     {
-      static const bool no_rcp_move = std::getenv("MISTRA_DIAG_NO_RCP_MOVE") != nullptr;     // A/B diagnostic
+      static const bool no_rcp_move = diag_env("MISTRA_DIAG_NO_RCP_MOVE") != nullptr;     // A/B diagnostic
       std::vector<int> lane_rows((size_t)nt, 0);
       for (size_t k = 0; k < items.size(); k++) lane_rows[(size_t)lane[k]] += nrec(items[k]);
       const int nw = nt / 64;
@@ -847,9 +858,9 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   {
     std::vector<VmEntry> fwd = solve_head_fwd_entries(m, lay, S.tail.h);
     // forward: long head-column dot products of the tail rows cut into partial sums (tail rows carry up to 42 terms)
-    static const int fwd_split = std::getenv("MISTRA_DIAG_FWD_SPLIT") ? std::atoi(std::getenv("MISTRA_DIAG_FWD_SPLIT")) : 6;
+    static const int fwd_split = diag_env("MISTRA_DIAG_FWD_SPLIT") ? std::atoi(diag_env("MISTRA_DIAG_FWD_SPLIT")) : 6;
     S.n_temps = split_long_entries(fwd, lay, fwd_split, 0);
-    static const int bwd_split = std::getenv("MISTRA_DIAG_BWD_SPLIT") ? std::atoi(std::getenv("MISTRA_DIAG_BWD_SPLIT")) : 4;
+    static const int bwd_split = diag_env("MISTRA_DIAG_BWD_SPLIT") ? std::atoi(diag_env("MISTRA_DIAG_BWD_SPLIT")) : 4;
     int bwd_temps = 0;
     std::vector<VmEntry> bwd = solve_head_bwd_entries(m, lay, S.tail.h, bwd_split, S.n_temps, &bwd_temps);
     S.n_temps += bwd_temps;

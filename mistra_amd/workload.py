@@ -1,7 +1,8 @@
 """Synthetic cell batches for the benchmark and the large-size tests.
 
-Base states are real chemistry states captured from the running reference model (tests/golden/integrate_<mech>.npz:
-VAR, FIX, RCONST of INTEGRATE_x calls in the cloudy layers of namelist.BTZ96).  Cell c of a batch takes base state
+Base states are real chemistry states captured from the running reference model (mistra_amd/data/base_<mech>.npz: VAR, FIX,
+RCONST of INTEGRATE_x calls in the cloudy layers of namelist.BTZ96 — the inputs of tests/golden/integrate_<mech>.npz, written
+next to them by tests/golden/make_golden.py).  Cell c of a batch takes base state
 c mod nbase and perturbs it with a counter-based generator keyed by (seed, c, index):
 
     VAR_i    <- VAR_i    * exp(sigma * g),   g ~ N(0,1)       sigma   = 0.10
@@ -20,7 +21,7 @@ import torch
 SEED = 20260101
 SIGMA = 0.10
 EPS = 0.05
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 _M1 = -7046029254386353131      # 0x9E3779B97F4A7C15 as int64
 _M2 = -4658895280553007687      # 0xBF58476D1CE4E5B9
@@ -47,8 +48,8 @@ def _uniform(seed, cell, index, stream):
 
 def load_base(mech):
     """(var, fix, rconst) numpy arrays [nbase, .] of the captured reference states"""
-    z = np.load(os.path.join(GOLDEN_DIR, "integrate_%s.npz" % mech))
-    return z["var_in"], z["fix"], z["rconst"]
+    z = np.load(os.path.join(DATA_DIR, "base_%s.npz" % mech))
+    return z["var"], z["fix"], z["rconst"]
 
 
 def make_batch(mech, cell_start, ncell, device, seed=SEED, sigma=SIGMA, eps=EPS, base=None):

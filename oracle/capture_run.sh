@@ -10,8 +10,10 @@ REFROOT="${MISTRA_REFERENCE:-/root/reference}"
 CASE="$1"; HOURS="$2"; shift 2
 RUN="$HERE/_ref/run_${CASE}${MISTRA_RUN_TAG:-}"
 rm -rf "$RUN/out"; mkdir -p "$RUN/out"
+# MISTRA_NAMELIST_SED: one more sed expression for the copy, e.g. 's/^\( *nuc *= *\)T/\1F/' for a case that ships with nucleation
+# on (oracle/column_driver.f90 sequences the model without the nucleation module)
 sed -e 's/^\( *netcdf *= *\)T/\1F/' -e 's/^\( *chem *= *\)F/\1T/' -e "s/^\( *lstmax *= *\)[0-9]*/\1$HOURS/" \
-    "$REFROOT/namelists/namelist.$CASE" > "$RUN/namelist"
+    -e "${MISTRA_NAMELIST_SED:-s/^$//}" "$REFROOT/namelists/namelist.$CASE" > "$RUN/namelist"
 cd "$RUN"
 env INPDIR="$REFROOT/input/" MECHDIR="$REFROOT/src/mech/" OUTDIR="$RUN/out/" NAMELIST="$RUN/namelist" \
     MISTRA_CAPTURE_FILE="$HERE/_ref/capture_${CASE}${MISTRA_RUN_TAG:-}.bin" "$@" "$HERE/_ref/mistra_capture" > "$RUN/stdout.log" 2> "$RUN/stderr.log"

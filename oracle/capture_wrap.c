@@ -10,6 +10,10 @@
  *   MISTRA_CAPTURE_SKIP_x first calls of mechanism x (g|a|t) to skip      (default 0)
  *   MISTRA_CAPTURE_EVERY_x keep every n-th call of mechanism x after that (default 1)
  *   MISTRA_CAPTURE_MAX_x  stop after this many records of mechanism x     (default 64)
+ *   MISTRA_CAPTURE_SEQ_FROM / MISTRA_CAPTURE_SEQ_TO   whole column steps: keep EVERY call, whatever its mechanism, whose
+ *                         position in the model's sequence of INTEGRATE_x calls is in [FROM, TO); the record's call
+ *                         number is then that global position (kpp_driver calls one of the three per layer and 10-s
+ *                         step, kpp.f90:4310-4470, so a column step is a run of consecutive positions)
  * A one-line call/step census per mechanism is printed at exit.
  */
 #include <stdio.h>
@@ -32,6 +36,8 @@ static FILE *fp;
 static long ncall[3], nrec[3], nstep_tot[3];
 static long skip[3], every[3] = {1, 1, 1}, maxrec[3] = {64, 64, 64};
 static int inited;
+static long seq, seq_from = -1, seq_to = -1;      /* global call position and the window kept (SEQ mode) */
+static long this_seq;
 
 static void census(void) {
   static const char *nm[3] = {"gas", "aer", "tot"};
@@ -58,11 +64,15 @@ static void init(void) {
     maxrec[m] = envl("MISTRA_CAPTURE_MAX", sfx[m], 64);
     if (every[m] < 1) every[m] = 1;
   }
+  if (getenv("MISTRA_CAPTURE_SEQ_FROM")) seq_from = atol(getenv("MISTRA_CAPTURE_SEQ_FROM"));
+  if (getenv("MISTRA_CAPTURE_SEQ_TO")) seq_to = atol(getenv("MISTRA_CAPTURE_SEQ_TO"));
   atexit(census);
 }
 
 static int want(int m) {
   long n = ncall[m]++;
+  this_seq = seq++;
+  if (seq_from >= 0) return fp && this_seq >= seq_from && this_seq < seq_to;
   if (!fp || nrec[m] >= maxrec[m] || n < skip[m]) return 0;
   return ((n - skip[m]) % every[m]) == 0;
 }
@@ -71,7 +81,7 @@ static int want(int m) {
  *         {tin, tout, c_in[nvar+nfix], rconst[nreact], var_out[nvar], tin_out, stepmin_out}                       */
 static void write_rec(int m, int nvar, int nfix, int nreact, double tin, double tout, const double *c_in,
                       const double *rconst, const double *var_out, double tin_out, double stepmin_out) {
-  int32_t h[6] = {0x4d495354, m, nvar, nfix, nreact, (int32_t)(ncall[m] - 1)};
+  int32_t h[6] = {0x4d495354, m, nvar, nfix, nreact, (int32_t)(seq_from >= 0 ? this_seq : ncall[m] - 1)};
   fwrite(h, sizeof h, 1, fp);
   fwrite(&statistics_, sizeof statistics_, 1, fp);
   fwrite(&tin, 8, 1, fp);

@@ -1,6 +1,8 @@
 ! Fortran side of the drop-in boundary: the reference's own subroutine surface,
 !     SUBROUTINE INTEGRATE_g / INTEGRATE_a / INTEGRATE_t (TIN, TOUT)          gas.f:710 | aer.f:1408 | tot.f:2812
-! implemented on top of the C ABI (include/mistra_chem.h) through ISO_C_BINDING.
+! implemented on top of the C ABI (include/mistra_chem.h) through ISO_C_BINDING, plus the batched form a two-pass
+! kpp_driver calls once per mechanism and 10-s step (INTEGRATION.md):
+!     SUBROUTINE INTEGRATE_BATCH_g / _a / _t (NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
 !
 ! Same names, same two REAL*8 arguments by reference, same data path: everything else travels through
 ! COMMON /GDATA_x/, whose member order is restated below from gas_Global.h:29-58 (aer_Global.h, tot_Global.h alike):
@@ -9,18 +11,38 @@
 ! Update_RCONST_x, the budgets and kpp_driver stay untouched (INTEGRATION.md shows the link line and the
 ! link-time alternative that needs no source edit).  Behaviour kept from the reference: VAR is advanced in place,
 ! TIN returns the exit time, STEPMIN the last step, RTOL/ATOL are (re)set to 1e-3 / 1e-25, an unsuccessful
-! integration prints a message and the model carries on (gas.f:764-767).
+! integration writes the lines of ros_ErrorMsg_x (gas.f:1474-1509) and of INTEGRATE_x (gas.f:764-767) to unit 6 and the
+! model carries on.  Not reproduced: the 'Warning: LU Decomposition returned ising =' line of ros_PrepareMatrix_x
+! (gas.f:1456) names the row of the zero pivot, which the kernel does not report; the shim prints the line once per
+! occurrence without the row.
 module mistra_chem_c_api
   use iso_c_binding
   implicit none
   interface
-     function mistra_chem_integrate_common(mech, gdata, tin, tout) bind(C, name="mistra_chem_integrate_common") result(rc)
-       import :: c_int, c_ptr, c_double
+     function mistra_chem_integrate_common_status(mech, gdata, tin, tout, ierr, t_err, h_err, nsng) &
+          bind(C, name="mistra_chem_integrate_common_status") result(rc)
+       import :: c_int, c_ptr, c_double, c_int32_t
        integer(c_int), value :: mech
        type(c_ptr), value :: gdata
-       real(c_double) :: tin, tout
+       real(c_double) :: tin, tout, t_err, h_err
+       integer(c_int32_t) :: ierr, nsng
        integer(c_int) :: rc
-     end function mistra_chem_integrate_common
+     end function mistra_chem_integrate_common_status
+     function mistra_chem_integrate_ex(mech, ncell, var_in, fix, rconst, tin, tout, var_out, ierr, stats, t_h) &
+          bind(C, name="mistra_chem_integrate_ex") result(rc)
+       import :: c_int, c_double, c_int32_t
+       integer(c_int), value :: mech, ncell
+       real(c_double), value :: tin, tout
+       real(c_double) :: var_in(*), fix(*), rconst(*), var_out(*), t_h(*)
+       integer(c_int32_t) :: ierr(*), stats(*)
+       integer(c_int) :: rc
+     end function mistra_chem_integrate_ex
+     function mistra_chem_init_devices(n_devices, device_ids) bind(C, name="mistra_chem_init_devices") result(rc)
+       import :: c_int, c_ptr
+       integer(c_int), value :: n_devices
+       type(c_ptr), value :: device_ids
+       integer(c_int) :: rc
+     end function mistra_chem_init_devices
      function mistra_chem_last_error() bind(C, name="mistra_chem_last_error") result(msg)
        import :: c_ptr
        type(c_ptr) :: msg
@@ -40,6 +62,84 @@ contains
     write (0, *)
     stop 'mistra_chem: GPU integrator unavailable (there is no CPU fallback)'
   end subroutine mistra_chem_fail
+
+  ! Use the first n GPUs of the node for the batched calls (one block of cells and one host thread per device inside the
+  ! library).  Optional: without it the first call initialises device MISTRA_CHEM_DEVICE (default 0).
+  subroutine mistra_chem_use_devices(n)
+    integer, intent(in) :: n
+    if (mistra_chem_init_devices(int(n, c_int), c_null_ptr) /= 0) call mistra_chem_fail('mistra_chem_init_devices')
+  end subroutine mistra_chem_use_devices
+
+  ! The reference's messages for an unsuccessful integration, statement by statement: ros_ErrorMsg_x (gas.f:1474-1509)
+  ! and the PRINT of INTEGRATE_x (gas.f:764-767).  sfx = 'g' | 'a' | 't'.
+  subroutine mistra_chem_report(sfx, code, t, h, tin, nsng)
+    character(len=1), intent(in) :: sfx
+    integer, intent(in) :: code, nsng
+    double precision, intent(in) :: t, h, tin
+    integer :: i
+    do i = 1, nsng
+       print *, 'Warning: LU Decomposition returned ising /= 0'
+    end do
+    if (code >= 0) return
+    write (6, *) 'Forced exit from Rosenbrock_'//sfx//' due to the following error:'
+    if (code == -1) then
+       write (6, *) '--> Improper value for maximal no of steps'
+    else if (code == -2) then
+       write (6, *) '--> Selected Rosenbrock method not implemented'
+    else if (code == -3) then
+       write (6, *) '--> Hmin/Hmax/Hstart must be positive'
+    else if (code == -4) then
+       write (6, *) '--> FacMin/FacMax/FacRej must be positive'
+    else if (code == -5) then
+       write (6, *) '--> Improper tolerance values'
+    else if (code == -6) then
+       write (6, *) '--> No of steps exceeds maximum bound'
+    else if (code == -7) then
+       write (6, *) '--> Step size too small: T + 10*H = T', ' or H < Roundoff'
+    else if (code == -8) then
+       write (6, *) '--> Matrix is repeatedly singular'
+    else
+       write (6, 102) 'Unknown Error code: ', code
+    end if
+102 format('       ', A, I4)
+    write (6, 103) t, h
+103 format('        T=', E15.7, ' and H=', E15.7)
+    print *, 'Rosenbrock: Unsucessful step at T=', tin, ' (IERR=', code, ')'
+  end subroutine mistra_chem_report
+
+  ! the three one-cell routines and the three batched ones differ in sizes only
+  subroutine integrate_one(mech, sfx, gdata, TIN, TOUT)
+    integer, intent(in) :: mech
+    character(len=1), intent(in) :: sfx
+    type(c_ptr), intent(in) :: gdata
+    real(c_double) :: TIN, TOUT
+    integer(c_int32_t) :: ierr, nsng
+    real(c_double) :: t_err, h_err, tin_in
+    tin_in = TIN
+    if (mistra_chem_integrate_common_status(int(mech, c_int), gdata, TIN, TOUT, ierr, t_err, h_err, nsng) /= 0) &
+         call mistra_chem_fail('INTEGRATE_'//sfx)
+    if (ierr < 0 .or. nsng > 0) call mistra_chem_report(sfx, int(ierr), t_err, h_err, tin_in, int(nsng))
+  end subroutine integrate_one
+
+  subroutine integrate_batch(mech, sfx, NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+    integer, intent(in) :: mech, NCELL
+    character(len=1), intent(in) :: sfx
+    real(c_double) :: VAR(*), FIX(*), RCONST(*), TEXIT(NCELL), HEXIT(NCELL)
+    real(c_double), intent(in) :: TIN, TOUT
+    integer(c_int32_t) :: IERR(NCELL), ISTAT(8, NCELL)
+    real(c_double), allocatable :: th(:, :)
+    integer :: k
+    if (NCELL <= 0) return
+    allocate (th(3, NCELL))
+    if (mistra_chem_integrate_ex(int(mech, c_int), int(NCELL, c_int), VAR, FIX, RCONST, TIN, TOUT, VAR, IERR, ISTAT, th) /= 0) &
+         call mistra_chem_fail('INTEGRATE_BATCH_'//sfx)
+    do k = 1, NCELL            ! the messages in layer order, as the serial loop would have written them
+       TEXIT(k) = th(1, k)
+       HEXIT(k) = th(2, k)
+       if (IERR(k) < 0 .or. ISTAT(8, k) > 0) call mistra_chem_report(sfx, int(IERR(k)), th(1, k), th(3, k), TIN, int(ISTAT(8, k)))
+    end do
+    deallocate (th)
+  end subroutine integrate_batch
 end module mistra_chem_c_api
 
 subroutine INTEGRATE_g(TIN, TOUT)
@@ -51,7 +151,7 @@ subroutine INTEGRATE_g(TIN, TOUT)
   real(c_double), target :: C(NVAR + NFIX)
   real(c_double) :: RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX
   common /GDATA_g/ C, RCONST, TIME, DT, ATOL, RTOL, STEPMIN, STEPMAX
-  if (mistra_chem_integrate_common(0_c_int, c_loc(C), TIN, TOUT) /= 0) call mistra_chem_fail('INTEGRATE_g')
+  call integrate_one(0, 'g', c_loc(C), TIN, TOUT)
 end subroutine INTEGRATE_g
 
 subroutine INTEGRATE_a(TIN, TOUT)
@@ -63,7 +163,7 @@ subroutine INTEGRATE_a(TIN, TOUT)
   real(c_double), target :: C(NVAR + NFIX)
   real(c_double) :: RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX
   common /GDATA_a/ C, RCONST, TIME, DT, ATOL, RTOL, STEPMIN, STEPMAX
-  if (mistra_chem_integrate_common(1_c_int, c_loc(C), TIN, TOUT) /= 0) call mistra_chem_fail('INTEGRATE_a')
+  call integrate_one(1, 'a', c_loc(C), TIN, TOUT)
 end subroutine INTEGRATE_a
 
 subroutine INTEGRATE_t(TIN, TOUT)
@@ -75,5 +175,40 @@ subroutine INTEGRATE_t(TIN, TOUT)
   real(c_double), target :: C(NVAR + NFIX)
   real(c_double) :: RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX
   common /GDATA_t/ C, RCONST, TIME, DT, ATOL, RTOL, STEPMIN, STEPMAX
-  if (mistra_chem_integrate_common(2_c_int, c_loc(C), TIN, TOUT) /= 0) call mistra_chem_fail('INTEGRATE_t')
+  call integrate_one(2, 't', c_loc(C), TIN, TOUT)
 end subroutine INTEGRATE_t
+
+! ---- batched form: what INTEGRATE_x does to COMMON /GDATA_x/, for NCELL cells at once.
+!   VAR(NVAR,NCELL)  in: concentrations, out: after [TIN, TOUT]            (C(1:NVAR) of each cell)
+!   FIX(NFIX,NCELL), RCONST(NREACT,NCELL)  in                              (C(NVAR+1:NSPEC), RCONST of each cell)
+!   TEXIT(NCELL), HEXIT(NCELL)  out: what the serial call leaves in TIN and STEPMIN (gas.f:769-770)
+!   IERR(NCELL)  out: 1 or the negative code of ros_ErrorMsg_x;  ISTAT(8,NCELL) out: COMMON /Statistics/ per cell
+subroutine INTEGRATE_BATCH_g(NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+  use iso_c_binding
+  use mistra_chem_c_api
+  implicit none
+  integer :: NCELL
+  real(c_double) :: VAR(102, *), FIX(3, *), RCONST(331, *), TIN, TOUT, TEXIT(*), HEXIT(*)
+  integer(c_int32_t) :: IERR(*), ISTAT(8, *)
+  call integrate_batch(0, 'g', NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+end subroutine INTEGRATE_BATCH_g
+
+subroutine INTEGRATE_BATCH_a(NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+  use iso_c_binding
+  use mistra_chem_c_api
+  implicit none
+  integer :: NCELL
+  real(c_double) :: VAR(257, *), FIX(5, *), RCONST(979, *), TIN, TOUT, TEXIT(*), HEXIT(*)
+  integer(c_int32_t) :: IERR(*), ISTAT(8, *)
+  call integrate_batch(1, 'a', NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+end subroutine INTEGRATE_BATCH_a
+
+subroutine INTEGRATE_BATCH_t(NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+  use iso_c_binding
+  use mistra_chem_c_api
+  implicit none
+  integer :: NCELL
+  real(c_double) :: VAR(417, *), FIX(7, *), RCONST(1627, *), TIN, TOUT, TEXIT(*), HEXIT(*)
+  integer(c_int32_t) :: IERR(*), ISTAT(8, *)
+  call integrate_batch(2, 't', NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+end subroutine INTEGRATE_BATCH_t

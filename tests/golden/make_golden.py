@@ -40,12 +40,60 @@ SETS = {
 }
 
 
+# whole column steps: EVERY INTEGRATE_x call of kpp_driver's layer loop (kpp.f90:4310-4470) for one or two 10-s steps, in
+# the model's call order, whatever mechanism each layer ran (BASELINE.json configs[4]: 148 cells per step)
+COLUMN_SETS = {
+    "Joyce2014": (os.path.join(REF, "capture_Joyce2014_basecase_col.bin"),
+                  "reference namelist.Joyce2014_basecase (netcdf=F; nuc=T -> F: oracle/column_driver.f90 sequences the model without the "
+                  "nucleation module; lstmax=1), column steps 180 and 181 of the first model hour (all 148 layers run the gas mechanism); "
+                  "MISTRA_RUN_TAG=_col MISTRA_NAMELIST_SED='s/^\\( *nuc *= *\\)T/\\1F/' oracle/capture_run.sh Joyce2014_basecase 1 "
+                  "MISTRA_CAPTURE_SEQ_FROM=26640 MISTRA_CAPTURE_SEQ_TO=26936"),
+    "base1": (os.path.join(REF, "capture_base1_col.bin"),
+              "reference namelist.base1 (netcdf=F, lstmax=1), column step 300 of the first model hour (79 layers run gas, 69 aer); "
+              "MISTRA_RUN_TAG=_col oracle/capture_run.sh base1 1 MISTRA_CAPTURE_SEQ_FROM=44400 MISTRA_CAPTURE_SEQ_TO=44548"),
+    "BTZ96": (os.path.join(REF, "capture_BTZ96_col.bin"),
+              "reference namelist.BTZ96 (chem=F -> T, netcdf=F, lstmax=1), column step 150 of the first model hour (stratus: gas, aer "
+              "and tot layers); MISTRA_RUN_TAG=_col oracle/capture_run.sh BTZ96 1 MISTRA_CAPTURE_SEQ_FROM=22200 MISTRA_CAPTURE_SEQ_TO=22348"),
+}
+
+
 def main():
     for suffix, (capture, cmd) in SETS.items():
         if os.path.exists(capture):
             convert(suffix, capture, cmd)
         else:
             print("no capture", capture, "- skipped")
+    for name, (capture, cmd) in COLUMN_SETS.items():
+        if os.path.exists(capture) and os.path.getsize(capture):
+            convert_column(name, capture, cmd)
+        else:
+            print("no capture", capture, "- skipped")
+
+
+def convert_column(name, capture, cmd):
+    """tests/golden/column_<name>.npz: per mechanism m the arrays m_var_in, m_fix, m_rconst, m_var_out, m_stats, m_tin_out,
+    m_stepmin_out and m_seq (position of the call in the model's sequence of INTEGRATE_x calls; 148 consecutive positions
+    = one column step)."""
+    recs = read_capture(capture)
+    info = open(os.path.join(HERE, "..", "..", "oracle", "_ref", "BUILD_INFO")).read()
+    out = dict(provenance=np.array(cmd + "; " + info.replace("\n", "; ")), cells_per_step=np.int32(148))
+    for mech in ("gas", "aer", "tot"):
+        rs = [r for r in recs if r["mech"] == mech]
+        if not rs:
+            continue
+        out[mech + "_var_in"] = np.stack([r["var_in"] for r in rs])
+        out[mech + "_fix"] = np.stack([r["fix"] for r in rs])
+        out[mech + "_rconst"] = np.stack([r["rconst"] for r in rs])
+        out[mech + "_var_out"] = np.stack([r["var_out"] for r in rs])
+        out[mech + "_stats"] = np.stack([r["stats"] for r in rs]).astype(np.int32)
+        out[mech + "_tin_out"] = np.array([r["tin_out"] for r in rs])
+        out[mech + "_stepmin_out"] = np.array([r["stepmin_out"] for r in rs])
+        out[mech + "_seq"] = np.array([r["callno"] for r in rs], np.int32)
+        assert all(r["tin"] == 0.0 and r["tout"] == rs[0]["tout"] for r in rs)
+        out["tout"] = np.float64(rs[0]["tout"])
+    path = os.path.join(HERE, "column_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("column", name, {m: len([r for r in recs if r["mech"] == m]) for m in ("gas", "aer", "tot")}, "->", path, os.path.getsize(path), "bytes")
 
 
 def convert(suffix, capture, cmd):
@@ -66,6 +114,9 @@ def convert(suffix, capture, cmd):
             provenance=np.array(cmd + "; " + info.replace("\n", "; ")))
         path = os.path.join(HERE, "integrate_%s%s.npz" % (mech, suffix))
         np.savez_compressed(path, **out)
+        if suffix == "":      # the benchmark workload's base states (mistra_amd/workload.py): the inputs only, inside the package
+            np.savez_compressed(os.path.join(HERE, "..", "..", "mistra_amd", "data", "base_%s.npz" % mech), var=out["var_in"],
+                                fix=out["fix"], rconst=out["rconst"], provenance=out["provenance"])
         print(mech, len(rs), "records ->", path, os.path.getsize(path), "bytes; steps", out["stats"][:, 2].min(), "..", out["stats"][:, 2].max())
 
 

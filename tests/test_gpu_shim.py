@@ -1,8 +1,10 @@
 """Drop-in proof for the Fortran surface (-m gpu): a Fortran program fills COMMON /GDATA_x/ and calls
 INTEGRATE_x(TIN, TOUT) — the reference's own signature (gas.f:710 | aer.f:1408 | tot.f:2812), here provided by
-shim/mistra_kpp_shim.f90 over the C ABI — and gets the captured reference results back."""
+shim/mistra_kpp_shim.f90 over the C ABI — and gets the captured reference results back; and the batched form a two-pass
+kpp_driver would call (INTEGRATE_BATCH_x) replays whole captured column steps of the reference model
+(BASELINE.json configs[4]: all 148 layers of one 10-s step) as ONE call per mechanism."""
 import os
-import shutil
+import re
 import subprocess
 
 import numpy as np
@@ -12,24 +14,97 @@ from conftest import MECHS, REPO, rel_diff
 
 pytestmark = pytest.mark.gpu
 FLANG = "/opt/rocm/lib/llvm/bin/flang"
+DRIVER = os.path.join(REPO, "shim", "shim_driver")
+needs_flang = pytest.mark.skipif(not os.path.exists(FLANG), reason="no Fortran compiler on this box")
 
 
-@pytest.mark.skipif(not os.path.exists(FLANG), reason="no Fortran compiler on this box")
+def _write_cells(path, var, fix, rconst):
+    rec = np.concatenate([var, fix, rconst], axis=1)
+    with open(path, "wb") as f:
+        f.write(np.array([float(var.shape[0])]).tobytes())
+        f.write(np.ascontiguousarray(rec).tobytes())
+
+
+@needs_flang
 @pytest.mark.parametrize("mech", MECHS)
 def test_fortran_integrate_x_through_shim(mech, golden, tmp_path):
     subprocess.run(["make", "-s", "-C", os.path.join(REPO, "shim")], check=True)
     g = golden[mech]
     n = 4
-    rec = np.concatenate([g["var_in"][:n], g["fix"][:n], g["rconst"][:n]], axis=1)
     fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
-    with open(fin, "wb") as f:
-        f.write(np.array([float(n)]).tobytes())
-        f.write(np.ascontiguousarray(rec).tobytes())
-    subprocess.run([os.path.join(REPO, "shim", "shim_driver"), mech[0], str(fin), str(fout)], check=True, timeout=300)
+    _write_cells(fin, g["var_in"][:n], g["fix"][:n], g["rconst"][:n])
+    subprocess.run([DRIVER, mech[0], str(fin), str(fout)], check=True, timeout=300)
     nvar = g["var_in"].shape[1]
-    out = np.fromfile(fout, np.float64).reshape(n, nvar + 2)
+    out = np.fromfile(fout, np.float64).reshape(n, nvar + 4)
     assert rel_diff(out[:, :nvar], g["var_out"][:n]).max() <= 2e-5
     assert np.allclose(out[:, nvar], g["tin_out"][:n], rtol=1e-12)              # TIN <- exit time
     # STEPMIN <- last step size: it follows the error estimate of the most sensitive trace species, so it carries the
     # same round-off-level spread as the concentrations (tests/test_gpu_parity.py), not more
     assert np.allclose(out[:, nvar + 1], g["stepmin_out"][:n], rtol=2e-5)
+    assert np.all(out[:, nvar + 2] == 1.0e-25) and np.all(out[:, nvar + 3] == 1.0e-3)    # ATOL, RTOL as INTEGRATE_x leaves them (gas.f:745-746)
+
+
+@needs_flang
+def test_fortran_prints_the_reference_messages_on_failure(golden, tmp_path):
+    """ros_ErrorMsg_x (gas.f:1474-1509) and INTEGRATE_x's PRINT (gas.f:764-767) come out of the Fortran shim on unit 6, and the
+    model carries on with the next cell.  A NaN concentration makes the step-size test fail at once (IERR = -7)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "shim")], check=True)
+    g = golden["gas"]
+    var = g["var_in"][:2].copy()
+    var[0, 5] = np.nan
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    _write_cells(fin, var, g["fix"][:2], g["rconst"][:2])
+    r = subprocess.run([DRIVER, "g", str(fin), str(fout)], check=True, timeout=300, capture_output=True, text=True)
+    text = r.stdout
+    assert "Forced exit from Rosenbrock_g due to the following error:" in text
+    assert "--> Step size too small: T + 10*H = T or H < Roundoff" in text
+    assert "T=" in text and "and H=" in text
+    assert "Rosenbrock: Unsucessful step at T=" in text and re.search(r"\(IERR=\s*-7\s*\)", text)
+    out = np.fromfile(fout, np.float64).reshape(2, 102 + 4)
+    assert rel_diff(out[1:, :102], g["var_out"][1:2]).max() <= 2e-5      # the second cell is integrated as if nothing had happened
+
+
+def _column(name):
+    return dict(np.load(os.path.join(REPO, "tests", "golden", "column_%s.npz" % name)))
+
+
+@needs_flang
+@pytest.mark.parametrize("name", ["Joyce2014", "base1", "BTZ96"])
+def test_fortran_batched_column_step(name, tmp_path, capsys):
+    """One captured 10-s step of the whole column, every layer's INTEGRATE_x call of the reference model, replayed from
+    Fortran as ONE INTEGRATE_BATCH_x call per mechanism (what kpp_driver's layer loop, kpp.f90:4310-4470, becomes with the
+    two-pass patch of INTEGRATION.md).  Results, exit times, last steps and /Statistics/ against the capture."""
+    path = os.path.join(REPO, "tests", "golden", "column_%s.npz" % name)
+    if not os.path.exists(path):
+        pytest.skip("no column fixture for %s" % name)
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "shim")], check=True)
+    col = _column(name)
+    per_step = int(col["cells_per_step"])
+    first = min(int(col[m + "_seq"].min()) for m in MECHS if m + "_seq" in col)
+    total_ms, ncells = 0.0, 0
+    for mech in MECHS:
+        if mech + "_seq" not in col:
+            continue
+        sel = (col[mech + "_seq"] - first) < per_step          # the first column step of the capture
+        var, fix, rconst = col[mech + "_var_in"][sel], col[mech + "_fix"][sel], col[mech + "_rconst"][sel]
+        n, nvar = var.shape
+        fin, fout = tmp_path / ("in_%s.bin" % mech), tmp_path / ("out_%s.bin" % mech)
+        _write_cells(fin, var, fix, rconst)
+        subprocess.run([DRIVER, mech[0].upper(), str(fin), str(fout)], check=True, timeout=300)
+        raw = np.fromfile(fout, np.float64)
+        out = raw[:n * (nvar + 4)].reshape(n, nvar + 4)
+        tail = raw[n * (nvar + 4):n * (nvar + 4) + 9 * n].reshape(n, 9)
+        ms = float(raw[-1])
+        assert np.all(tail[:, 0] == 1), "IERR"
+        assert np.array_equal(tail[:, 1:].astype(np.int32), col[mech + "_stats"][sel]), "/Statistics/ differ from the reference's"
+        assert rel_diff(out[:, :nvar], col[mech + "_var_out"][sel]).max() <= 2e-5
+        assert np.allclose(out[:, nvar], col[mech + "_tin_out"][sel], rtol=1e-12)
+        assert np.allclose(out[:, nvar + 1], col[mech + "_stepmin_out"][sel], rtol=2e-5)
+        total_ms += ms
+        ncells += n
+        with capsys.disabled():
+            print("\n  column %s, %s: %d layers in one call from Fortran, %.2f ms" % (name, mech, n, ms))
+    assert ncells == per_step
+    with capsys.disabled():
+        # SURVEY.md §6: the reference spends 69 us per gas call inside kpp_driver on one 2.1 GHz core (pack + rates + integrator)
+        print("  column %s: %d cells of one 10-s step in %.2f ms through the batched Fortran surface" % (name, ncells, total_ms))

@@ -61,6 +61,90 @@ def test_two_rank_partition_matches_single_rank():
     assert agg == [float(st[:, 2].sum()), 0.0, float(ncell)]
 
 
+class _OracleEngine:
+    """Stand-in for bench.GpuEngine in the CPU suite: same interface, the oracle instead of the HIP library (test-only; the
+    product has no CPU path and bench.py itself only ever builds GpuEngine)."""
+
+    def __init__(self):
+        from oracle.oracle import Oracle
+        self.oracles = {m: Oracle(m) for m in ("gas",)}
+
+    def integrate_into(self, mech, var, fix, rconst, out, ierr, stats):
+        o, e, st = self.oracles[mech].integrate_batch(var.numpy(), fix.numpy(), rconst.numpy())
+        out.copy_(torch.from_numpy(o))
+        ierr.copy_(torch.from_numpy(e.astype(np.int32)))
+        stats.copy_(torch.from_numpy(st.astype(np.int32)))
+
+    def synchronize(self):
+        pass
+
+    def event(self):
+        import time
+        return time.perf_counter()
+
+    @staticmethod
+    def elapsed_ms(a, b):
+        return 1e3 * (b - a)
+
+
+def _bench_rank_main(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    import bench
+    args = argparse.Namespace(gpus=world, steps=2, warmup=1, cells_per_gpu=9, mech="gas", backend="gloo", share_device=False,
+                              no_cpu_baseline=True)
+    line = bench.rank_body(args, rank, world, torch.device("cpu"), _OracleEngine())
+    if rank == 0:
+        q.put(line)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_rank_logic_on_two_gloo_ranks():
+    """bench.py's own rank code — shard, timed loop between barriers, max/sum reductions, the broadcast-integrate-gather leg —
+    on two CPU ranks over gloo, with the oracle standing in for the GPU."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    line = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2
+    assert line["config"]["cells_per_gpu"] == 9 and line["config"]["failed_cells"] == 0
+    assert line["value"] > 0 and abs(line["value"] - 18 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    io = line["config"]["root_io_path"]
+    assert io["cells_ok_at_root"] == 18 and io["value"] > 0          # every shard's results arrived at rank 0
+    for key in ("roofline",):
+        assert key in line
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts torch.distributed.run itself, as a child process."""
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        class R:
+            returncode = 0
+        return R()
+    import subprocess
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
 def test_shard_covers_everything():
     from mistra_amd.workload import shard
     for total in (0, 1, 7, 100000, 1000003):

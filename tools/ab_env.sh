@@ -1,11 +1,12 @@
 #!/bin/bash
 # Same-box A/B of one build under two environments: tools/ab_env.sh VAR=value [mech] [cells]
-# (e.g. MISTRA_DIAG_PLAIN_DEAL=1, MISTRA_NT_TOT=1024).  Prints timesteps/s of alternating runs.
+# (e.g. MISTRA_DIAG_PLAIN_DEAL=1) on the diagnostic library that reads such switches (tools/diag_dense.sh env -> libdiag_env.so;
+# the product library ignores them).  Prints timesteps/s of alternating runs.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 SETTING=$1; MECH=${2:-tot}; CELLS=${3:-25600}
 for rep in 1 2; do
   for V in 0 1; do
-    if [ $V = 1 ]; then PRE="env $SETTING"; else PRE=""; fi
+    if [ $V = 1 ]; then PRE="env $SETTING MISTRA_CHEM_LIB=$PWD/mistra_amd/lib/libdiag_env.so"; else PRE="env MISTRA_CHEM_LIB=$PWD/mistra_amd/lib/libdiag_env.so"; fi
     $PRE timeout -k 10 200 python bench.py --no-cpu-baseline --mech $MECH --cells-per-gpu $CELLS --steps 2 --warmup 1 2>/dev/null \
       | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('${SETTING} applied=$V', '%.0f' % d['value'], 'timesteps/s')"
   done

@@ -5,6 +5,12 @@
 cd "$(dirname "$0")/.."
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math"
 for V in "$@"; do
+  if [ "$V" = env ]; then      # the schedule compiler's A/B switches (MISTRA_DIAG_*), read from the environment -> libdiag_env.so
+    hipcc --offload-arch=gfx950 $FLAGS -DMISTRA_DIAG_ENV -c mistra_amd/csrc/capi.cpp -o /tmp/capi_env.o &&
+    hipcc --offload-arch=gfx950 $FLAGS -DMISTRA_DIAG_ENV -c mistra_amd/csrc/schedule.cpp -o /tmp/schedule_env.o &&
+    hipcc --offload-arch=gfx950 -shared -fPIC -o mistra_amd/lib/libdiag_env.so mistra_amd/build/ros3_kernel.o /tmp/capi_env.o /tmp/schedule_env.o mistra_amd/build/mech_tables.o -ldl
+    continue
+  fi
   case $V in
     p*) DEF="-DMISTRA_DIAG_DENSE_PANELS=${V#p}";;
     stamps) DEF="-DMISTRA_DIAG_STAMPS";;

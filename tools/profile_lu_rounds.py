@@ -14,7 +14,8 @@ res = chem.integrate('tot', var.numpy(), fix.numpy(), rconst.numpy())
 print('NDEC', res.stats[:, 5].mean())
 ''' % ROOT
 for n in [int(x) for x in sys.argv[1:]] or [1, 5, 10, 16, 17, 18, 19, 30, 45, 57, 70, 88, 89]:
-    env = dict(os.environ, MISTRA_DIAG_LU_ROUNDS=str(n))
+    env = dict(os.environ, MISTRA_DIAG_LU_ROUNDS=str(n),
+               MISTRA_CHEM_LIB=os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'mistra_amd', 'lib', 'libdiag_env.so'))   # tools/diag_dense.sh env
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
     lu = re.search(r' lu=(\d+)', r.stderr)
     nd = re.search(r'NDEC ([\d.]+)', r.stdout)
