@@ -395,8 +395,18 @@ int mistra_chem_integrate(int mech, int ncell, const double* var_in, const doubl
   return mistra_chem_integrate_ex(mech, ncell, var_in, fix, rconst, tin, tout, var_out, ierr, stats, nullptr);
 }
 
+// A Fortran caller has no init hook: the first call brings the library up on device MISTRA_CHEM_DEVICE (default 0), or on the
+// first MISTRA_CHEM_DEVICES GPUs of the node when that is set.
+static int lazy_init() {
+  if (g_inited) return 0;
+  if (const char* n = std::getenv("MISTRA_CHEM_DEVICES")) return mistra_chem_init_devices(std::atoi(n), nullptr);
+  const char* dev = std::getenv("MISTRA_CHEM_DEVICE");
+  return mistra_chem_init(dev ? std::atoi(dev) : 0);
+}
+
 int mistra_chem_integrate_ex(int mech, int ncell, const double* var_in, const double* fix, const double* rconst, double tin,
                              double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h) {
+  if (int rc = lazy_init()) return rc;
   if (int rc = check_call(mech, ncell)) return rc;
   if (ncell == 0) return 0;
   if (!var_in || !fix || !rconst || !var_out) return fail("null host pointer");
@@ -447,10 +457,7 @@ static const char* ros_error_text(int code) {
 
 int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, double* tout, int32_t* ierr_out, double* t_err,
                                         double* h_err, int32_t* nsng) {
-  if (!g_inited) {   // the Fortran caller has no init hook: first use selects the device (env MISTRA_CHEM_DEVICE, default 0)
-    const char* dev = std::getenv("MISTRA_CHEM_DEVICE");
-    if (int rc = mistra_chem_init(dev ? std::atoi(dev) : 0)) return rc;
-  }
+  if (int rc = lazy_init()) return rc;
   if (int rc = check_call(mech, 1)) return rc;
   if (!gdata || !tin || !tout) return fail("null pointer");
   const int nv = kDims[mech][0], nf = kDims[mech][1], nr = kDims[mech][2];

@@ -60,7 +60,7 @@ contains
        write (0, '(a)', advance='no') txt(i)
     end do
     write (0, *)
-    stop 'mistra_chem: GPU integrator unavailable (there is no CPU fallback)'
+    error stop 'mistra_chem: GPU integrator unavailable (there is no CPU fallback)'
   end subroutine mistra_chem_fail
 
   ! Use the first n GPUs of the node for the batched calls (one block of cells and one host thread per device inside the

@@ -45,6 +45,9 @@ def test_no_cpu_fallback(lib):
     assert b"no HIP device" in lib.mistra_chem_last_error()
     with pytest.raises(chem.MistraChemError):
         chem.integrate("gas", np.zeros((1, 102)), np.zeros((1, 3)), np.zeros((1, 331)))
+    # (the Fortran-facing entry points bring the library up themselves; without a device that fails loudly too)
+    rc = lib.mistra_chem_integrate_ex(0, 1, None, None, None, 0.0, 10.0, None, None, None, None)
+    assert rc != 0 and b"no HIP device" in lib.mistra_chem_last_error()
     # compute entry point without init: error, not a silent result
     out = np.zeros(102)
     dp = C.POINTER(C.c_double)
