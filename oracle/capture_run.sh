@@ -3,6 +3,7 @@
 # reference's shipped namelists and captures real INTEGRATE_x calls (see capture_wrap.c) into oracle/_ref/capture_<case>.bin.
 # The namelist is read from /root/reference/namelists, a modified COPY (netcdf=F: the image has no netCDF; chem=T;
 # lstmax=<hours>) is written to the scratch run directory under oracle/_ref/ — nothing under /root/reference is touched.
+# MISTRA_MODEL_BIN: another build of the model to run instead (oracle/_ref/mistra_two_pass, build_two_pass.sh).
 # Usage: capture_run.sh <namelist-suffix e.g. BTZ96> <hours> [extra env assignments for capture_wrap.c ...]
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
@@ -16,5 +17,5 @@ sed -e 's/^\( *netcdf *= *\)T/\1F/' -e 's/^\( *chem *= *\)F/\1T/' -e "s/^\( *lst
     -e "${MISTRA_NAMELIST_SED:-s/^$//}" "$REFROOT/namelists/namelist.$CASE" > "$RUN/namelist"
 cd "$RUN"
 env INPDIR="$REFROOT/input/" MECHDIR="$REFROOT/src/mech/" OUTDIR="$RUN/out/" NAMELIST="$RUN/namelist" \
-    MISTRA_CAPTURE_FILE="$HERE/_ref/capture_${CASE}${MISTRA_RUN_TAG:-}.bin" "$@" "$HERE/_ref/mistra_capture" > "$RUN/stdout.log" 2> "$RUN/stderr.log"
+    MISTRA_CAPTURE_FILE="$HERE/_ref/capture_${CASE}${MISTRA_RUN_TAG:-}.bin" "$@" "${MISTRA_MODEL_BIN:-$HERE/_ref/mistra_capture}" > "$RUN/stdout.log" 2> "$RUN/stderr.log"
 tail -4 "$RUN/stderr.log"

@@ -14,6 +14,11 @@
  *                         position in the model's sequence of INTEGRATE_x calls is in [FROM, TO); the record's call
  *                         number is then that global position (kpp_driver calls one of the three per layer and 10-s
  *                         step, kpp.f90:4310-4470, so a column step is a run of consecutive positions)
+ *   MISTRA_RESET_DUMMIES=1  before every real call, zero the KPP dummy product species of the mechanism (DUMM1, and DUMM2 in
+ *                         aer/tot: gas_Parameters.h:60, aer_Parameters.h:60-63).  x_drive never initialises them, so in the
+ *                         reference they carry whatever the PREVIOUS layer's integration left in COMMON /GDATA_x/ — a
+ *                         layer-to-layer coupling through the error norm only, which no batched evaluation can reproduce.
+ *                         tests/test_two_pass.py switches it off in both models to compare them bit for bit.
  * A one-line call/step census per mechanism is printed at exit.
  */
 #include <stdio.h>
@@ -35,7 +40,7 @@ extern struct { int32_t nfun, njac, nstp, nacc, nrej, ndec, nsol, nsng; } statis
 static FILE *fp;
 static long ncall[3], nrec[3], nstep_tot[3];
 static long skip[3], every[3] = {1, 1, 1}, maxrec[3] = {64, 64, 64};
-static int inited;
+static int inited, reset_dummies;
 static long seq, seq_from = -1, seq_to = -1;      /* global call position and the window kept (SEQ mode) */
 static long this_seq;
 
@@ -64,6 +69,7 @@ static void init(void) {
     maxrec[m] = envl("MISTRA_CAPTURE_MAX", sfx[m], 64);
     if (every[m] < 1) every[m] = 1;
   }
+  reset_dummies = getenv("MISTRA_RESET_DUMMIES") != NULL;
   if (getenv("MISTRA_CAPTURE_SEQ_FROM")) seq_from = atol(getenv("MISTRA_CAPTURE_SEQ_FROM"));
   if (getenv("MISTRA_CAPTURE_SEQ_TO")) seq_to = atol(getenv("MISTRA_CAPTURE_SEQ_TO"));
   atexit(census);
@@ -98,6 +104,7 @@ static void write_rec(int m, int nvar, int nfix, int nreact, double tin, double 
   void __wrap_integrate_##sfx##_(double *tin, double *tout) {                                      \
     if (!inited) init();                                                                            \
     int keep = want(M);                                                                             \
+    if (reset_dummies) { gdata_##sfx##_.c[3] = 0.0; if (M > 0) gdata_##sfx##_.c[4] = 0.0; }          \
     double t0 = *tin, t1 = *tout;                                                                   \
     static double c_in[NVAR + NFIX];                                                                \
     if (keep) memcpy(c_in, gdata_##sfx##_.c, sizeof c_in);                                          \

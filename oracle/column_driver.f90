@@ -25,7 +25,8 @@ program mistra_column_capture
 
   real(dp), parameter :: dt_slow = 60._dp, dt_fast = 10._dp
   character(len=1), parameter :: tag = 'a'
-  integer :: minutes, sub, k, nbl
+  integer :: minutes, sub, k, nbl, max_minutes, envstat
+  character(len=32) :: envbuf
   real(dp) :: xra, u0_floor
   logical :: daylight
 
@@ -72,7 +73,10 @@ program mistra_column_capture
   u0_floor = merge(1.75e-2_dp, 3.48e-2_dp, lpBuys13_0D)
 
   ! ---- minutes
-  do minutes = 1, 60 * lstmax
+  call get_environment_variable('MISTRA_COLUMN_MINUTES', envbuf, status=envstat)      ! shorter runs for the test-suite
+  max_minutes = 60 * lstmax
+  if (envstat == 0) read (envbuf, *) max_minutes
+  do minutes = 1, min(max_minutes, 60 * lstmax)
      it = minutes
      if (lct > nf) stop 'cloud top above nf'
      lmin = lmin + 1

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — applies the two-pass kpp_driver patch of INTEGRATION.md §4 to scratch copies of four reference files
+(kpp.f90, gas.f, aer.f, tot.f) and writes the unified diff a maintainer would apply.
+
+    two_pass_patch.py <reference src dir> <scratch dir> [<diff out>]
+
+Nothing under the reference tree is touched; the scratch copies live under oracle/_ref/ (git-ignored).  The edits are
+anchored on the exact reference lines they follow or replace (kpp.f90:4168-4470, gas.f:172-173, aer.f:216-217,
+tot.f:603-604) and fail loudly if an anchor is missing."""
+import difflib
+import os
+import sys
+
+
+def edit(text, old, new, count=1):
+    if text.count(old) != count:
+        raise SystemExit("anchor not found exactly %d time(s):\n%s" % (count, old))
+    return text.replace(old, new)
+
+
+def patch_kpp(t):
+    # the driver's USE list: the batch module
+    t = edit(t, "subroutine kpp_driver (box,dd_ch,n_bl)\n", "subroutine kpp_driver (box,dd_ch,n_bl)\n\n  USE mistra_kpp_batch, ONLY : kpp_pass, kpp_batch_begin, kpp_batch_run   ! two-pass layer loop (shim/)\n")
+    # the layer loop runs twice around one batched integration per mechanism
+    t = edit(t, "  do k=n_min,n_max\n\n! define temp, H2O, air, ..",
+             "  call kpp_batch_begin\n  do kpp_pass=1,2      ! pass 1: pack + rates, layers recorded; pass 2: budgets + hand-over of the batched results\n"
+             "  if (kpp_pass.eq.2) call kpp_batch_run (0.d0,dd_ch)\n  do k=n_min,n_max\n\n! define temp, H2O, air, ..")
+    # the one statement of the loop body that is not idempotent: advection is applied in pass 1 only
+    t = edit(t, "     if (neula.eq.0) then\n        if (k.le.kinv) then\n           do j=1,nadvmax",
+             "     if (neula.eq.0 .and. kpp_pass.ne.2) then\n        if (k.le.kinv) then\n           do j=1,nadvmax")
+    t = edit(t, "  enddo ! k\n\n! eliminate negative values\n  where (s1 < 0.d0) s1 = 0._dp",
+             "  enddo ! k\n  enddo ! kpp_pass\n  kpp_pass=0\n\n! eliminate negative values\n  where (s1 < 0.d0) s1 = 0._dp")
+    return t
+
+
+def patch_drive(t, sfx, indent):
+    use_anchor = {"g": "      subroutine gas_drive\n", "a": "      subroutine aer_drive\n", "t": "      subroutine tot_drive\n"}[sfx]
+    if t.count(use_anchor) != 1:
+        raise SystemExit("x_drive header not found for " + sfx)
+    # first USE statement of x_drive: add ours in front of it
+    head = t.index(use_anchor)
+    first_use = t.index("      USE ", head)
+    t = t[:first_use] + "      USE mistra_kpp_batch, ONLY : kpp_pass\n" + t[first_use:]
+    call = "%scall INTEGRATE_%s (tkpp" % (indent, sfx)
+    at = t.index(call)
+    eol = t.index("\n", at)
+    t = t[:eol + 1] + "%sif (kpp_pass.eq.1) return   ! pass 1 of the batched driver: this layer's C and RCONST are recorded\n" % indent + t[eol + 1:]
+    return t
+
+
+def main():
+    src, scratch = sys.argv[1], sys.argv[2]
+    os.makedirs(scratch, exist_ok=True)
+    diff = []
+    for name, fn in (("kpp.f90", patch_kpp), ("gas.f", lambda t: patch_drive(t, "g", "      ")),
+                     ("aer.f", lambda t: patch_drive(t, "a", "      ")), ("tot.f", lambda t: patch_drive(t, "t", "         "))):
+        old = open(os.path.join(src, name), errors="replace").read()
+        new = fn(old)
+        open(os.path.join(scratch, name), "w").write(new)
+        diff += list(difflib.unified_diff(old.splitlines(True), new.splitlines(True), "a/src/" + name, "b/src/" + name, n=2))
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write("".join(diff))
+    print("patched 4 files into", scratch, "(%d diff lines)" % len(diff))
+
+
+if __name__ == "__main__":
+    main()

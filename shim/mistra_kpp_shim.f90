@@ -145,37 +145,67 @@ end module mistra_chem_c_api
 subroutine INTEGRATE_g(TIN, TOUT)
   use iso_c_binding
   use mistra_chem_c_api
+  use mistra_kpp_batch
   implicit none
   real(c_double) :: TIN, TOUT
   integer, parameter :: NVAR = 102, NFIX = 3, NREACT = 331              ! gas_Parameters.h:28-49
   real(c_double), target :: C(NVAR + NFIX)
   real(c_double) :: RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX
   common /GDATA_g/ C, RCONST, TIME, DT, ATOL, RTOL, STEPMIN, STEPMAX
-  call integrate_one(0, 'g', c_loc(C), TIN, TOUT)
+  select case (kpp_pass)            ! two-pass layer loop of a batched kpp_driver (mistra_kpp_batch.f90); 0 = serial
+  case (1)
+     call kpp_batch_store(1, C, RCONST)
+  case (2)
+     call kpp_batch_fetch(1, C, TIN, STEPMIN)
+     RTOL = 1.0d-3                  ! as INTEGRATE_x leaves them (gas.f:745-746)
+     ATOL = 1.0d-25
+  case default
+     call integrate_one(0, 'g', c_loc(C), TIN, TOUT)
+  end select
 end subroutine INTEGRATE_g
 
 subroutine INTEGRATE_a(TIN, TOUT)
   use iso_c_binding
   use mistra_chem_c_api
+  use mistra_kpp_batch
   implicit none
   real(c_double) :: TIN, TOUT
   integer, parameter :: NVAR = 257, NFIX = 5, NREACT = 979              ! aer_Parameters.h:28-49
   real(c_double), target :: C(NVAR + NFIX)
   real(c_double) :: RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX
   common /GDATA_a/ C, RCONST, TIME, DT, ATOL, RTOL, STEPMIN, STEPMAX
-  call integrate_one(1, 'a', c_loc(C), TIN, TOUT)
+  select case (kpp_pass)            ! two-pass layer loop of a batched kpp_driver (mistra_kpp_batch.f90); 0 = serial
+  case (1)
+     call kpp_batch_store(2, C, RCONST)
+  case (2)
+     call kpp_batch_fetch(2, C, TIN, STEPMIN)
+     RTOL = 1.0d-3                  ! as INTEGRATE_x leaves them (gas.f:745-746)
+     ATOL = 1.0d-25
+  case default
+     call integrate_one(1, 'a', c_loc(C), TIN, TOUT)
+  end select
 end subroutine INTEGRATE_a
 
 subroutine INTEGRATE_t(TIN, TOUT)
   use iso_c_binding
   use mistra_chem_c_api
+  use mistra_kpp_batch
   implicit none
   real(c_double) :: TIN, TOUT
   integer, parameter :: NVAR = 417, NFIX = 7, NREACT = 1627             ! tot_Parameters.h:28-49
   real(c_double), target :: C(NVAR + NFIX)
   real(c_double) :: RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX
   common /GDATA_t/ C, RCONST, TIME, DT, ATOL, RTOL, STEPMIN, STEPMAX
-  call integrate_one(2, 't', c_loc(C), TIN, TOUT)
+  select case (kpp_pass)            ! two-pass layer loop of a batched kpp_driver (mistra_kpp_batch.f90); 0 = serial
+  case (1)
+     call kpp_batch_store(3, C, RCONST)
+  case (2)
+     call kpp_batch_fetch(3, C, TIN, STEPMIN)
+     RTOL = 1.0d-3                  ! as INTEGRATE_x leaves them (gas.f:745-746)
+     ATOL = 1.0d-25
+  case default
+     call integrate_one(2, 't', c_loc(C), TIN, TOUT)
+  end select
 end subroutine INTEGRATE_t
 
 ! ---- batched form: what INTEGRATE_x does to COMMON /GDATA_x/, for NCELL cells at once.
