@@ -87,6 +87,14 @@ int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tou
 int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, double* tout, int32_t* ierr, double* t_err,
                                         double* h_err, int32_t* nsng);
 
+/* Diagnostics for the phase-level parity tests: integrates the cells like mistra_chem_integrate (results discarded) with the
+ * kernel variant that writes out, per cell, the intermediate results of the FIRST attempt of the first Rosenbrock step
+ * (gas.f:1201-1262): dump[cell][5*NVAR + 2*LU_NONZERO + 2] = Fcn0 (Fun_x) | Ghimj as ros_PrepareMatrix_x builds it | Ghimj
+ * after KppDecomp_x in the kernel's form (multipliers in L; the rows of the solves' tail chain row-scaled by 1/U(k,k)) |
+ * 1/U(k,k) | K(1) | K(2) | K(3) (KppSolve_x results of the three stages) | Err (ros_ErrorNorm_x) | H. */
+int mistra_chem_debug_first_step(int mech, int ncell, const double* var_in, const double* fix, const double* rconst,
+                                 double tin, double tout, double* dump);
+
 /* Text of the last error on this thread ("" if none). */
 const char* mistra_chem_last_error(void);
 

@@ -229,7 +229,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* th) {
   KernelArgs a;
   a.var_in = var_in; a.fix = fix; a.rconst = rconst; a.var_out = var_out; a.ierr = ierr; a.stats = stats;
-  a.texit_hexit = th; a.h_last = nullptr; a.prof = nullptr; a.n_temps = S.n_temps; a.tin = tin; a.tout = tout; a.ncell = ncell;
+  a.texit_hexit = th; a.h_last = nullptr; a.prof = nullptr; a.dump = nullptr; a.n_temps = S.n_temps; a.tin = tin; a.tout = tout; a.ncell = ncell;
   a.consts = S.consts.p; a.fun_fac = S.fun_fac.p; a.jac_fac = S.jac_fac.p; a.jvs_pos = S.jvs_pos.p;
   a.zero_pos = S.zero_pos.p; a.diag_pos = S.diag_pos.p;
   a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev();
@@ -388,6 +388,37 @@ int mistra_chem_integrate_device(int mech, int ncell, const double* d_var_in, co
   HIP_TRY(hipSetDevice(D->id));
   KernelArgs a = make_args(D->mech[mech], ncell, d_var_in, d_fix, d_rconst, tin, tout, d_var_out, d_ierr, d_stats, d_texit_hexit);
   return launch(*D, mech, a, static_cast<hipStream_t>(hip_stream));
+}
+
+int mistra_chem_debug_first_step(int mech, int ncell, const double* var_in, const double* fix, const double* rconst, double tin,
+                                 double tout, double* dump) {
+  if (int rc = check_call(mech, ncell)) return rc;
+  if (ncell == 0) return 0;
+  if (!var_in || !fix || !rconst || !dump) return fail("null host pointer");
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  HIP_TRY(hipSetDevice(D.id));
+  MechState& S = D.mech[mech];
+  const size_t nv = (size_t)kDims[mech][0], nf = (size_t)kDims[mech][1], nr = (size_t)kDims[mech][2], nc = (size_t)ncell;
+  const size_t per = 5 * nv + 2 * (size_t)kDims[mech][3] + 2;
+  DevBuf<double> d_dump;
+  HIP_TRY(S.s_var.reserve(nc * nv));
+  HIP_TRY(S.s_fix.reserve(nc * nf));
+  HIP_TRY(S.s_rct.reserve(nc * nr));
+  HIP_TRY(S.s_ierr.reserve(nc));
+  HIP_TRY(S.s_stats.reserve(nc * 8));
+  HIP_TRY(d_dump.reserve(nc * per));
+  HIP_TRY(hipMemset(d_dump.p, 0, nc * per * sizeof(double)));
+  HIP_TRY(hipMemcpy(S.s_var.p, var_in, nc * nv * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S.s_fix.p, fix, nc * nf * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(S.s_rct.p, rconst, nc * nr * sizeof(double), hipMemcpyHostToDevice));
+  KernelArgs a = make_args(S, ncell, S.s_var.p, S.s_fix.p, S.s_rct.p, tin, tout, S.s_var.p, S.s_ierr.p, S.s_stats.p, nullptr);
+  a.dump = d_dump.p;
+  if (int rc = launch(D, mech, a, nullptr)) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(dump, d_dump.p, nc * per * sizeof(double), hipMemcpyDeviceToHost));
+  d_dump.release();
+  return 0;
 }
 
 int mistra_chem_integrate(int mech, int ncell, const double* var_in, const double* fix, const double* rconst, double tin,

@@ -733,8 +733,12 @@ __device__ __attribute__((noinline)) void dense_lu(int lane) {
 
 }  // namespace
 
-template <class MT, int NT, bool PROF>
+// VARIANT: 0 = the product kernel; 1 = phase timing (MISTRA_CHEM_PROFILE, capi.cpp); 2 = first-step dump: the intermediate
+// results of the FIRST attempt of the first step of every cell go to a.dump (layout: kernel_args.hpp), for the phase-level
+// parity tests (tests/test_gpu_parity.py); the integration itself is untouched.
+template <class MT, int NT, int VARIANT>
 __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(const KernelArgs a) {
+  constexpr bool PROF = VARIANT == 1, DUMP = VARIANT == 2;
   constexpr int NVAR = MT::NVAR, NFIX = MT::NFIX, NREACT = MT::NREACT, NNZ = MT::NNZ, NCONST = MT::NCONST;
   constexpr int NW = NT / 64;
   constexpr int SPT = (NVAR + NT - 1) / NT, RPT = (NREACT + NT - 1) / NT;
@@ -805,6 +809,28 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       const unsigned long long now = clock64();
       pc[slot] += now - t_last;
       t_last = now;
+    }
+  };
+
+  // first-step dump (VARIANT 2): one block of doubles per cell, see DumpLayout in kernel_args.hpp
+  bool dumping = DUMP;
+  gptr_mut<double> dump = nullptr;
+  if constexpr (DUMP) dump = GM_(a.dump) + (size_t)cell * (size_t)(5 * NVAR + 2 * NNZ + 2);
+  auto dump_vec = [&](int at, const double (&v)[SPT]) {
+    if constexpr (DUMP) {
+      if (dumping) {
+#pragma unroll
+        for (int q = 0; q < SPT; q++) {
+          const int s = q * NT + t;
+          if (s < NVAR) dump[at + s] = v[q];
+        }
+      }
+    }
+  };
+  auto dump_matrix = [&](int at) {      // Ghimj as it stands in LDS (every lane's stores are behind a barrier at the call sites)
+    if constexpr (DUMP) {
+      if (dumping)
+        for (int i = t; i < NNZ; i += NT) dump[at + i] = M[i];
     }
   };
 
@@ -975,6 +1001,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
 
     lap(6);
     fun(y, fcn0);
+    dump_vec(0, fcn0);
     lap(0);
     // ros_FunTimeDerivative_x (gas.f:1375): Fun_x does not depend on T and RCONST is frozen, so
     // dFdT = (1/Delta)*(Fun - Fcn0) is an exact +0.0; the evaluation is skipped, its count and its "+ HG*0.0" are kept.
@@ -994,6 +1021,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
         while (singular) {
           const double ghinv = 1.0 / (Direction * H * kRosGamma1);
           singular = prepare(ghinv, k1);
+          dump_matrix(NVAR);      // Ghimj = 1/(H*gamma) - Jac0
           ndec += 1;
           lap(2);
           if (singular) {
@@ -1018,6 +1046,11 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
               lap(12);
             }
             lap(3);
+            if constexpr (DUMP) {
+              if (MT::DENSE_ND == 0) lds_barrier();      // (the dense tail's caller has just passed one)
+              dump_matrix(NVAR + NNZ);      // the factors as the kernel keeps them; R(k) = 1/U(k,k) behind them
+              if (dumping && t < NVAR) dump[NVAR + 2 * NNZ + t] = M[NNZ + NVAR + 4 + t];
+            }
           }
         }
         if (ierr == -8) break;
@@ -1026,6 +1059,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       // stage 1: its right-hand side went through the LU program above, only the backward half of the solve is left
       lap(6);
       solve(k1, true);
+      dump_vec(2 * NVAR + 2 * NNZ, k1);
       lap(4);
       // stage 2: new function value at Y + A21*K1
 #pragma unroll
@@ -1041,6 +1075,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       }
       lap(6);
       solve(k2, false);
+      dump_vec(3 * NVAR + 2 * NNZ, k2);
       lap(4);
       // stage 3 reuses the stage-2 function value
       {
@@ -1050,6 +1085,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       }
       lap(6);
       solve(k3, false);
+      dump_vec(4 * NVAR + 2 * NNZ, k3);
       lap(4);
       nsol += 3;
 #pragma unroll
@@ -1059,6 +1095,10 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       }
       lap(6);
       const double Err = error_norm(y, ynew, yerr);
+      if constexpr (DUMP) {
+        if (dumping && t == 0) { dump[5 * NVAR + 2 * NNZ] = Err; dump[5 * NVAR + 2 * NNZ + 1] = H; }
+        dumping = false;      // the first attempt only
+      }
       lap(5);
       const double Fac = fmin_f(FacMax, fmax_f(FacMin, FacSafe / pow(Err, 1.0 / kRosElo)));
       double Hnew = H * Fac;
@@ -1113,17 +1153,19 @@ template <class MT, int NT>
 hipError_t launch_ros3(const KernelArgs& a, hipStream_t stream, bool* lds_configured) {
   constexpr size_t lds_bytes = LdsLayout<MT, NT>::TOTAL * sizeof(double);
   bool& configured = *lds_configured;      // per device (capi.cpp: DeviceState): the attribute is a property of the device's code object
-  auto kern = ros3_integrate_kernel<MT, NT, false>;
-  auto kern_prof = ros3_integrate_kernel<MT, NT, true>;      // MISTRA_CHEM_PROFILE diagnostics (capi.cpp)
+  auto kern = ros3_integrate_kernel<MT, NT, 0>;
+  auto kern_prof = ros3_integrate_kernel<MT, NT, 1>;      // MISTRA_CHEM_PROFILE diagnostics (capi.cpp)
+  auto kern_dump = ros3_integrate_kernel<MT, NT, 2>;      // first-step dump (mistra_chem_debug_first_step)
   if (!configured) {
-    for (const void* k : {reinterpret_cast<const void*>(kern), reinterpret_cast<const void*>(kern_prof)}) {
+    for (const void* k : {reinterpret_cast<const void*>(kern), reinterpret_cast<const void*>(kern_prof), reinterpret_cast<const void*>(kern_dump)}) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return e;
     }
     configured = true;
   }
   if (a.ncell <= 0) return hipSuccess;
-  if (a.prof) hipLaunchKernelGGL(kern_prof, dim3((unsigned)a.ncell), dim3(NT), lds_bytes, stream, a);
+  if (a.dump) hipLaunchKernelGGL(kern_dump, dim3((unsigned)a.ncell), dim3(NT), lds_bytes, stream, a);
+  else if (a.prof) hipLaunchKernelGGL(kern_prof, dim3((unsigned)a.ncell), dim3(NT), lds_bytes, stream, a);
   else hipLaunchKernelGGL(kern, dim3((unsigned)a.ncell), dim3(NT), lds_bytes, stream, a);
   return hipGetLastError();
 }
