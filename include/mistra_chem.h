@@ -72,6 +72,16 @@ int mistra_chem_integrate_device(int mech, int ncell, const double* d_var_in, co
                                  const double* d_rconst, double tin, double tout, double* d_var_out,
                                  int32_t* d_ierr, int32_t* d_stats, double* d_texit_hexit, void* hip_stream);
 
+/* OPT-IN, NOT the reference's behaviour: the same call with a first step size per cell.  INTEGRATE_x starts
+ * every call at Hstart = 1e-3 s (gas.f:743) and works its way up to the step the chemistry allows, ~130 steps per call in
+ * cloudy layers; a caller that feeds each cell's last step size (d_texit_hexit[2c+1] of the previous chemistry timestep)
+ * back as d_hstart[c] skips that ramp.  Results then differ from the reference's at the level of the integrator's own
+ * tolerance (study: profiles/r02_hstart_reuse_study.txt).  d_hstart = NULL, or an entry <= 0, gives the reference's 1e-3. */
+int mistra_chem_integrate_device_hstart(int mech, int ncell, const double* d_var_in, const double* d_fix,
+                                        const double* d_rconst, double tin, double tout, double* d_var_out,
+                                        int32_t* d_ierr, int32_t* d_stats, double* d_texit_hexit,
+                                        const double* d_hstart, void* hip_stream);
+
 /* Fortran-callable per-cell entry points with the reference's own signature, `SUBROUTINE INTEGRATE_x(TIN,TOUT)`
  * (REAL*8 by reference; data through COMMON /GDATA_x/).  `gdata` is the address of that COMMON block, laid out
  * C(NSPEC), RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX (gas_Global.h:29-58).  On return VAR

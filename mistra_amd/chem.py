@@ -54,6 +54,9 @@ def lib():
         L.mistra_chem_integrate.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip]
         L.mistra_chem_integrate_device.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                                    C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mistra_chem_integrate_device_hstart.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                          C.c_void_p]
         L.mistra_chem_integrate_common.argtypes = [C.c_int, C.c_void_p, _dp, _dp]
         L.mistra_chem_last_error.restype = C.c_char_p
         L.mistra_chem_describe.restype = C.c_char_p
@@ -131,7 +134,7 @@ def integrate(mech, var, fix, rconst, tin=0.0, tout=10.0, device=None):
     return IntegrateResult(out, ierr, stats)
 
 
-def _integrate_torch(mid, name, var, fix, rconst, tin, tout, out=None, ierr=None, stats=None):
+def _integrate_torch(mid, name, var, fix, rconst, tin, tout, out=None, ierr=None, stats=None, texit_hexit=None, hstart=None):
     import torch
     nvar, nfix, nreact, _ = DIMS[name]
     if not var.is_cuda:
@@ -148,13 +151,16 @@ def _integrate_torch(mid, name, var, fix, rconst, tin, tout, out=None, ierr=None
     ierr = torch.empty(ncell, dtype=torch.int32, device=var.device) if ierr is None else ierr
     stats = torch.empty((ncell, 8), dtype=torch.int32, device=var.device) if stats is None else stats
     stream = torch.cuda.current_stream(var.device).cuda_stream
-    _check(lib().mistra_chem_integrate_device(mid, ncell, var.data_ptr(), fix.data_ptr(), rconst.data_ptr(), float(tin),
-                                             float(tout), out.data_ptr(), ierr.data_ptr(), stats.data_ptr(), None,
-                                             C.c_void_p(stream)))
+    _check(lib().mistra_chem_integrate_device_hstart(mid, ncell, var.data_ptr(), fix.data_ptr(), rconst.data_ptr(), float(tin),
+                                                    float(tout), out.data_ptr(), ierr.data_ptr(), stats.data_ptr(),
+                                                    None if texit_hexit is None else texit_hexit.data_ptr(),
+                                                    None if hstart is None else hstart.data_ptr(), C.c_void_p(stream)))
     return IntegrateResult(out, ierr, stats)
 
 
-def integrate_into(mech, var, fix, rconst, out, ierr, stats, tin=0.0, tout=10.0):
-    """Device path with caller-owned output tensors (no allocation inside the timed region of bench.py)."""
+def integrate_into(mech, var, fix, rconst, out, ierr, stats, tin=0.0, tout=10.0, texit_hexit=None, hstart=None):
+    """Device path with caller-owned output tensors (no allocation inside the timed region of bench.py).  texit_hexit
+    [ncell, 2]: exit time and last step size per cell (what INTEGRATE_x leaves in TIN and STEPMIN).  hstart [ncell]: OPT-IN
+    first step size per cell instead of the reference's 1e-3 (include/mistra_chem.h: mistra_chem_integrate_device_hstart)."""
     mid, name = _mech_id(mech)
-    return _integrate_torch(mid, name, var, fix, rconst, tin, tout, out, ierr, stats)
+    return _integrate_torch(mid, name, var, fix, rconst, tin, tout, out, ierr, stats, texit_hexit, hstart)

@@ -229,7 +229,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* th) {
   KernelArgs a;
   a.var_in = var_in; a.fix = fix; a.rconst = rconst; a.var_out = var_out; a.ierr = ierr; a.stats = stats;
-  a.texit_hexit = th; a.h_last = nullptr; a.prof = nullptr; a.dump = nullptr; a.n_temps = S.n_temps; a.tin = tin; a.tout = tout; a.ncell = ncell;
+  a.texit_hexit = th; a.h_last = nullptr; a.hstart = nullptr; a.prof = nullptr; a.dump = nullptr; a.n_temps = S.n_temps; a.tin = tin; a.tout = tout; a.ncell = ncell;
   a.consts = S.consts.p; a.fun_fac = S.fun_fac.p; a.jac_fac = S.jac_fac.p; a.jvs_pos = S.jvs_pos.p;
   a.zero_pos = S.zero_pos.p; a.diag_pos = S.diag_pos.p;
   a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev();
@@ -377,6 +377,13 @@ const char* mistra_chem_describe(int mech) {
 int mistra_chem_integrate_device(int mech, int ncell, const double* d_var_in, const double* d_fix, const double* d_rconst,
                                  double tin, double tout, double* d_var_out, int32_t* d_ierr, int32_t* d_stats,
                                  double* d_texit_hexit, void* hip_stream) {
+  return mistra_chem_integrate_device_hstart(mech, ncell, d_var_in, d_fix, d_rconst, tin, tout, d_var_out, d_ierr, d_stats, d_texit_hexit,
+                                             nullptr, hip_stream);
+}
+
+int mistra_chem_integrate_device_hstart(int mech, int ncell, const double* d_var_in, const double* d_fix, const double* d_rconst,
+                                        double tin, double tout, double* d_var_out, int32_t* d_ierr, int32_t* d_stats,
+                                        double* d_texit_hexit, const double* d_hstart, void* hip_stream) {
   if (int rc = check_call(mech, ncell)) return rc;
   if (ncell == 0) return 0;
   if (!d_var_in || !d_fix || !d_rconst || !d_var_out || !d_ierr || !d_stats) return fail("null device pointer");
@@ -387,6 +394,7 @@ int mistra_chem_integrate_device(int mech, int ncell, const double* d_var_in, co
   if (!D) return fail("the buffers live on device " + std::to_string(attr.device) + ", which mistra_chem_init(_devices) did not set up");
   HIP_TRY(hipSetDevice(D->id));
   KernelArgs a = make_args(D->mech[mech], ncell, d_var_in, d_fix, d_rconst, tin, tout, d_var_out, d_ierr, d_stats, d_texit_hexit);
+  a.hstart = d_hstart;
   return launch(*D, mech, a, static_cast<hipStream_t>(hip_stream));
 }
 

@@ -43,6 +43,7 @@ struct KernelArgs {
   int32_t* ierr;               // [ncell]         1 = success, <0 = ros_ErrorMsg code (gas.f:1474)
   int32_t* stats;              // [ncell][8]      Nfun,Njac,Nstp,Nacc,Nrej,Ndec,Nsol,Nsng  (COMMON /Statistics/)
   double* texit_hexit;         // [ncell][2] or null: what INTEGRATE_x leaves in TIN and STEPMIN
+  const double* hstart;        // [ncell] or null: first step size per cell instead of INTEGRATE_x's 1e-3 (opt-in, not the reference's behaviour)
   double* h_last;              // [ncell] or null: the step size H when the integrator returned (ros_ErrorMsg_x prints it, gas.f:1506)
   double* dump;                // [ncell][5*NVAR + 2*LU_NONZERO + 2] or null: first-step dump (kernel VARIANT 2): Fcn0 | Ghimj prepared |
                                //   Ghimj factorised (kernel form) | R | K1 | K2 | K3 | Err, H  of the first attempt of the first step

@@ -985,7 +985,10 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   const double FacMin = 0.2, FacMax = 6.0, FacRej = 0.1, FacSafe = 0.9;
   const double Direction = (Tend >= Tstart) ? 1.0 : -1.0;
   double T = Tstart, Hexit = 0.0;
-  double H = fmin_f(fmin_f(1.0e-3, fabs(Tend - Tstart)), Hmax);
+  // Hstart: INTEGRATE_x fixes RPAR(3) = 1e-3 (gas.f:743).  Opt-in departure from the reference: a caller that keeps
+  // each cell's last step size from one chemistry timestep to the next passes it in a.hstart; <= 0 means the reference's value.
+  const double hstart0 = (a.hstart && G_(a.hstart)[cell] > 0.0) ? G_(a.hstart)[cell] : 1.0e-3;
+  double H = fmin_f(fmin_f(hstart0, fabs(Tend - Tstart)), Hmax);
   if (fabs(H) <= 10.0 * Roundoff) H = 1.0e-5;
   bool RejectLastH = false, RejectMoreH = false;
   int nfun = 0, njac = 0, nstp = 0, nacc = 0, nrej = 0, ndec = 0, nsol = 0, nsng = 0;

@@ -92,6 +92,11 @@ int kpp_mech_dim(const kpp_mech *m, int which) {
 static int kpp_variant = 0;
 void kpp_set_variant(int v) { kpp_variant = v; }
 
+/* Study knobs — NOT INTEGRATE_x's values (gas.f:743-746 fixes RTOL 1e-3, ATOL 1e-25, Hstart 1e-3): a tighter tolerance gives
+ * the "truth" the opt-in Hstart-reuse mode of the kernel is measured against (tools/hstart_study.py).  0 = the reference's value. */
+static double opt_rtol = 0.0, opt_atol = 0.0, opt_hstart = 0.0;
+void kpp_set_options(double rtol, double atol, double hstart) { opt_rtol = rtol; opt_atol = atol; opt_hstart = hstart; }
+
 /* factor lookup into X = [V | F | consts] */
 static inline double xval(const kpp_mech *m, const double *V, const double *F, int code) {
   if (code < m->nvar) return V[code];
@@ -229,10 +234,10 @@ static int ros_integrator(const kpp_mech *m, double *Y, const double *FIX, const
                           double *T_out, double *Hexit_out, int32_t *st, ros_work *w) {
   const int n = m->nvar, nnz = m->nnz;
   const double Roundoff = DBL_EPSILON, Hmin = 0.0, FacMin = 0.2, FacMax = 6.0, FacRej = 0.1, FacSafe = 0.9;
-  const double AbsTol = 1.0e-25, RelTol = 1.0e-3, DeltaMin = 1.0e-5;
+  const double AbsTol = opt_atol > 0.0 ? opt_atol : 1.0e-25, RelTol = opt_rtol > 0.0 ? opt_rtol : 1.0e-3, DeltaMin = 1.0e-5;
   const int Max_no_steps = 100000;
   const double Hmax = fabs(Tend - Tstart);
-  const double Hstart = fmin_f(fabs(1.0e-3), fabs(Tend - Tstart));
+  const double Hstart = fmin_f(fabs(opt_hstart > 0.0 ? opt_hstart : 1.0e-3), fabs(Tend - Tstart));
   double *K1 = w->K, *K2 = w->K + n, *K3 = w->K + 2 * n;
   double *Kst[3] = {K1, K2, K3};
 

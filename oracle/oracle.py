@@ -54,6 +54,7 @@ def _oracle_lib():
         lib.kpp_solve.argtypes = [C.c_void_p, _dp, _dp]
         lib.kpp_integrate.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _dp, _dp, _dp]
         lib.kpp_set_variant.argtypes = [C.c_int]
+        lib.kpp_set_options.argtypes = [C.c_double, C.c_double, C.c_double]
         lib.kpp_integrate_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _ip]
         _lib = lib
     return _lib
@@ -63,6 +64,11 @@ def set_variant(v):
     """0 = pinned restatement; bit 0 descending backward sweep; bit 1 fma-contracted; bit 2 reciprocal instead of
     division by pivots (sensitivity studies only)"""
     _oracle_lib().kpp_set_variant(int(v))
+
+
+def set_options(rtol=0.0, atol=0.0, hstart=0.0):
+    """Study knobs of the oracle (0 = INTEGRATE_x's fixed value): tolerances and first step size (tools/hstart_study.py)."""
+    _oracle_lib().kpp_set_options(float(rtol), float(atol), float(hstart))
 
 
 class Oracle:

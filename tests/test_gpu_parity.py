@@ -146,3 +146,38 @@ def test_full_size_properties(chem):
     want, ierr, st = Oracle("tot").integrate_batch(var[sel].cpu().numpy(), fix[sel].cpu().numpy(), rconst[sel].cpu().numpy())
     check(res.var[sel].cpu().numpy(), want, "tot 1e5 sample:")
     assert np.array_equal(res.stats[sel].cpu().numpy(), st)
+
+
+def test_opt_in_hstart_reuse(chem, golden):
+    """SURVEY §8 f4, opt-in and NOT the reference's behaviour: a first step size per cell (the previous call's last step)
+    instead of INTEGRATE_x's 1e-3.  Default (no hstart, or entries <= 0) is the reference path bit for bit; with reuse the
+    second of two consecutive calls needs fewer steps and lands within the integrator's own tolerance of the reference path
+    (study: profiles/r02_hstart_reuse_study.txt)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = golden["tot"]
+    var, fix, rconst = (torch.tensor(g[k][:16], device=dev) for k in ("var_in", "fix", "rconst"))
+    n = var.shape[0]
+
+    def call(v, hstart):
+        out = torch.empty_like(v)
+        ierr = torch.empty(n, dtype=torch.int32, device=dev)
+        stats = torch.empty((n, 8), dtype=torch.int32, device=dev)
+        th = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        chem.integrate_into("tot", v, fix, rconst, out, ierr, stats, 0.0, 10.0, texit_hexit=th, hstart=hstart)
+        torch.cuda.synchronize()
+        assert int((ierr != 1).sum()) == 0
+        return out, stats, th
+
+    o1, s1, th1 = call(var, None)
+    o1z, s1z, _ = call(var, torch.zeros(n, dtype=torch.float64, device=dev))
+    assert torch.equal(o1, o1z) and torch.equal(s1, s1z)                 # entries <= 0: the reference's Hstart
+    assert np.array_equal(s1.cpu().numpy(), g["stats"][:16])
+    o2_ref, s2_ref, _ = call(o1, None)                                     # second timestep, as the reference runs it
+    o2, s2, _ = call(o1, th1[:, 1].contiguous())                           # ... and from the first call's last step size
+    assert int(s2[:, 2].sum()) < int(s2_ref[:, 2].sum())
+    d = rel_diff(o2.cpu().numpy(), o2_ref.cpu().numpy())
+    major = np.abs(o2_ref.cpu().numpy()) >= 1e-4 * np.abs(o2_ref.cpu().numpy()).max(axis=1, keepdims=True)
+    print("Hstart reuse, second call: %d steps instead of %d; max rel diff %.2e (all), %.2e (major species)"
+          % (int(s2[:, 2].sum()), int(s2_ref[:, 2].sum()), d.max(), np.where(major, d, 0).max()))
+    assert d.max() <= 1e-3 and np.where(major, d, 0).max() <= 1e-6
