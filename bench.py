@@ -66,7 +66,7 @@ def measured_traffic(mech, ncell):
     cell count.  bench.py cannot collect PMC counters itself (they need their own rocprofv3 pass), so a pass is only used
     while it was taken on THIS kernel: the file records the kernel source hash, and a stale or missing pass gives null."""
     import glob
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic*.json")), reverse=True):
         d = json.load(open(path))
         if d.get("mech") == mech:
             if d.get("kernel_source_hash") != kernel_source_hash():
@@ -85,7 +85,10 @@ def cpu_baseline(mech, budget_s=15.0):
     if kind == "port":
         build_oracle()
     cores_available = len(os.sched_getaffinity(0))
-    cores = max(1, cores_available)          # every core this process may run on: the reference is serial, one process per core
+    # One process per core (the reference is serial).  A one-GPU box of the pool shows the whole host in its affinity mask
+    # (256 logical CPUs) but grants a job the CPU share of ONE GPU, 16 cores: forking 256 workers there stalls the run, so the
+    # baseline uses min(affinity, MISTRA_BENCH_CPU_CORES or 16) and reports both numbers.
+    cores = max(1, min(cores_available, int(os.environ.get("MISTRA_BENCH_CPU_CORES", "16"))))
     # calibrate on a few cells, then size the sample for ~budget_s seconds on all cores
     var, fix, rconst = (x.numpy() for x in make_batch(mech, 0, 4, "cpu"))
     dt, _ = _cpu_worker((kind, mech, var, fix, rconst))

@@ -97,6 +97,17 @@ int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tou
 int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, double* tout, int32_t* ierr, double* t_err,
                                         double* h_err, int32_t* nsng);
 
+/* Update_RCONST_x for ncell cells (gas.f:275 | aer.f:304 | tot.f:1040; called by x_drive right before INTEGRATE_x, gas.f:172):
+ * rconst[cell][NREACT] from env[cell][mistra_chem_rates_env_size(mech)], the per-cell inputs the generated routine and its
+ * rate laws (kpp.f90:7127-8601) read from COMMON /cb_1/, /kpp_rate_x/, /ph_r_x/ and C — for gas 74 doubles instead of
+ * 331: aircc, te, h2oppm, pk | conv1, xhal, xiod, xhet1, xhet2 | ycwd(1:2) | ph_rat(1:47) | FIX(1:3) | what fdhetg reads
+ * (layout: tools/extract_rates.py ENV).  Host buffers / device buffers on a HIP stream.  Available for the gas mechanism;
+ * the other two return an error (their 13 further rate-law functions are not on the device yet).  The lazy
+ * initialisation of the Fortran-facing entry points applies to the host-buffer form. */
+int mistra_chem_rates_env_size(int mech);
+int mistra_chem_update_rconst(int mech, int ncell, const double* env, double* rconst);
+int mistra_chem_update_rconst_device(int mech, int ncell, const double* d_env, double* d_rconst, void* hip_stream);
+
 /* Diagnostics for the phase-level parity tests: integrates the cells like mistra_chem_integrate (results discarded) with the
  * kernel variant that writes out, per cell, the intermediate results of the FIRST attempt of the first Rosenbrock step
  * (gas.f:1201-1262): dump[cell][5*NVAR + 2*LU_NONZERO + 2] = Fcn0 (Fun_x) | Ghimj as ros_PrepareMatrix_x builds it | Ghimj

@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libmistra_chem.so")
 ARCH = "gfx950"
 # -ffp-contract=off: one rounding per multiply and per add, as in the reference built without FMA contraction
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-SOURCES = ["mech_tables.cpp", "schedule.cpp", "capi.cpp", "ros3_kernel.hip"]
+SOURCES = ["mech_tables.cpp", "schedule.cpp", "capi.cpp", "ros3_kernel.hip", "rates.hip"]
 
 
 def hipcc():

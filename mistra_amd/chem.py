@@ -57,6 +57,9 @@ def lib():
         L.mistra_chem_integrate_device_hstart.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                                           C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                           C.c_void_p]
+        L.mistra_chem_rates_env_size.argtypes = [C.c_int]
+        L.mistra_chem_update_rconst.argtypes = [C.c_int, C.c_int, _dp, _dp]
+        L.mistra_chem_update_rconst_device.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mistra_chem_integrate_common.argtypes = [C.c_int, C.c_void_p, _dp, _dp]
         L.mistra_chem_last_error.restype = C.c_char_p
         L.mistra_chem_describe.restype = C.c_char_p
@@ -156,6 +159,34 @@ def _integrate_torch(mid, name, var, fix, rconst, tin, tout, out=None, ierr=None
                                                     None if texit_hexit is None else texit_hexit.data_ptr(),
                                                     None if hstart is None else hstart.data_ptr(), C.c_void_p(stream)))
     return IntegrateResult(out, ierr, stats)
+
+
+def update_rconst(mech, env):
+    """Update_RCONST_x for a batch of cells (gas.f:275): env [ncell, rates_env_size] -> rconst [ncell, NREACT].  numpy in ->
+    numpy out; torch CUDA tensor in -> torch tensor out, on torch's current stream.  gas only so far (include/mistra_chem.h)."""
+    mid, name = _mech_id(mech)
+    nreact = DIMS[name][2]
+    try:
+        import torch
+        is_torch = isinstance(env, torch.Tensor)
+    except ImportError:      # pragma: no cover
+        is_torch = False
+    if is_torch:
+        init(env.device.index or 0)
+        ne = lib().mistra_chem_rates_env_size(mid)
+        if env.dtype != torch.float64 or not env.is_contiguous() or env.shape[-1] != ne:
+            raise MistraChemError("expected a contiguous float64 [ncell,%d] tensor" % ne)
+        out = torch.empty((env.numel() // ne, nreact), dtype=torch.float64, device=env.device)
+        stream = torch.cuda.current_stream(env.device).cuda_stream
+        _check(lib().mistra_chem_update_rconst_device(mid, out.shape[0], env.data_ptr(), out.data_ptr(), C.c_void_p(stream)))
+        return out
+    if _inited_device is None:
+        init(0)
+    ne = lib().mistra_chem_rates_env_size(mid)
+    e = np.ascontiguousarray(env, np.float64).reshape(-1, ne if ne else 1)
+    out = np.empty((e.shape[0], nreact))
+    _check(lib().mistra_chem_update_rconst(mid, e.shape[0], e.ctypes.data_as(_dp), out.ctypes.data_as(_dp)))
+    return out
 
 
 def integrate_into(mech, var, fix, rconst, out, ierr, stats, tin=0.0, tout=10.0, texit_hexit=None, hstart=None):

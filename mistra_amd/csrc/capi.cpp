@@ -17,6 +17,7 @@
 
 #include "kernel_args.hpp"
 #include "mech_tables.hpp"
+#include "rates.hpp"
 #include "ros3_kernel.hpp"
 #include "schedule.hpp"
 
@@ -63,6 +64,26 @@ struct DevBuf {
   }
 };
 
+}  // namespace
+
+bool mistra::RatesTable::load(const std::string& path, std::string* err) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) { if (err) *err = "cannot open " + path; return false; }
+  int32_t h[6];
+  bool ok = std::fread(h, sizeof h, 1, f) == 1 && h[0] == 0x5441524B && h[1] == 1;
+  if (ok) {
+    nreact = h[2]; nenv = h[3];
+    consts.resize((size_t)h[4]); offs.resize((size_t)nreact + 1); words.resize((size_t)h[5]);
+    ok = std::fread(consts.data(), 8, consts.size(), f) == consts.size() && std::fread(offs.data(), 4, offs.size(), f) == offs.size() &&
+         std::fread(words.data(), 4, words.size(), f) == words.size();
+  }
+  std::fclose(f);
+  if (!ok && err) *err = path + ": not a rate table";
+  return ok;
+}
+
+namespace {
+
 struct VmBufs {
   DevBuf<uint32_t> wave_base, recs;
   DevBuf<uint16_t> blk_n;
@@ -103,6 +124,11 @@ struct MechState {
   VmBufs lu, solve_head_fwd, solve_head_bwd;
   DevBuf<uint32_t> tail_fwd, tail_bwd, lu_scale;
   DevBuf<uint32_t> dense_rows;
+  // Update_RCONST_x on the device (rates.hip): present for the mechanisms whose table and rate-law functions exist
+  bool rates_ready = false;
+  int rates_nenv = 0;
+  DevBuf<double> rates_consts, s_env;
+  DevBuf<int32_t> rates_offs, rates_words;
   int lu_scale_slots = 0;
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
@@ -115,7 +141,7 @@ struct MechState {
     consts.release(); fun_fac.release(); jac_fac.release(); jvs_pos.release(); zero_pos.release(); diag_pos.release();
     vdot.release(); jvs.release(); lu.release(); solve_head_fwd.release(); solve_head_bwd.release();
     tail_fwd.release(); tail_bwd.release(); lu_scale.release();
-    dense_rows.release();
+    dense_rows.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); s_env.release(); rates_ready = false;
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release();
     if (one_dev) (void)hipFree(one_dev);
     if (one_host) (void)hipHostFree(one_host);
@@ -211,6 +237,18 @@ int setup_mech(DeviceState& D, int mech) {
   HIP_TRY(S.tail_bwd.upload(K.tail.bwd));
   HIP_TRY(S.lu_scale.upload(K.lu_scale.recs));
   HIP_TRY(S.dense_rows.upload(K.dense.row_info));
+  {   // optional: the rate table (gas today)
+    RatesTable T;
+    std::string rerr;
+    if (T.load(mech_dir() + "/" + kMechName[mech] + ".rates", &rerr)) {
+      if (T.nreact != S.tab.nreact) return fail(std::string(kMechName[mech]) + ".rates does not belong to this mechanism");
+      HIP_TRY(S.rates_consts.upload(T.consts));
+      HIP_TRY(S.rates_offs.upload(T.offs));
+      HIP_TRY(S.rates_words.upload(T.words));
+      S.rates_nenv = T.nenv;
+      S.rates_ready = true;
+    }
+  }
   S.lu_scale_slots = K.lu_scale.nslots;
   S.ready = true;
   return 0;
@@ -335,6 +373,8 @@ int integrate_host_on(DeviceState& D, int mech, int ncell, const double* var_in,
 
 }  // namespace
 
+static int lazy_init();
+
 extern "C" {
 
 const char* mistra_chem_last_error(void) { return g_err.c_str(); }
@@ -396,6 +436,48 @@ int mistra_chem_integrate_device_hstart(int mech, int ncell, const double* d_var
   KernelArgs a = make_args(D->mech[mech], ncell, d_var_in, d_fix, d_rconst, tin, tout, d_var_out, d_ierr, d_stats, d_texit_hexit);
   a.hstart = d_hstart;
   return launch(*D, mech, a, static_cast<hipStream_t>(hip_stream));
+}
+
+int mistra_chem_rates_env_size(int mech) {
+  if (mech < 0 || mech > 2 || !g_inited || g_devs.empty() || !g_devs[0].mech[mech].rates_ready) return 0;
+  return g_devs[0].mech[mech].rates_nenv;
+}
+
+int mistra_chem_update_rconst_device(int mech, int ncell, const double* d_env, double* d_rconst, void* hip_stream) {
+  if (int rc = check_call(mech, ncell)) return rc;
+  if (ncell == 0) return 0;
+  if (!d_env || !d_rconst) return fail("null device pointer");
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, d_env) != hipSuccess) return fail("d_env is not a device pointer");
+  DeviceState* D = device_slot(attr.device);
+  if (!D) return fail("the buffers live on a device mistra_chem_init(_devices) did not set up");
+  MechState& S = D->mech[mech];
+  if (!S.rates_ready) return fail(std::string("no device rate table for the ") + kMechName[mech] + " mechanism (gas only so far)");
+  HIP_TRY(hipSetDevice(D->id));
+  const RatesDev R{S.rates_consts.p, S.rates_offs.p, S.rates_words.p, S.tab.nreact, S.rates_nenv};
+  hipError_t e = launch_update_rconst(R, d_env, d_rconst, ncell, static_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int mistra_chem_update_rconst(int mech, int ncell, const double* env, double* rconst) {
+  if (int rc = lazy_init()) return rc;
+  if (int rc = check_call(mech, ncell)) return rc;
+  if (ncell == 0) return 0;
+  if (!env || !rconst) return fail("null host pointer");
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  MechState& S = D.mech[mech];
+  if (!S.rates_ready) return fail(std::string("no device rate table for the ") + kMechName[mech] + " mechanism (gas only so far)");
+  HIP_TRY(hipSetDevice(D.id));
+  const size_t nc = (size_t)ncell, ne = (size_t)S.rates_nenv, nr = (size_t)S.tab.nreact;
+  HIP_TRY(S.s_env.reserve(nc * ne));
+  HIP_TRY(S.s_rct.reserve(nc * nr));
+  HIP_TRY(hipMemcpy(S.s_env.p, env, nc * ne * sizeof(double), hipMemcpyHostToDevice));
+  if (int rc = mistra_chem_update_rconst_device(mech, ncell, S.s_env.p, S.s_rct.p, nullptr)) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(rconst, S.s_rct.p, nc * nr * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int mistra_chem_debug_first_step(int mech, int ncell, const double* var_in, const double* fix, const double* rconst, double tin,

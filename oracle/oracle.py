@@ -176,6 +176,36 @@ class Reference:
         self._sol(_d(np.ascontiguousarray(LU, np.float64)), _d(x))
         return x
 
+    def update_rconst_gas(self, env):
+        """Update_RCONST_g (gas.f:275) on one cell's inputs, given as the 74-double vector of tools/extract_rates.py ENV["gas"]:
+        fills COMMON /cb_1/ (kpp.f90:7140), /kpp_rate_g/ and /ph_r_g/ (gas_Global.h:76-96) and C, calls the compiled
+        reference routine, returns RCONST(331)."""
+        assert self.mech == "gas"
+        e = np.asarray(env, np.float64)
+        nspec = self.nvar + self.nfix
+        cb1 = (C.c_double * 4).in_dll(self.lib, "cb_1_")
+        rate = (C.c_double * (2 * nspec + nspec + nspec + 2 + 5)).in_dll(self.lib, "kpp_rate_g_")      # yxkmtd(NSPEC,2) yhenry yxeq ycwd(2) conv1 xhal xiod xhet1 xhet2
+        ph = (C.c_double * 47).in_dll(self.lib, "ph_r_g_")
+        cb1[:] = list(e[0:4])
+        r = np.ctypeslib.as_array(rate)
+        r[:] = 0.0
+        # species numbers of gas_Parameters.h:79-203 (1-based)
+        ind = {"ind_hno3l1": 13, "ind_hno3l2": 16, "ind_h2so4": 19, "ind_nh3": 24, "ind_n2o5": 32, "ind_hno3": 75}
+        for k, sp in enumerate(("hno3", "n2o5", "nh3", "h2so4")):
+            for b in range(2):
+                r[b * nspec + ind["ind_" + sp] - 1] = e[61 + 2 * k + b]                 # yxkmtd(sp, bin), column-major
+        r[2 * nspec + ind["ind_hno3"] - 1] = e[69]                                      # yhenry
+        r[3 * nspec + ind["ind_hno3"] - 1] = e[70]                                      # yxeq
+        r[4 * nspec:4 * nspec + 2] = e[9:11]                                            # ycwd
+        r[4 * nspec + 2:4 * nspec + 7] = e[4:9]                                         # conv1 xhal xiod xhet1 xhet2
+        ph[:] = list(e[11:58])
+        c = np.ctypeslib.as_array(self.gdata.c)
+        c[:] = 0.0
+        c[self.nvar:] = e[58:61]                                                        # FIX
+        c[ind["ind_hno3"] - 1], c[ind["ind_hno3l1"] - 1], c[ind["ind_hno3l2"] - 1] = e[71], e[72], e[73]
+        self.lib.update_rconst_g_()
+        return np.ctypeslib.as_array(self.gdata.rconst).copy()
+
     def integrate(self, var, fix, rconst, tin=0.0, tout=10.0):
         g = self.gdata
         np.ctypeslib.as_array(g.c)[:self.nvar] = var

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/rates_gas.npz: inputs of Update_RCONST_g (the 74-double per-cell vector of tools/extract_rates.py
+ENV["gas"]) and the RCONST(331) the COMPILED REFERENCE makes of them (oracle/_ref/libmistra_ref.so: update_rconst_g_ and the
+rate laws of kpp.f90, flang -O2 -ffp-contract=off), for the parity test of the device evaluator (tests/test_gpu_rates.py).
+
+The inputs are drawn, seeded, over the ranges the model visits: temperature 220-310 K, pressure 3e4-1.05e5 Pa with air
+density and water vapour to match, switches on/off, photolysis rates from zero (night) to daytime magnitudes, dry-aerosol
+uptake coefficients and HNO3 partitioning inputs from zero to large.  Run in the build container (needs the compiled
+reference); the fixture is data."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle.oracle import Reference  # noqa: E402
+
+
+def draw(rng, n):
+    env = np.zeros((n, 74))
+    te = rng.uniform(220.0, 310.0, n)
+    pk = rng.uniform(3.0e4, 1.05e5, n)
+    env[:, 0] = pk / (1.380649e-23 * te) * 1.0e-6                 # aircc, molecules per cm^3
+    env[:, 1] = te
+    env[:, 2] = 10.0 ** rng.uniform(1.0, 4.6, n)                  # h2oppm
+    env[:, 3] = pk
+    env[:, 4] = 6.022e23 / 1.0e6 * rng.uniform(0.9, 1.1, n) * 1e-6 * 1e6   # conv1 ~ cm^3/mlc -> m^3/mol, order 6e17
+    env[:, 5:9] = rng.integers(0, 2, (n, 4)).astype(float)        # xhal xiod xhet1 xhet2
+    env[:, 9:11] = 10.0 ** rng.uniform(-13, -9, (n, 2)) * rng.integers(0, 2, (n, 2))      # ycwd
+    day = rng.integers(0, 2, n)[:, None]
+    env[:, 11:58] = day * 10.0 ** rng.uniform(-8, -2, (n, 47))   # ph_rat
+    env[:, 58:61] = 10.0 ** rng.uniform(-2, 2, (n, 3))            # FIX (O2, N2, H2O-like magnitudes in mol/m^3)
+    env[:, 61:69] = 10.0 ** rng.uniform(2, 8, (n, 8)) * rng.integers(0, 2, (n, 8))        # yxkmtd
+    env[:, 69] = 10.0 ** rng.uniform(0, 6, n) * rng.integers(0, 2, n)                      # yhenry(HNO3)
+    env[:, 70] = 10.0 ** rng.uniform(-3, 3, n)                    # yxeq(HNO3)
+    env[:, 71:74] = 10.0 ** rng.uniform(-14, -7, (n, 3)) * rng.integers(0, 2, (n, 3))    # C(HNO3), C(HNO3l1), C(HNO3l2)
+    return env
+
+
+def main():
+    rng = np.random.default_rng(20261004)
+    env = draw(rng, 96)
+    ref = Reference("gas")
+    rconst = np.stack([ref.update_rconst_gas(e) for e in env])
+    info = open(os.path.join(HERE, "..", "..", "oracle", "_ref", "BUILD_INFO")).read().replace("\n", "; ")
+    path = os.path.join(HERE, "rates_gas.npz")
+    np.savez_compressed(path, env=env, rconst=rconst, provenance=np.array("tests/golden/make_rates_golden.py, seed 20261004; " + info))
+    print(path, os.path.getsize(path), "bytes;", int((rconst != 0).sum(axis=1).min()), "..", int((rconst != 0).sum(axis=1).max()),
+          "non-zero rate constants per cell; finite:", bool(np.isfinite(rconst).all()))
+
+
+if __name__ == "__main__":
+    main()
