@@ -99,11 +99,13 @@ int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, doub
 
 /* Update_RCONST_x for ncell cells (gas.f:275 | aer.f:304 | tot.f:1040; called by x_drive right before INTEGRATE_x, gas.f:172):
  * rconst[cell][NREACT] from env[cell][mistra_chem_rates_env_size(mech)], the per-cell inputs the generated routine and its
- * rate laws (kpp.f90:7127-8601) read from COMMON /cb_1/, /kpp_rate_x/, /ph_r_x/ and C — for gas 74 doubles instead of
- * 331: aircc, te, h2oppm, pk | conv1, xhal, xiod, xhet1, xhet2 | ycwd(1:2) | ph_rat(1:47) | FIX(1:3) | what fdhetg reads
- * (layout: tools/extract_rates.py ENV).  Host buffers / device buffers on a HIP stream.  Available for the gas mechanism;
- * the other two return an error (their 13 further rate-law functions are not on the device yet).  The lazy
- * initialisation of the Fortran-facing entry points applies to the host-buffer form. */
+ * rate laws (kpp.f90:7127-8601) read from COMMON /cb_1/, /kpp_rate_x/, /ph_r_x/ and C.  Sizes: gas 74 doubles, aer 330,
+ * tot 544 (instead of the 331 / 807 / 1627 rate constants); gas e.g.: aircc, te, h2oppm, pk | conv1, xhal, xiod, xhet1,
+ * xhet2 | ycwd(1:2) | ph_rat(1:47) | FIX(1:3) | what fdhetg reads.  The layout of each mechanism is listed by name in
+ * mistra_amd/mech/<mech>.rates_env.json (made by tools/extract_rates.py together with the rate table <mech>.rates the
+ * library loads); Fortran array names there index as the reference declares them (kpp.f90:7140-7180).  Host buffers /
+ * device buffers on a HIP stream.  The lazy initialisation of the Fortran-facing entry points applies to the host-buffer
+ * form. */
 int mistra_chem_rates_env_size(int mech);
 int mistra_chem_update_rconst(int mech, int ncell, const double* env, double* rconst);
 int mistra_chem_update_rconst_device(int mech, int ncell, const double* d_env, double* d_rconst, void* hip_stream);

@@ -163,7 +163,7 @@ def _integrate_torch(mid, name, var, fix, rconst, tin, tout, out=None, ierr=None
 
 def update_rconst(mech, env):
     """Update_RCONST_x for a batch of cells (gas.f:275): env [ncell, rates_env_size] -> rconst [ncell, NREACT].  numpy in ->
-    numpy out; torch CUDA tensor in -> torch tensor out, on torch's current stream.  gas only so far (include/mistra_chem.h)."""
+    numpy out; torch CUDA tensor in -> torch tensor out, on torch's current stream.  Entry names of env: mistra_amd/mech/<mech>.rates_env.json."""
     mid, name = _mech_id(mech)
     nreact = DIMS[name][2]
     try:

@@ -69,13 +69,13 @@ struct DevBuf {
 bool mistra::RatesTable::load(const std::string& path, std::string* err) {
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) { if (err) *err = "cannot open " + path; return false; }
-  int32_t h[6];
-  bool ok = std::fread(h, sizeof h, 1, f) == 1 && h[0] == 0x5441524B && h[1] == 1;
+  int32_t h[8];
+  bool ok = std::fread(h, sizeof h, 1, f) == 1 && h[0] == 0x5441524B && h[1] == 2;
   if (ok) {
     nreact = h[2]; nenv = h[3];
-    consts.resize((size_t)h[4]); offs.resize((size_t)nreact + 1); words.resize((size_t)h[5]);
-    ok = std::fread(consts.data(), 8, consts.size(), f) == consts.size() && std::fread(offs.data(), 4, offs.size(), f) == offs.size() &&
-         std::fread(words.data(), 4, words.size(), f) == words.size();
+    consts.resize((size_t)h[4]); offs.resize((size_t)nreact + 1); words.resize((size_t)h[5]); fslot.resize((size_t)h[6]);
+    ok = h[6] == 50 && std::fread(consts.data(), 8, consts.size(), f) == consts.size() && std::fread(offs.data(), 4, offs.size(), f) == offs.size() &&
+         std::fread(words.data(), 4, words.size(), f) == words.size() && std::fread(fslot.data(), 4, fslot.size(), f) == fslot.size();
   }
   std::fclose(f);
   if (!ok && err) *err = path + ": not a rate table";
@@ -128,7 +128,7 @@ struct MechState {
   bool rates_ready = false;
   int rates_nenv = 0;
   DevBuf<double> rates_consts, s_env;
-  DevBuf<int32_t> rates_offs, rates_words;
+  DevBuf<int32_t> rates_offs, rates_words, rates_fslot;
   int lu_scale_slots = 0;
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
@@ -141,7 +141,7 @@ struct MechState {
     consts.release(); fun_fac.release(); jac_fac.release(); jvs_pos.release(); zero_pos.release(); diag_pos.release();
     vdot.release(); jvs.release(); lu.release(); solve_head_fwd.release(); solve_head_bwd.release();
     tail_fwd.release(); tail_bwd.release(); lu_scale.release();
-    dense_rows.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); s_env.release(); rates_ready = false;
+    dense_rows.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); rates_fslot.release(); s_env.release(); rates_ready = false;
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release();
     if (one_dev) (void)hipFree(one_dev);
     if (one_host) (void)hipHostFree(one_host);
@@ -245,6 +245,7 @@ int setup_mech(DeviceState& D, int mech) {
       HIP_TRY(S.rates_consts.upload(T.consts));
       HIP_TRY(S.rates_offs.upload(T.offs));
       HIP_TRY(S.rates_words.upload(T.words));
+      HIP_TRY(S.rates_fslot.upload(T.fslot));
       S.rates_nenv = T.nenv;
       S.rates_ready = true;
     }
@@ -452,9 +453,9 @@ int mistra_chem_update_rconst_device(int mech, int ncell, const double* d_env, d
   DeviceState* D = device_slot(attr.device);
   if (!D) return fail("the buffers live on a device mistra_chem_init(_devices) did not set up");
   MechState& S = D->mech[mech];
-  if (!S.rates_ready) return fail(std::string("no device rate table for the ") + kMechName[mech] + " mechanism (gas only so far)");
+  if (!S.rates_ready) return fail(std::string("no device rate table for the ") + kMechName[mech] + " mechanism");
   HIP_TRY(hipSetDevice(D->id));
-  const RatesDev R{S.rates_consts.p, S.rates_offs.p, S.rates_words.p, S.tab.nreact, S.rates_nenv};
+  const RatesDev R{S.rates_consts.p, S.rates_offs.p, S.rates_words.p, S.rates_fslot.p, S.tab.nreact, S.rates_nenv};
   hipError_t e = launch_update_rconst(R, d_env, d_rconst, ncell, static_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
   return 0;
@@ -468,7 +469,7 @@ int mistra_chem_update_rconst(int mech, int ncell, const double* env, double* rc
   std::lock_guard<std::mutex> lock(g_mu);
   DeviceState& D = g_devs[0];
   MechState& S = D.mech[mech];
-  if (!S.rates_ready) return fail(std::string("no device rate table for the ") + kMechName[mech] + " mechanism (gas only so far)");
+  if (!S.rates_ready) return fail(std::string("no device rate table for the ") + kMechName[mech] + " mechanism");
   HIP_TRY(hipSetDevice(D.id));
   const size_t nc = (size_t)ncell, ne = (size_t)S.rates_nenv, nr = (size_t)S.tab.nreact;
   HIP_TRY(S.s_env.reserve(nc * ne));

@@ -4,7 +4,9 @@
 // The generated Update_RCONST_x (gas.f:275-666 | aer.f:304-1364 | tot.f:1040-2768) is one assignment per reaction,
 //     RCONST(i) = <product of switches, literals, rate-law calls, array elements>
 // tools/extract_rates.py turns those into postfix programs (mistra_amd/mech/<mech>.rates); this file holds the evaluator
-// and the rate-law functions of kpp.f90:7127-8601 that the gas mechanism calls (aer / tot add 13 more: next step).
+// and the rate-law functions of kpp.f90:7127-8376 that the three mechanisms call.  What a rate law reads from COMMON itself
+// (uptake coefficients, liquid water, a few concentrations) it finds through the table's slot list (FS_*, tools/extract_rates.py:
+// fslot_names), so the functions are the same code for every mechanism.
 // Arithmetic follows the reference statement by statement: Fortran evaluation order, integer arguments converted where
 // the reference converts them, DEFAULT-REAL literals as the double nearest their float32 — `300.` is exact,
 // `8.314` is 8.31400012969970703, `0.21` is 0.209999993443489075, `10**(-6.16)` is the single-precision power
@@ -63,19 +65,80 @@ __device__ double dms_add(const Cb1& c) {
   const double o2 = k021 * c.aircc, tte = 1.0 / c.te;
   return ((9.5e-39 * exp(5270.0 * tte)) * o2) / (1.0 + (7.5e-29 * exp(5610.0 * tte)) * o2);
 }
-// kpp.f90:8198  fdhetg(na, nb): uptake on dry aerosol; env slots of what it reads: tools/extract_rates.py ENV["gas"]
-__device__ double fdhetg(const double* e, int na, int nb) {
-  constexpr int YCWD = 9, YXK = 61, YHENRY = 69, YXEQ = 70, C_HNO3 = 71, C_HNO3L = 72;
-  const double ycwd = e[YCWD + na - 1];
+// positions in the table's slot list of what the rate laws read from COMMON (tools/extract_rates.py: fslot_names)
+enum { FS_H2OL = 0, FS_CLM = 4, FS_BRM = 8, FS_YXKMT_N2O5 = 12, FS_YXKMT_CLNO3 = 16, FS_YXKMT_BRNO3 = 20, FS_YCW = 24,
+       FS_YXKMTD_N2O5 = 28, FS_YXKMTD_BRNO3 = 30, FS_YXKMTD_CLNO3 = 32, FS_YXKMTD_HNO3 = 34, FS_YXKMTD_NH3 = 36,
+       FS_YXKMTD_H2SO4 = 38, FS_YCWD = 40, FS_YHENRY_HNO3 = 42, FS_YXEQ_HNO3 = 43, FS_C_HNO3 = 44, FS_C_HNO3L = 45,
+       FS_C_NO3ML = 47, FS_XHAL = 49 };
+
+struct Env {
+  const double* e;
+  const int32_t* fs;
+  __device__ double at(int f) const { return e[fs[f]]; }            // the value behind slot-list position f
+  __device__ bool has(int f) const { return fs[f] >= 0; }
+};
+
+// kpp.f90:8198 fdhetg | :8269 fdheta | :8311 fdhett (na, nb): uptake on dry aerosol.  The three differ in the "aqueous" HNO3
+// of the nb = 1 branch: gas knows no NO3- species and takes C(HNO3lz)*1.5d3 (a hard-coded pH 2, kpp.f90:8232-8233); aer and
+// tot take C(HNO3lz)+C(NO3mlz) behind a guard on the denominator (kpp.f90:8285-8291).
+__device__ double fdhet(const Env& v, int na, int nb) {
+  const double ycwd = v.at(FS_YCWD + na - 1);
   if (nb == 1) {
-    const double yx = e[YXK + 0 + na - 1];
+    const double yx = v.at(FS_YXKMTD_HNO3 + na - 1);
     const double x1 = yx * ycwd;
-    const double caq = ((e[C_HNO3L + na - 1] * 1.5e3) * 1.0e-2) / (e[YXEQ] + 1.0e-2);
+    double caq;
+    if (v.has(FS_C_NO3ML)) {
+      caq = 0.0;
+      if ((v.at(FS_YXEQ_HNO3) + 1.0e-2) != 0.0) caq = ((v.at(FS_C_HNO3L + na - 1) + v.at(FS_C_NO3ML + na - 1)) * 1.0e-2) / (v.at(FS_YXEQ_HNO3) + 1.0e-2);
+    } else {
+      caq = ((v.at(FS_C_HNO3L + na - 1) * 1.5e3) * 1.0e-2) / (v.at(FS_YXEQ_HNO3) + 1.0e-2);
+    }
     double x2 = 0.0;
-    if (e[C_HNO3] != 0.0 && e[YHENRY] != 0.0) x2 = ((-yx) / (e[C_HNO3] * e[YHENRY])) * caq;
+    if (v.at(FS_C_HNO3) != 0.0 && v.at(FS_YHENRY_HNO3) != 0.0) x2 = ((-yx) / (v.at(FS_C_HNO3) * v.at(FS_YHENRY_HNO3))) * caq;
     return fmax_fortran(0.0, x1 + x2);
   }
-  return e[YXK + 2 * (nb - 1) + na - 1] * ycwd;        // N2O5, NH3, H2SO4
+  const int sp = nb == 2 ? FS_YXKMTD_N2O5 : nb == 3 ? FS_YXKMTD_NH3 : FS_YXKMTD_H2SO4;
+  return v.at(sp + na - 1) * ycwd;
+}
+// kpp.f90:7562  farr2=a0*exp(dble(b0)*(1.d0/te-3.3557d-3))
+__device__ double farr2(const Cb1& c, double a0, double b0) { return a0 * exp(b0 * (1.0 / c.te - 3.3557e-3)); }
+// kpp.f90:7582  fhet_t(a0,b0,c0): bin a0 = 1..4; b0 picks the reaction partner (H2O | Cl- | Br-), c0 the gas (N2O5 | ClNO3 | BrNO3)
+__device__ double fhet_t(const Env& v, int a0, int b0, int c0) {
+  const double h2oa = v.at(FS_H2OL + a0 - 1);
+  const double hetT = (h2oa + 5.0e2 * v.at(FS_CLM + a0 - 1)) + 3.0e5 * v.at(FS_BRM + a0 - 1);
+  const double xbr = b0 == 1 ? h2oa : b0 == 2 ? 5.0e2 : 3.0e5;
+  const double xtr = v.at((c0 == 1 ? FS_YXKMT_N2O5 : c0 == 2 ? FS_YXKMT_CLNO3 : FS_YXKMT_BRNO3) + a0 - 1);
+  return hetT > 0.0 ? ((xtr * v.at(FS_YCW + a0 - 1)) * xbr) / hetT : 0.0;
+}
+// kpp.f90:8023 fhet_da | :8111 fhet_dt (xliq, xhet, a0, b0, c0), a0 = 1..2: on the deliquesced aerosol (xhet = 0) or on the dry one
+__device__ double fhet_d(const Env& v, double xliq, double xhet, int a0, int b0, int c0) {
+  constexpr double k5555 = 55.549999237060547;      // 55.55 as a default-real literal
+  const double xhal = v.at(FS_XHAL);
+  double xtr, h2oa, hetT, yw;
+  if (xhet == 0.0) {
+    xtr = v.at((c0 == 1 ? FS_YXKMT_N2O5 : c0 == 2 ? FS_YXKMT_CLNO3 : FS_YXKMT_BRNO3) + a0 - 1);
+    h2oa = v.at(FS_H2OL + a0 - 1);
+    hetT = (h2oa + 5.0e2 * v.at(FS_CLM + a0 - 1)) + 3.0e5 * v.at(FS_BRM + a0 - 1);
+    yw = v.at(FS_YCW + a0 - 1);
+    if (xhal == 0.0) {
+      if (c0 == 2 || c0 == 3) xtr = 0.0;
+      hetT = v.at(FS_H2OL + a0 - 1);
+    }
+  } else {      // (note the reference's order here: c0 = 2 is BrNO3, c0 = 3 ClNO3, kpp.f90:8066-8068)
+    xtr = v.at((c0 == 1 ? FS_YXKMTD_N2O5 : c0 == 2 ? FS_YXKMTD_BRNO3 : FS_YXKMTD_CLNO3) + a0 - 1);
+    h2oa = (k5555 * v.at(FS_YCWD + a0 - 1)) * 1.0e3;
+    hetT = (h2oa + 5.0e2 * v.at(FS_CLM + a0 - 1)) + 3.0e5 * v.at(FS_BRM + a0 - 1);
+    yw = v.at(FS_YCWD + a0 - 1);
+    if (xhal == 0.0) {
+      if (c0 == 2 || c0 == 3) xtr = 0.0;
+      hetT = (k5555 * v.at(FS_YCWD + a0 - 1)) * 1.0e3;
+    }
+  }
+  const double xbr = b0 == 1 ? h2oa : b0 == 2 ? 5.0e2 : 3.0e5;
+  double r = hetT > 0.0 ? ((xtr * yw) * xbr) / hetT : 0.0;
+  if ((c0 == 2 || c0 == 3 || b0 == 2 || b0 == 3) && xhal == 0.0) r = 0.0;
+  if (xliq == 0.0) r = 0.0;
+  return r;
 }
 
 __global__ __launch_bounds__(256) void update_rconst_kernel(const RatesDev R, const double* __restrict__ env, double* __restrict__ rconst,
@@ -85,6 +148,8 @@ __global__ __launch_bounds__(256) void update_rconst_kernel(const RatesDev R, co
   const int cell = (int)(gid / R.nreact), r = (int)(gid % R.nreact);
   const double* e = env + (size_t)cell * R.nenv;
   const Cb1 cb{e[0], e[1], e[2], e[3]};
+  const Env ev{e, R.fslot};
+  constexpr double dclim = 1.0e10;      // the reaction-rate ceiling of dmin2 / uplim / uparm / uplip / uparp
   double st[12];
   int sp = 0;
   for (int w = R.offs[r]; w < R.offs[r + 1]; w++) {
@@ -117,7 +182,56 @@ __global__ __launch_bounds__(256) void update_rconst_kernel(const RatesDev R, co
           case 9: sp -= 6; v = sp_23(cb, st[sp], st[sp + 1], st[sp + 2], st[sp + 3], st[sp + 4], st[sp + 5]); break;
           case 10: sp -= 1; v = fcn(cb, st[sp]); break;
           case 11: v = dms_add(cb); break;
-          case 12: sp -= 2; v = fdhetg(e, (int)st[sp], (int)st[sp + 1]); break;
+          case 12: sp -= 2; v = fdhet(ev, (int)st[sp], (int)st[sp + 1]); break;
+          case 13: sp -= 2; v = farr2(cb, st[sp], st[sp + 1]); break;
+          case 14: sp -= 3; v = fhet_t(ev, (int)st[sp], (int)st[sp + 1], (int)st[sp + 2]); break;
+          case 15: sp -= 5; v = fhet_d(ev, st[sp], st[sp + 1], (int)st[sp + 2], (int)st[sp + 3], (int)st[sp + 4]); break;
+          case 16: {   // fliq_60 (kpp.f90:7662): a1*exp(dble(b1)*(1.d0/te-3.3557d-3))*c/(c+0.1d0/d)
+            sp -= 4;
+            const double a1 = st[sp], b1 = st[sp + 1], c = st[sp + 2], d = st[sp + 3];
+            v = d > 0.0 ? ((a1 * exp(b1 * (1.0 / cb.te - 3.3557e-3))) * c) / (c + 0.1 / d) : 0.0;
+            break;
+          }
+          case 17: sp -= 1; v = st[sp] < dclim ? st[sp] : dclim; break;                    // dmin2 = dmin1(a, 1.d10)
+          case 18: sp -= 1; v = st[sp] < dclim * 2.0 ? st[sp] : dclim * 2.0; break;        // dmin3 = dmin1(a, 2.d10)
+          case 19: {   // flsc4 = a*b*c**3 (kpp.f90:7755); c**3 as the compiler expands it: c*c*c
+            sp -= 3;
+            const double c = st[sp + 2];
+            v = c > 0.0 ? (st[sp] * st[sp + 1]) * ((c * c) * c) : 0.0;
+            break;
+          }
+          case 20: {   // flsc5 = a*b**2*c**4 (kpp.f90:7778); c**4 as the reference's compiler expands it: ((c*c)*c)*c
+            sp -= 3;
+            const double b = st[sp + 1], c = st[sp + 2];
+            v = c > 0.0 ? (st[sp] * (b * b)) * (((c * c) * c) * c) : 0.0;
+            break;
+          }
+          case 21: sp -= 2; v = st[sp + 1] > 1.0e-15 ? st[sp] / st[sp + 1] : 0.0; break;    // flsc6 (kpp.f90:7801)
+          case 22: {   // uplim = a/(1 + b/dclim*max(c,0)*d) (kpp.f90:7862)
+            sp -= 4;
+            const double a = st[sp], b = st[sp + 1], c = st[sp + 2], d = st[sp + 3];
+            v = d > 0.0 ? a / (1.0 + ((b / dclim) * fmax_fortran(c, 0.0)) * d) : 0.0;
+            break;
+          }
+          case 23: {   // uparm = a0*exp(dble(b0)*(1/te-3.3557d-3))/(1+c/dclim*d*e) (kpp.f90:7888)
+            sp -= 5;
+            const double a0 = st[sp], b0 = st[sp + 1], c = st[sp + 2], d = st[sp + 3], ee = st[sp + 4];
+            v = d > 0.0 ? (a0 * exp(b0 * (1.0 / cb.te - 3.3557e-3))) / (1.0 + ((c / dclim) * d) * ee) : 0.0;
+            break;
+          }
+          case 24: {   // uplip = a/(1 + a/dclim*max(b,0)*c)*c**2 (kpp.f90:7916)
+            sp -= 3;
+            const double a = st[sp], b = st[sp + 1], c = st[sp + 2];
+            v = c > 0.0 ? (a / (1.0 + ((a / dclim) * fmax_fortran(b, 0.0)) * c)) * (c * c) : 0.0;
+            break;
+          }
+          case 25: {   // uparp = k/(1 + k/dclim*c*d)*d**2, k = a0*exp(dble(b0)*(1/te-3.3557d-3)) (kpp.f90:7942)
+            sp -= 4;
+            const double a0 = st[sp], b0 = st[sp + 1], c = st[sp + 2], d = st[sp + 3];
+            const double k = a0 * exp(b0 * (1.0 / cb.te - 3.3557e-3));
+            v = d > 0.0 ? (k / (1.0 + ((k / dclim) * c) * d)) * (d * d) : 0.0;
+            break;
+          }
         }
         st[sp++] = v;
       }

@@ -12,13 +12,14 @@ struct RatesDev {              // device copy of one mechanism's table
   const double* consts;        // literal pool
   const int32_t* offs;         // [nreact + 1] first word of each reaction's postfix program
   const int32_t* words;        // opcode | operand << 8   (0 const, 1 env slot, 2 + 3 - 4 * 5 / 6 neg 7 call function id)
+  const int32_t* fslot;        // env slots of what the rate-law functions read from COMMON themselves, -1 = not in this mechanism
   int nreact, nenv;            // reactions; doubles per cell in the input vector ("env", layout: tools/extract_rates.py ENV)
 };
 
 struct RatesTable {
   int nreact = 0, nenv = 0;
   std::vector<double> consts;
-  std::vector<int32_t> offs, words;
+  std::vector<int32_t> offs, words, fslot;
   bool load(const std::string& path, std::string* err);
 };
 

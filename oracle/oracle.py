@@ -176,34 +176,53 @@ class Reference:
         self._sol(_d(np.ascontiguousarray(LU, np.float64)), _d(x))
         return x
 
-    def update_rconst_gas(self, env):
-        """Update_RCONST_g (gas.f:275) on one cell's inputs, given as the 74-double vector of tools/extract_rates.py ENV["gas"]:
-        fills COMMON /cb_1/ (kpp.f90:7140), /kpp_rate_g/ and /ph_r_g/ (gas_Global.h:76-96) and C, calls the compiled
-        reference routine, returns RCONST(331)."""
-        assert self.mech == "gas"
-        e = np.asarray(env, np.float64)
+    # COMMON /kpp_rate_x/ member order (gas_Global.h:82-87 | aer_Global.h:82-88 | tot_Global.h:91-95); NSPEC = nvar + nfix
+    RATE_LAYOUT = {
+        "gas": [("yxkmtd", 2), ("yhenry", 0), ("yxeq", 0), ("ycwd", -2), ("conv1", -1), ("xhal", -1), ("xiod", -1), ("xhet1", -1), ("xhet2", -1)],
+        "aer": [("yhenry", 0), ("yxkmt", 2), ("ykef", 2), ("ykeb", 2), ("yxkmtd", 2), ("yxeq", 0), ("ycw", -2), ("ycwd", -2), ("conv1", -1),
+                ("cvv1", -1), ("cvv2", -1), ("xhal", -1), ("xiod", -1), ("xliq1", -1), ("xliq2", -1), ("xhet1", -1), ("xhet2", -1)],
+        "tot": [("conv1", -1), ("cvv1", -1), ("cvv2", -1), ("cvv3", -1), ("cvv4", -1), ("xhal", -1), ("xiod", -1), ("xliq1", -1), ("xliq2", -1),
+                ("xliq3", -1), ("xliq4", -1), ("ycw", -4), ("yhenry", 0), ("yxkmt", 4), ("ykef", 4), ("ykeb", 4), ("xhet1", -1), ("xhet2", -1),
+                ("yxkmtd", 2), ("yxeq", 0), ("ycwd", -2)],
+    }       # (name, k): k > 0 array (NSPEC, k) column-major; 0 array (NSPEC); -1 scalar; -n small array of n
+
+    def update_rconst(self, names, env):
+        """Update_RCONST_x (gas.f:275 | aer.f:304 | tot.f:1040) on one cell's inputs: `names` says what each entry of `env` is
+        (mistra_amd/mech/<mech>.rates_env.json, written by tools/extract_rates.py).  Fills COMMON /cb_1/ (kpp.f90:7140),
+        /kpp_rate_x/, /ph_r_x/ and C, calls the compiled reference routine, returns RCONST."""
+        import re
+        sfx = SFX[self.mech]
         nspec = self.nvar + self.nfix
+        e = np.asarray(env, np.float64)
+        off, total = {}, 0
+        for nm, k in self.RATE_LAYOUT[self.mech]:
+            off[nm] = (total, k)
+            total += nspec * k if k > 0 else nspec if k == 0 else -k
         cb1 = (C.c_double * 4).in_dll(self.lib, "cb_1_")
-        rate = (C.c_double * (2 * nspec + nspec + nspec + 2 + 5)).in_dll(self.lib, "kpp_rate_g_")      # yxkmtd(NSPEC,2) yhenry yxeq ycwd(2) conv1 xhal xiod xhet1 xhet2
-        ph = (C.c_double * 47).in_dll(self.lib, "ph_r_g_")
-        cb1[:] = list(e[0:4])
-        r = np.ctypeslib.as_array(rate)
-        r[:] = 0.0
-        # species numbers of gas_Parameters.h:79-203 (1-based)
-        ind = {"ind_hno3l1": 13, "ind_hno3l2": 16, "ind_h2so4": 19, "ind_nh3": 24, "ind_n2o5": 32, "ind_hno3": 75}
-        for k, sp in enumerate(("hno3", "n2o5", "nh3", "h2so4")):
-            for b in range(2):
-                r[b * nspec + ind["ind_" + sp] - 1] = e[61 + 2 * k + b]                 # yxkmtd(sp, bin), column-major
-        r[2 * nspec + ind["ind_hno3"] - 1] = e[69]                                      # yhenry
-        r[3 * nspec + ind["ind_hno3"] - 1] = e[70]                                      # yxeq
-        r[4 * nspec:4 * nspec + 2] = e[9:11]                                            # ycwd
-        r[4 * nspec + 2:4 * nspec + 7] = e[4:9]                                         # conv1 xhal xiod xhet1 xhet2
-        ph[:] = list(e[11:58])
+        rate = np.ctypeslib.as_array((C.c_double * total).in_dll(self.lib, "kpp_rate_%s_" % sfx))
+        ph = np.ctypeslib.as_array((C.c_double * 47).in_dll(self.lib, "ph_r_%s_" % sfx))
         c = np.ctypeslib.as_array(self.gdata.c)
+        rate[:] = 0.0
+        ph[:] = 0.0
         c[:] = 0.0
-        c[self.nvar:] = e[58:61]                                                        # FIX
-        c[ind["ind_hno3"] - 1], c[ind["ind_hno3l1"] - 1], c[ind["ind_hno3l2"] - 1] = e[71], e[72], e[73]
-        self.lib.update_rconst_g_()
+        for nm, v in zip(names, e):
+            m = re.match(r"(\w+)\((\d+)(?:,(\d+))?\)$", nm)
+            if nm in ("aircc", "te", "h2oppm", "pk"):
+                cb1[("aircc", "te", "h2oppm", "pk").index(nm)] = v
+            elif m is None:
+                rate[off[nm][0]] = v
+            else:
+                arr, i, j = m.group(1), int(m.group(2)), int(m.group(3) or 1)
+                if arr == "ph_rat":
+                    ph[i - 1] = v
+                elif arr == "c":
+                    c[i - 1] = v
+                elif arr == "fix":
+                    c[self.nvar + i - 1] = v
+                else:
+                    o, k = off[arr]
+                    rate[o + (j - 1) * nspec + (i - 1) if k > 0 else o + i - 1] = v
+        getattr(self.lib, "update_rconst_%s_" % sfx)()
         return np.ctypeslib.as_array(self.gdata.rconst).copy()
 
     def integrate(self, var, fix, rconst, tin=0.0, tout=10.0):

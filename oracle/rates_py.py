@@ -20,19 +20,89 @@ def _troe(e, a1, a2, b1, b2, fc, tref):
     return (a0 / (1.0 + a0 / b0)) * math.pow(fc, 1.0 / (1.0 + l * l))
 
 
-def _fdhetg(e, na, nb):
+K5555 = float(np.float32(55.55))
+DCLIM = 1.0e10
+# positions in the slot list of what the rate laws read from COMMON themselves (tools/extract_rates.py: fslot_names)
+FS = dict(H2OL=0, CLM=4, BRM=8, YXKMT_N2O5=12, YXKMT_CLNO3=16, YXKMT_BRNO3=20, YCW=24, YXKMTD_N2O5=28, YXKMTD_BRNO3=30,
+          YXKMTD_CLNO3=32, YXKMTD_HNO3=34, YXKMTD_NH3=36, YXKMTD_H2SO4=38, YCWD=40, YHENRY_HNO3=42, YXEQ_HNO3=43, C_HNO3=44,
+          C_HNO3L=45, C_NO3ML=47, XHAL=49)
+
+
+class E(list):
+    """env vector that also knows the slot list: e.at("YCWD", 1)"""
+    fslot = None
+
+    def at(self, key, k=0):
+        return self[self.fslot[FS[key] + k]]
+
+    def has(self, key):
+        return self.fslot[FS[key]] >= 0
+
+
+def _fmax(a, b):
+    return a if (a > b or b != b) else b
+
+
+def _fdhet(e, na, nb):      # fdhetg | fdheta | fdhett (kpp.f90:8198, 8269, 8311)
     na, nb = int(na), int(nb)
-    ycwd = e[9 + na - 1]
+    ycwd = e.at("YCWD", na - 1)
     if nb == 1:
-        yx = e[61 + na - 1]
+        yx = e.at("YXKMTD_HNO3", na - 1)
         x1 = yx * ycwd
-        caq = ((e[72 + na - 1] * 1.5e3) * 1.0e-2) / (e[70] + 1.0e-2)
+        if e.has("C_NO3ML"):
+            caq = 0.0
+            if (e.at("YXEQ_HNO3") + 1.0e-2) != 0.0:
+                caq = ((e.at("C_HNO3L", na - 1) + e.at("C_NO3ML", na - 1)) * 1.0e-2) / (e.at("YXEQ_HNO3") + 1.0e-2)
+        else:
+            caq = ((e.at("C_HNO3L", na - 1) * 1.5e3) * 1.0e-2) / (e.at("YXEQ_HNO3") + 1.0e-2)
         x2 = 0.0
-        if e[71] != 0.0 and e[69] != 0.0:
-            x2 = ((-yx) / (e[71] * e[69])) * caq
-        s = x1 + x2
-        return 0.0 if (0.0 > s or s != s) else s
-    return e[61 + 2 * (nb - 1) + na - 1] * ycwd
+        if e.at("C_HNO3") != 0.0 and e.at("YHENRY_HNO3") != 0.0:
+            x2 = ((-yx) / (e.at("C_HNO3") * e.at("YHENRY_HNO3"))) * caq
+        return _fmax(0.0, x1 + x2)
+    return e.at({2: "YXKMTD_N2O5", 3: "YXKMTD_NH3", 4: "YXKMTD_H2SO4"}[nb], na - 1) * ycwd
+
+
+def _fhet_t(e, a0, b0, c0):      # kpp.f90:7582
+    a0, b0, c0 = int(a0), int(b0), int(c0)
+    h2oa = e.at("H2OL", a0 - 1)
+    het = (h2oa + 5.0e2 * e.at("CLM", a0 - 1)) + 3.0e5 * e.at("BRM", a0 - 1)
+    xbr = h2oa if b0 == 1 else 5.0e2 if b0 == 2 else 3.0e5
+    xtr = e.at({1: "YXKMT_N2O5", 2: "YXKMT_CLNO3", 3: "YXKMT_BRNO3"}[c0], a0 - 1)
+    return ((xtr * e.at("YCW", a0 - 1)) * xbr) / het if het > 0.0 else 0.0
+
+
+def _fhet_d(e, xliq, xhet, a0, b0, c0):      # fhet_da | fhet_dt (kpp.f90:8023, 8111)
+    a0, b0, c0 = int(a0), int(b0), int(c0)
+    xhal = e.at("XHAL")
+    if xhet == 0.0:
+        xtr = e.at({1: "YXKMT_N2O5", 2: "YXKMT_CLNO3", 3: "YXKMT_BRNO3"}[c0], a0 - 1)
+        h2oa = e.at("H2OL", a0 - 1)
+        het = (h2oa + 5.0e2 * e.at("CLM", a0 - 1)) + 3.0e5 * e.at("BRM", a0 - 1)
+        yw = e.at("YCW", a0 - 1)
+        if xhal == 0.0:
+            if c0 in (2, 3):
+                xtr = 0.0
+            het = e.at("H2OL", a0 - 1)
+    else:
+        xtr = e.at({1: "YXKMTD_N2O5", 2: "YXKMTD_BRNO3", 3: "YXKMTD_CLNO3"}[c0], a0 - 1)
+        h2oa = (K5555 * e.at("YCWD", a0 - 1)) * 1.0e3
+        het = (h2oa + 5.0e2 * e.at("CLM", a0 - 1)) + 3.0e5 * e.at("BRM", a0 - 1)
+        yw = e.at("YCWD", a0 - 1)
+        if xhal == 0.0:
+            if c0 in (2, 3):
+                xtr = 0.0
+            het = (K5555 * e.at("YCWD", a0 - 1)) * 1.0e3
+    xbr = h2oa if b0 == 1 else 5.0e2 if b0 == 2 else 3.0e5
+    r = ((xtr * yw) * xbr) / het if het > 0.0 else 0.0
+    if (c0 in (2, 3) or b0 in (2, 3)) and xhal == 0.0:
+        r = 0.0
+    if xliq == 0.0:
+        r = 0.0
+    return r
+
+
+def _arr2(e, a0, b0):
+    return a0 * math.exp(b0 * (1.0 / e[1] - 3.3557e-3))
 
 
 def _sp23(e, a1, b1, a2, b2, a3, b3):
@@ -79,12 +149,28 @@ FUNCS = {
     "sp_23": _sp23,
     "fcn": _fcn,
     "dms_add": _dms,
-    "fdhetg": _fdhetg,
+    "fdhetg": _fdhet, "fdheta": _fdhet, "fdhett": _fdhet,
+    "farr2": _arr2,
+    "fhet_t": _fhet_t,
+    "fhet_da": _fhet_d, "fhet_dt": _fhet_d,
+    "fliq_60": lambda e, a1, b1, c, d: ((_arr2(e, a1, b1)) * c) / (c + 0.1 / d) if d > 0.0 else 0.0,
+    "dmin2": lambda e, a: a if a < DCLIM else DCLIM,
+    "dmin3": lambda e, a: a if a < DCLIM * 2.0 else DCLIM * 2.0,
+    "flsc4": lambda e, a, b, c: (a * b) * ((c * c) * c) if c > 0.0 else 0.0,
+    "flsc5": lambda e, a, b, c: (a * (b * b)) * (((c * c) * c) * c) if c > 0.0 else 0.0,      # flang expands c**4 as ((c*c)*c)*c
+    "flsc6": lambda e, a, b: a / b if b > 1.0e-15 else 0.0,
+    "uplim": lambda e, a, b, c, d: a / (1.0 + ((b / DCLIM) * _fmax(c, 0.0)) * d) if d > 0.0 else 0.0,
+    "uparm": lambda e, a0, b0, c, d, ee: _arr2(e, a0, b0) / (1.0 + ((c / DCLIM) * d) * ee) if d > 0.0 else 0.0,
+    "uplip": lambda e, a, b, c: (a / (1.0 + ((a / DCLIM) * _fmax(b, 0.0)) * c)) * (c * c) if c > 0.0 else 0.0,
+    "uparp": lambda e, a0, b0, c, d: (_arr2(e, a0, b0) / (1.0 + ((_arr2(e, a0, b0) / DCLIM) * c) * d)) * (d * d) if d > 0.0 else 0.0,
 }
 
 
-def evaluate(table, slot, env):
-    """rconst[nreact] for one env vector; table = the .rates.json dict, slot = {name: env index} (tools/extract_rates.py ENV)"""
+def evaluate(table, slot, env, fslot=None):
+    """rconst[nreact] for one env vector; table = the .rates.json dict, slot = {name: env index}, fslot = the slot list of the
+    mechanism (both from mistra_amd/mech/<mech>.rates_env.json)"""
+    env = E(float(x) for x in env)
+    env.fslot = fslot
     out = np.empty(table["nreact"])
     for r, prog in enumerate(table["programs"]):
         st = []

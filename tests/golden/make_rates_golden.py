@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/rates_gas.npz: inputs of Update_RCONST_g (the 74-double per-cell vector of tools/extract_rates.py
-ENV["gas"]) and the RCONST(331) the COMPILED REFERENCE makes of them (oracle/_ref/libmistra_ref.so: update_rconst_g_ and the
-rate laws of kpp.f90, flang -O2 -ffp-contract=off), for the parity test of the device evaluator (tests/test_gpu_rates.py).
+"""Generates tests/golden/rates_{gas,aer,tot}.npz: inputs of Update_RCONST_x (the per-cell vector whose entries
+mistra_amd/mech/<mech>.rates_env.json names: 74 / 330 / 544 doubles) and the RCONST the COMPILED REFERENCE makes of them
+(oracle/_ref/libmistra_ref.so: update_rconst_x_ and the rate laws of kpp.f90, flang -O2 -ffp-contract=off), for the parity tests
+of the rate tables (tests/test_rates.py) and of the device evaluator (tests/test_gpu_rates.py).
 
 The inputs are drawn, seeded, over the ranges the model visits: temperature 220-310 K, pressure 3e4-1.05e5 Pa with air
 density and water vapour to match, switches on/off, photolysis rates from zero (night) to daytime magnitudes, dry-aerosol
@@ -38,16 +39,53 @@ def draw(rng, n):
     return env
 
 
+def draw_generic(rng, names, n):
+    """aer / tot: every entry by its name (mistra_amd/mech/<mech>.rates_env.json)"""
+    env = np.zeros((n, len(names)))
+    te = rng.uniform(220.0, 310.0, n)
+    pk = rng.uniform(3.0e4, 1.05e5, n)
+    day = rng.integers(0, 2, n)
+    for i, nm in enumerate(names):
+        if nm == "aircc":
+            env[:, i] = pk / (1.380649e-23 * te) * 1.0e-6
+        elif nm == "te":
+            env[:, i] = te
+        elif nm == "h2oppm":
+            env[:, i] = 10.0 ** rng.uniform(1.0, 4.6, n)
+        elif nm == "pk":
+            env[:, i] = pk
+        elif nm == "conv1":
+            env[:, i] = 6.022e17 * rng.uniform(0.9, 1.1, n)
+        elif nm.startswith("cvv"):
+            env[:, i] = 10.0 ** rng.uniform(8, 12, n)                      # 1/LWC-like conversion factors
+        elif nm.startswith(("xhal", "xiod", "xliq", "xhet")):
+            env[:, i] = rng.integers(0, 2, n).astype(float)
+        elif nm.startswith("ph_rat"):
+            env[:, i] = day * 10.0 ** rng.uniform(-8, -2, n)
+        elif nm.startswith("fix"):
+            env[:, i] = 10.0 ** rng.uniform(-2, 2, n)
+        elif nm.startswith("c("):
+            env[:, i] = 10.0 ** rng.uniform(-14, -6, n) * rng.integers(0, 2, n)      # H+, halides, HNO3 ... incl. exact zeros
+        elif nm.startswith(("ycw", "ycwd")):
+            env[:, i] = 10.0 ** rng.uniform(-13, -6, n) * rng.integers(0, 2, n)
+        else:                                                               # yxkmt, yxkmtd, yhenry, yxeq, ykef, ykeb
+            env[:, i] = 10.0 ** rng.uniform(-6, 8, n) * rng.integers(0, 2, n)
+    return env
+
+
 def main():
-    rng = np.random.default_rng(20261004)
-    env = draw(rng, 96)
-    ref = Reference("gas")
-    rconst = np.stack([ref.update_rconst_gas(e) for e in env])
+    import json
     info = open(os.path.join(HERE, "..", "..", "oracle", "_ref", "BUILD_INFO")).read().replace("\n", "; ")
-    path = os.path.join(HERE, "rates_gas.npz")
-    np.savez_compressed(path, env=env, rconst=rconst, provenance=np.array("tests/golden/make_rates_golden.py, seed 20261004; " + info))
-    print(path, os.path.getsize(path), "bytes;", int((rconst != 0).sum(axis=1).min()), "..", int((rconst != 0).sum(axis=1).max()),
-          "non-zero rate constants per cell; finite:", bool(np.isfinite(rconst).all()))
+    for mech, n in (("gas", 96), ("aer", 48), ("tot", 48)):
+        rng = np.random.default_rng(20261004)
+        names = json.load(open(os.path.join(HERE, "..", "..", "mistra_amd", "mech", mech + ".rates_env.json")))["env"]
+        env = draw(rng, n) if mech == "gas" else draw_generic(rng, names, n)
+        ref = Reference(mech)
+        rconst = np.stack([ref.update_rconst(names, e) for e in env])
+        path = os.path.join(HERE, "rates_%s.npz" % mech)
+        np.savez_compressed(path, env=env, rconst=rconst, provenance=np.array("tests/golden/make_rates_golden.py, seed 20261004; " + info))
+        print(path, os.path.getsize(path), "bytes;", int((rconst != 0).sum(axis=1).min()), "..", int((rconst != 0).sum(axis=1).max()),
+              "non-zero rate constants per cell; finite:", bool(np.isfinite(rconst).all()))
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
-"""Update_RCONST_g on the device (-m gpu): the rate constants the HIP evaluator (mistra_amd/csrc/rates.hip) makes
-of 96 seeded input vectors against what the COMPILED REFERENCE made of them (tests/golden/rates_gas.npz: update_rconst_g_ and
-the rate laws of kpp.f90 through oracle/_ref/libmistra_ref.so, recorded by tests/golden/make_rates_golden.py).
+"""Update_RCONST_g/a/t on the device (-m gpu): the rate constants the HIP evaluator (mistra_amd/csrc/rates.hip)
+makes of seeded input vectors against what the COMPILED REFERENCE made of them (tests/golden/rates_<mech>.npz: update_rconst_x_
+and the rate laws of kpp.f90 through oracle/_ref/libmistra_ref.so, recorded by tests/golden/make_rates_golden.py).
 
 Tolerance: the table and the evaluation order are the reference's (tests/test_rates.py reproduces it bit for bit with the
 host libm); the device's exp / pow / log10 differ from the host's in the last place, and a rate law chains up to five of
@@ -24,20 +24,21 @@ def chem():
     return c
 
 
-def test_device_rate_constants_match_the_reference(chem):
-    g = np.load(os.path.join(REPO, "tests", "golden", "rates_gas.npz"))
+@pytest.mark.parametrize("mech", ["gas", "aer", "tot"])
+def test_device_rate_constants_match_the_reference(chem, mech):
+    g = np.load(os.path.join(REPO, "tests", "golden", "rates_%s.npz" % mech))
     env, want = g["env"], g["rconst"]
-    got = chem.update_rconst("gas", env)
+    got = chem.update_rconst(mech, env)
     assert got.shape == want.shape
     assert np.array_equal(got == 0.0, want == 0.0)
     nz = want != 0.0
     rel = np.abs(got[nz] - want[nz]) / np.abs(want[nz])
     exact = float((got[nz] == want[nz]).mean())
-    print("gas RCONST on the device vs compiled reference: %d values, %.1f %% bit-identical, max rel diff %.2e" % (int(nz.sum()), 100 * exact, rel.max()))
+    print("%s RCONST on the device vs compiled reference: %d values, %.1f %% bit-identical, max rel diff %.2e" % (mech, int(nz.sum()), 100 * exact, rel.max()))
     assert rel.max() <= 1e-13
     # reactions without a rate-law call are products of inputs and literals: no library function, no tolerance
     import json
-    table = json.load(open(os.path.join(REPO, "mistra_amd", "mech", "gas.rates.json")))
+    table = json.load(open(os.path.join(REPO, "mistra_amd", "mech", mech + ".rates.json")))
     plain = np.array([not any(t[0] == "call" for t in p) for p in table["programs"]])
     assert plain.sum() > 100 and np.array_equal(got[:, plain], want[:, plain])
 

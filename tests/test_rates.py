@@ -1,54 +1,59 @@
-"""Host logic of the device Update_RCONST_x path, CPU: the rate table tools/extract_rates.py cuts out of the
-generated Update_RCONST_g (gas.f:275-666), evaluated by a plain-Python restatement of the rate laws (oracle/rates_py.py),
-reproduces what the COMPILED REFERENCE computes from the same inputs (tests/golden/rates_gas.npz, made by
-tests/golden/make_rates_golden.py from oracle/_ref/libmistra_ref.so) — reaction by reaction, to the last bit where no
-transcendental function is involved and to 4 ulp where exp / pow / log10 of two libm builds may differ."""
+"""Host logic of the device Update_RCONST_x path, CPU: the rate tables tools/extract_rates.py cuts out of the
+generated Update_RCONST_x (gas.f:275-666 | aer.f:304-1364 | tot.f:1040-2768), evaluated by a plain-Python restatement of the 26
+rate laws they call (oracle/rates_py.py), reproduce what the COMPILED REFERENCE computes from the same inputs
+(tests/golden/rates_<mech>.npz, made by tests/golden/make_rates_golden.py from oracle/_ref/libmistra_ref.so) — every
+reaction of every mechanism, to the last bit: same evaluation order, same float32-literal semantics, the compiler's expansion
+of small integer powers, and the same host libm."""
 import json
 import os
-import sys
 
 import numpy as np
 import pytest
 
-from conftest import REPO
-
-sys.path.insert(0, os.path.join(REPO, "tools"))
+from conftest import MECHS, REPO
 
 
-def _load():
-    from extract_rates import ENV
-    table = json.load(open(os.path.join(REPO, "mistra_amd", "mech", "gas.rates.json")))
-    slot = {n: i for i, n in enumerate(ENV["gas"])}
-    g = np.load(os.path.join(REPO, "tests", "golden", "rates_gas.npz"))
-    return table, slot, g["env"], g["rconst"]
+def _load(mech):
+    table = json.load(open(os.path.join(REPO, "mistra_amd", "mech", mech + ".rates.json")))
+    ev = json.load(open(os.path.join(REPO, "mistra_amd", "mech", mech + ".rates_env.json")))
+    g = np.load(os.path.join(REPO, "tests", "golden", "rates_%s.npz" % mech))
+    return table, ev["env"], ev["fslot"], g["env"], g["rconst"]
 
 
-def test_extracted_gas_rate_table_reproduces_the_reference():
+@pytest.mark.parametrize("mech", MECHS)
+def test_extracted_rate_table_reproduces_the_reference(mech):
     from oracle.rates_py import evaluate
-    table, slot, env, want = _load()
-    assert table["nreact"] == 331 and len(slot) == 74
+    table, names, fslot, env, want = _load(mech)
+    assert table["nreact"] == want.shape[1] and len(names) == env.shape[1]
+    slot = {n: i for i, n in enumerate(names)}
     worst = 0.0
-    for i in range(0, env.shape[0], 3):
-        got = evaluate(table, slot, env[i])
+    for i in range(0, env.shape[0], 4):
+        got = evaluate(table, slot, env[i], fslot)
         assert np.array_equal(got == 0.0, want[i] == 0.0)
         nz = want[i] != 0.0
-        rel = np.abs(got[nz] - want[i][nz]) / np.abs(want[i][nz])
-        worst = max(worst, rel.max())
-    print("gas rate table vs compiled reference: max rel diff %.2e" % worst)
-    assert worst <= 1e-15
+        worst = max(worst, (np.abs(got[nz] - want[i][nz]) / np.abs(want[i][nz])).max())
+    print("%s rate table vs compiled reference: max rel diff %.2e" % (mech, worst))
+    assert worst == 0.0
 
 
-def test_binary_table_matches_json():
-    """mistra_amd/mech/gas.rates (what the library loads) holds the same programs as the JSON form."""
-    from extract_rates import ENV, FUNC_ID, OP
-    table, slot, _, _ = _load()
-    raw = open(os.path.join(REPO, "mistra_amd", "mech", "gas.rates"), "rb").read()
-    h = np.frombuffer(raw, np.int32, 6)
-    assert h[0] == 0x5441524B and h[2] == 331 and h[3] == len(ENV["gas"])
-    consts = np.frombuffer(raw, np.float64, h[4], 24)
-    offs = np.frombuffer(raw, np.int32, 332, 24 + 8 * h[4])
-    words = np.frombuffer(raw, np.int32, h[5], 24 + 8 * h[4] + 4 * 332)
-    fid = {v[0]: k for k, v in FUNC_ID.items()}
+@pytest.mark.parametrize("mech", MECHS)
+def test_binary_table_matches_json(mech):
+    """mistra_amd/mech/<mech>.rates (what the library loads) holds the same programs as the JSON form."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from extract_rates import FUNC_ID, OP
+    table, names, fslot, _, _ = _load(mech)
+    raw = open(os.path.join(REPO, "mistra_amd", "mech", mech + ".rates"), "rb").read()
+    h = np.frombuffer(raw, np.int32, 8)
+    n = table["nreact"]
+    assert h[0] == 0x5441524B and h[1] == 2 and h[2] == n and h[3] == len(names) and h[6] == len(fslot) == 50
+    consts = np.frombuffer(raw, np.float64, h[4], 32)
+    offs = np.frombuffer(raw, np.int32, n + 1, 32 + 8 * h[4])
+    words = np.frombuffer(raw, np.int32, h[5], 32 + 8 * h[4] + 4 * (n + 1))
+    assert np.array_equal(np.frombuffer(raw, np.int32, 50, 32 + 8 * h[4] + 4 * (n + 1) + 4 * h[5]), fslot)
+    ids = {}
+    for k, v in FUNC_ID.items():
+        ids.setdefault(v[0], set()).add(k)
     for r, prog in enumerate(table["programs"]):
         ws = words[offs[r]:offs[r + 1]]
         assert len(ws) == len(prog)
@@ -57,8 +62,8 @@ def test_binary_table_matches_json():
             if t[0] == "num":
                 assert op == OP["const"] and consts[arg] == float(t[1])
             elif t[0] == "call":
-                assert op == OP["call"] and fid[arg] == t[1]
+                assert op == OP["call"] and t[1] in ids[arg]
             elif t[0] in ("var", "arr"):
-                assert op == OP["env"] and 0 <= arg < 74
+                assert op == OP["env"] and 0 <= arg < len(names)
             else:
                 assert op == OP[t[0]]

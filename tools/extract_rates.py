@@ -222,30 +222,99 @@ def extract(mech):
     path = os.path.join(OUT, mech + ".rates.json")
     json.dump(table, open(path, "w"), separators=(",", ":"))
     print(mech, n, "reactions; functions", table["functions"], "; scalars", table["scalars"], "; arrays", table["arrays"], "->", path, os.path.getsize(path), "bytes")
-    if mech in ENV:
-        write_binary(mech, table, params)
+    write_binary(mech, table, params)
 
 
-# ---- binary form for the device evaluator (mistra_amd/csrc/rates.hip), for the mechanisms whose rate-law functions it has.
-# A cell's inputs are ONE vector of doubles ("env") in the order below — what Update_RCONST_x and its rate laws read from
-# COMMON /cb_1/, /kpp_rate_x/, /ph_r_x/ and C (kpp.f90:7140, gas_Global.h:76-96), and nothing else.
-ENV = {
-    "gas": ["aircc", "te", "h2oppm", "pk", "conv1", "xhal", "xiod", "xhet1", "xhet2", "ycwd(1)", "ycwd(2)"] +
+# ---- binary form for the device evaluator (mistra_amd/csrc/rates.hip).
+# A cell's inputs are ONE vector of doubles ("env"): what Update_RCONST_x and its rate laws read from COMMON /cb_1/,
+# /kpp_rate_x/, /ph_r_x/ and C (kpp.f90:7140, gas_Global.h:76-96 | aer_Global.h:76-88 | tot_Global.h:76-98), and nothing else:
+#   aircc te h2oppm pk | the scalars the assignments name | the array elements they name | what the rate-law FUNCTIONS read
+# from COMMON themselves (FSLOT_NAMES, in the fixed order the device code indexes them by; -1 where a mechanism has no such
+# entry).  The gas layout is spelled out (its fixture, tests/golden/rates_gas.npz, is in this order); aer and tot are built.
+GAS_ENV = (["aircc", "te", "h2oppm", "pk", "conv1", "xhal", "xiod", "xhet1", "xhet2", "ycwd(1)", "ycwd(2)"] +
            ["ph_rat(%d)" % i for i in range(1, 48)] + ["fix(1)", "fix(2)", "fix(3)"] +
-           # what fdhetg reads (kpp.f90:8198-8268): yxkmtd(sp, bin) for HNO3, N2O5, NH3, H2SO4; yhenry, yxeq, C of HNO3; C of HNO3l1/2
            ["yxkmtd(ind_hno3,1)", "yxkmtd(ind_hno3,2)", "yxkmtd(ind_n2o5,1)", "yxkmtd(ind_n2o5,2)", "yxkmtd(ind_nh3,1)",
             "yxkmtd(ind_nh3,2)", "yxkmtd(ind_h2so4,1)", "yxkmtd(ind_h2so4,2)", "yhenry(ind_hno3)", "yxeq(ind_hno3)",
-            "c(ind_hno3)", "c(ind_hno3l1)", "c(ind_hno3l2)"],
-}
+            "c(ind_hno3)", "c(ind_hno3l1)", "c(ind_hno3l2)"])
+
+
+def fslot_names():
+    """what the rate-law functions read from COMMON, symbolic; index = position the device code uses (rates.hip: FS_*)"""
+    n = []
+    n += ["fix(indf_h2ol%d)" % a for a in (1, 2, 3, 4)]                        # 0   FS_H2OL
+    n += ["c(ind_clml%d)" % a for a in (1, 2, 3, 4)]                           # 4   FS_CLM
+    n += ["c(ind_brml%d)" % a for a in (1, 2, 3, 4)]                           # 8   FS_BRM
+    n += ["yxkmt(ind_n2o5,%d)" % a for a in (1, 2, 3, 4)]                      # 12  FS_YXKMT_N2O5
+    n += ["yxkmt(ind_clno3,%d)" % a for a in (1, 2, 3, 4)]                     # 16  FS_YXKMT_CLNO3
+    n += ["yxkmt(ind_brno3,%d)" % a for a in (1, 2, 3, 4)]                     # 20  FS_YXKMT_BRNO3
+    n += ["ycw(%d)" % a for a in (1, 2, 3, 4)]                                 # 24  FS_YCW
+    for sp in ("n2o5", "brno3", "clno3", "hno3", "nh3", "h2so4"):              # 28  FS_YXKMTD (species-major, 2 bins)
+        n += ["yxkmtd(ind_%s,%d)" % (sp, a) for a in (1, 2)]
+    n += ["ycwd(1)", "ycwd(2)"]                                                # 40  FS_YCWD
+    n += ["yhenry(ind_hno3)", "yxeq(ind_hno3)", "c(ind_hno3)"]                 # 42 43 44
+    n += ["c(ind_hno3l1)", "c(ind_hno3l2)", "c(ind_no3ml1)", "c(ind_no3ml2)"]  # 45 46 47 48
+    n += ["xhal"]                                                              # 49
+    return n
+
+
+def resolve(name, params):
+    """symbolic array element -> numeric key 'arr(i,j)'; None if the mechanism does not have the species / the bin"""
+    m = re.match(r"(\w+)\((.*)\)$", name)
+    if not m:
+        return name
+    idx = []
+    for t in m.group(2).split(","):
+        t = t.strip()
+        if t.isdigit():
+            idx.append(int(t))
+        elif t in params:
+            idx.append(params[t])
+        else:
+            return None
+    return "%s(%s)" % (m.group(1), ",".join(str(i) for i in idx))
+
+
+NSPEC_BINS = {"gas": 2, "aer": 2, "tot": 4}
+
+
+def env_names(mech, table, params):
+    if mech == "gas":
+        names = [resolve(n, params) for n in GAS_ENV]
+        assert None not in names
+        return names
+    names = ["aircc", "te", "h2oppm", "pk"] + table["scalars"]
+    arr = sorted({(t[1],) + tuple(t[2:]) for p in table["programs"] for t in p if t[0] == "arr"})
+    names += ["%s(%s)" % (a[0], ",".join(str(i) for i in a[1:])) for a in arr]
+    have = set(names)
+    for n in fslot_names():
+        r = resolve(n, params)
+        if r is None or r in have:
+            continue
+        m = re.match(r"(\w+)\((?:\d+,)?(\d+)\)$", r)
+        if m and m.group(1) in ("yxkmt", "ycw") and int(m.group(2)) > NSPEC_BINS[mech]:
+            continue                                                            # a bin the mechanism does not have
+        names.append(r)
+        have.add(r)
+    return names
+
+
 FUNC_ID = {"farr": (0, 2), "farr_sp": (1, 4), "atk_3": (2, 5), "atk_3f": (3, 5), "shno3": (4, 6), "fbck": (5, 7), "fbckj": (6, 6),
-           "fbck2": (7, 6), "sp_17": (8, 2), "sp_23": (9, 6), "fcn": (10, 1), "dms_add": (11, 0), "fdhetg": (12, 2)}      # id, nargs
+           "fbck2": (7, 6), "sp_17": (8, 2), "sp_23": (9, 6), "fcn": (10, 1), "dms_add": (11, 0), "fdhetg": (12, 2),
+           "fdheta": (12, 2), "fdhett": (12, 2),      # one routine: the three differ in the caq line, told apart by the NO3- slots
+           "farr2": (13, 2), "fhet_t": (14, 3), "fhet_da": (15, 5), "fhet_dt": (15, 5), "fliq_60": (16, 4), "dmin2": (17, 1),
+           "dmin3": (18, 1), "flsc4": (19, 3), "flsc5": (20, 3), "flsc6": (21, 2), "uplim": (22, 4), "uparm": (23, 5),
+           "uplip": (24, 3), "uparp": (25, 4)}      # id, nargs
 OP = {"const": 0, "env": 1, "+": 2, "-": 3, "*": 4, "/": 5, "neg": 6, "call": 7}
 
 
 def write_binary(mech, table, params):
     import struct
-    env = ENV[mech]
+    env = env_names(mech, table, params)
     slot = {name: i for i, name in enumerate(env)}
+    fslot = []
+    for n in fslot_names():
+        r = resolve(n, params)
+        fslot.append(slot.get(r, -1) if r is not None else -1)
     consts, words, offs = [], [], [0]
 
     def const(v):
@@ -268,10 +337,12 @@ def write_binary(mech, table, params):
         offs.append(len(words))
     path = os.path.join(OUT, mech + ".rates")
     with open(path, "wb") as f:
-        f.write(struct.pack("<6i", 0x5441524B, 1, table["nreact"], len(env), len(consts), len(words)))      # 'KRAT'
+        f.write(struct.pack("<8i", 0x5441524B, 2, table["nreact"], len(env), len(consts), len(words), len(fslot), 0))      # 'KRAT' v2
         f.write(np.asarray(consts, np.float64).tobytes())
         f.write(np.asarray(offs, np.int32).tobytes())
         f.write(np.asarray(words, np.int32).tobytes())
+        f.write(np.asarray(fslot, np.int32).tobytes())
+    json.dump({"env": env, "fslot": fslot}, open(os.path.join(OUT, mech + ".rates_env.json"), "w"), separators=(",", ":"))
     print("   binary:", path, os.path.getsize(path), "bytes;", len(env), "env doubles per cell,", len(consts), "constants,", len(words), "words")
 
 
