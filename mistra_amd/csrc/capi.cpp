@@ -188,7 +188,7 @@ std::string mech_dir() {
   return "mech";
 }
 
-int default_nt(int mech) { return mech == MISTRA_MECH_GAS ? 128 : 512; }      // the workgroup sizes ros3_kernel.hip instantiates
+int default_nt(int mech) { return mech == MISTRA_MECH_GAS ? kGasNT : mech == MISTRA_MECH_AER ? kAerNT : kTotNT; }      // the workgroup sizes ros3_kernel.hip instantiates
 
 template <class MT>
 bool traits_match(const MechTables& t, int n_jnz, int tail_regs, bool scale_pass, const DenseTail& dense) {
@@ -201,13 +201,13 @@ int setup_mech(DeviceState& D, int mech) {
   std::string err;
   if (!S.tab.load(mech_dir() + "/" + kMechName[mech] + ".mech", &err)) return fail(err);
   S.nt = default_nt(mech);
-  const bool nt_ok = (mech == MISTRA_MECH_GAS && S.nt == 128) || (mech == MISTRA_MECH_AER && S.nt == 512) ||
-                     (mech == MISTRA_MECH_TOT && S.nt == 512);
+  const bool nt_ok = (mech == MISTRA_MECH_GAS && S.nt == kGasNT) || (mech == MISTRA_MECH_AER && S.nt == kAerNT) ||
+                     (mech == MISTRA_MECH_TOT && S.nt == kTotNT);
   if (!nt_ok) return fail(std::string("no kernel instantiated for workgroup size ") + std::to_string(S.nt) + " of " + kMechName[mech]);
   // LDS byte address of the A/B product array for this <mechanism, workgroup size> (the gather-sum tables hold addresses)
-  const uint32_t ab_base = 8u * (uint32_t)(mech == MISTRA_MECH_GAS   ? LdsLayout<GasTraits, 128>::AB
-                                           : mech == MISTRA_MECH_AER ? LdsLayout<AerTraits, 512>::AB
-                                                                     : LdsLayout<TotTraits, 512>::AB);
+  const uint32_t ab_base = 8u * (uint32_t)(mech == MISTRA_MECH_GAS   ? LdsLayout<GasTraits, kGasNT>::AB
+                                           : mech == MISTRA_MECH_AER ? LdsLayout<AerTraits, kAerNT>::AB
+                                                                     : LdsLayout<TotTraits, kTotNT>::AB);
   KernelSchedule K;
   try {
     const int max_temps = mech == MISTRA_MECH_GAS ? GasTraits::MAX_TEMPS : mech == MISTRA_MECH_AER ? AerTraits::MAX_TEMPS : TotTraits::MAX_TEMPS;
@@ -257,9 +257,9 @@ int setup_mech(DeviceState& D, int mech) {
 
 int launch(DeviceState& D, int mech, const KernelArgs& a, hipStream_t stream) {
   hipError_t e = hipErrorInvalidValue;
-  if (mech == MISTRA_MECH_GAS) e = launch_ros3<GasTraits, 128>(a, stream, &D.lds_configured[mech]);
-  else if (mech == MISTRA_MECH_AER) e = launch_ros3<AerTraits, 512>(a, stream, &D.lds_configured[mech]);
-  else e = launch_ros3<TotTraits, 512>(a, stream, &D.lds_configured[mech]);
+  if (mech == MISTRA_MECH_GAS) e = launch_ros3<GasTraits, kGasNT>(a, stream, &D.lds_configured[mech]);
+  else if (mech == MISTRA_MECH_AER) e = launch_ros3<AerTraits, kAerNT>(a, stream, &D.lds_configured[mech]);
+  else e = launch_ros3<TotTraits, kTotNT>(a, stream, &D.lds_configured[mech]);
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
   return 0;
 }
@@ -355,9 +355,9 @@ int integrate_host_on(DeviceState& D, int mech, int ncell, const double* var_in,
     double sum[kProfSlots] = {0};
     for (size_t c = 0; c < nc; c++)
       for (int k = 0; k < kProfSlots; k++) sum[k] += (double)h[c * kProfSlots + k];
-    const char* names[kProfSlots] = {"fun", "jac", "prepare", "lu", "solve(rest)", "norm", "other", "total", "solve_head_fwd", "solve_tail", "solve_head_bwd", "lu_scale", "lu_dense", "-", "-", "-"};
+    const char* names[kProfSlots] = {"fun", "jac", "prepare", "lu", "solve(rest)", "norm", "other", "total", "solve_head_fwd", "solve_tail", "solve_head_bwd", "lu_scale", "lu_dense", "jac_products", "jac_sums", "fun_products"};
     std::fprintf(stderr, "[mistra_chem profile] %s, %zu cells, mean shader-clock ticks per cell:", kMechName[mech], nc);
-    for (int k = 0; k < 13; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
+    for (int k = 0; k < kProfSlots; k++) std::fprintf(stderr, " %s=%.0f (%.1f%%)", names[k], sum[k] / nc, 100.0 * sum[k] / sum[7]);
     std::fprintf(stderr, "\n");
     prof.release();
   }

@@ -782,13 +782,15 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
 #pragma unroll
   for (int q = 0; q < (ZPT + 1) / 2; q++)
     zpos[q] = (uint32_t)G_(a.zero_pos)[(2 * q) * NT + t] | ((2 * q + 1 < ZPT ? (uint32_t)G_(a.zero_pos)[(2 * q + 1) * NT + t] : (uint32_t)kPosNone) << 16);
-  // factor words of the products this thread forms in Fun (one per owned reaction) and Jac_SP (up to three): static per
-  // mechanism, kept in registers for the whole integration instead of being fetched ~400 times per cell
-  uint64_t ffac[RPT], jfac[3 * RPT];
+  // factor words of the products this thread forms in Fun (one per owned reaction): static per mechanism, kept in registers
+  // for the whole integration.  The (up to three per reaction) words of Jac_SP's products are NOT: values that live across
+  // the calls of the step loop need callee-saved registers, there are not enough of those, and the compiler's answer was to
+  // spill nine of the twelve and reload them one at a time, each load's latency exposed.  jac() fetches them in one batch of
+  // coalesced loads instead (48 KB table, L2-resident; measured: the batch lands in ~380 cycles, Jac_SP's products went from
+  // 11 000 to 7 400 cycles per call, the kernel's scratch from 104 to 8 bytes per lane).
+  uint64_t ffac[RPT];
 #pragma unroll
   for (int q = 0; q < RPT; q++) ffac[q] = G_(a.fun_fac)[q * NT + t];
-#pragma unroll
-  for (int q = 0; q < 3 * RPT; q++) jfac[q] = G_(a.jac_fac)[q * NT + t];
   if (t < NFIX) X[NVAR + t] = G_(a.fix)[(size_t)cell * NFIX + t];
   if (t < NCONST) X[NVAR + NFIX + t] = G_(a.consts)[t];
   if constexpr (MT::DENSE_ND > 0) {      // the dense tail block's row table stays in LDS for the whole call
@@ -853,6 +855,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       AB[(uint32_t)(w >> 48)] = p;            // a slot without a reaction (rct = 0) writes the spare cell: no branch
     }
     lds_barrier();
+    lap(15);
     // sums land in this thread's own cells of XS (free here: the solves copy their result out before Fun runs again);
     // a thread without a species parks its (empty) sum in the trash cell
     gsum_run<NT, MT::RING_LOW>(a.vdot, wave, lane, t < NVAR ? 8u * (uint32_t)(NNZ + t) : 8u * (uint32_t)(NNZ + NVAR + 2),
@@ -867,13 +870,19 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   // ---- Jac_SP_x (gas.f:2656) on the V already in X: B products under their reaction, JVS sums into registers
   double jac0[JPT];
   auto jac = [&]() {
+    uint64_t jfac[3 * RPT];
+    {
+      const uint64_t* jf = a.jac_fac;
+      asm volatile("" : "+s"(jf));      // opaque: loads through it are not hoisted out of the step loop (and spilled there)
+#pragma unroll
+      for (int q = 0; q < 3 * RPT; q++) jfac[q] = G_(jf)[q * NT + t];
+    }
     lds_barrier();   // every lane is done reading AB as A
 #pragma unroll
     for (int q = 0; q < RPT; q++) {
 #pragma unroll
       for (int b = 0; b < 3; b++) {
-        uint64_t w = jfac[q * 3 + b];
-        asm volatile("" : "+v"(w));
+        const uint64_t w = jfac[q * 3 + b];
         double p = rct[q] * X[w & 0xFFFFu];
         p = p * X[(w >> 16) & 0xFFFFu];
         p = p * X[(w >> 32) & 0xFFFFu];
@@ -881,8 +890,10 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       }
     }
     lds_barrier();
+    lap(13);
     // sums land in this thread's own cells of the Ghimj area (free here: ros_PrepareMatrix rebuilds it from jac0)
     gsum_run<NT, MT::RING_LOW>(a.jvs, wave, lane, 8u * (uint32_t)t, 8u * (uint32_t)NT);
+    lap(14);
 #pragma unroll
     for (int q = 0; q < JPT; q++) jac0[q] = M[q * NT + t];
   };
@@ -1184,9 +1195,9 @@ extern "C" int mistra_diag_dense_stamps(unsigned long long* out16, int reset) {
 }
 #endif
 
-template hipError_t launch_ros3<GasTraits, 128>(const KernelArgs&, hipStream_t, bool*);
-template hipError_t launch_ros3<AerTraits, 512>(const KernelArgs&, hipStream_t, bool*);
-template hipError_t launch_ros3<TotTraits, 512>(const KernelArgs&, hipStream_t, bool*);
+template hipError_t launch_ros3<GasTraits, kGasNT>(const KernelArgs&, hipStream_t, bool*);
+template hipError_t launch_ros3<AerTraits, kAerNT>(const KernelArgs&, hipStream_t, bool*);
+template hipError_t launch_ros3<TotTraits, kTotNT>(const KernelArgs&, hipStream_t, bool*);
 // (a 1024-thread tot variant was measured slower, and instantiating it caps the register budget of the shared
 //  non-inlined device functions at that of a 16-wave workgroup)
 

@@ -12,8 +12,27 @@
 
 namespace mistra {
 
-struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 16, WAVES_PER_SIMD = 4, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
-struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2, MAX_TEMPS = 192, WAVES_PER_SIMD = 4, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
+// Workgroup sizes and register budgets (waves per SIMD the compiler must leave room for) of the three instantiations; the
+// macros exist for same-box A/B builds (tools/build_variant.sh), the product library is built without them.
+#ifndef MISTRA_GAS_NT
+#define MISTRA_GAS_NT 128
+#endif
+#ifndef MISTRA_AER_NT
+#define MISTRA_AER_NT 512
+#endif
+#ifndef MISTRA_TOT_NT
+#define MISTRA_TOT_NT 512
+#endif
+#ifndef MISTRA_GAS_WPS
+#define MISTRA_GAS_WPS 3
+#endif
+#ifndef MISTRA_AER_WPS
+#define MISTRA_AER_WPS 4
+#endif
+constexpr int kGasNT = MISTRA_GAS_NT, kAerNT = MISTRA_AER_NT, kTotNT = MISTRA_TOT_NT;
+
+struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 16, WAVES_PER_SIMD = MISTRA_GAS_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
+struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2, MAX_TEMPS = 192, WAVES_PER_SIMD = MISTRA_AER_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
 struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2, MAX_TEMPS = 768, WAVES_PER_SIMD = 2, DENSE_ND = 64, DENSE_KB = 14; static constexpr bool RING_LOW = false, SCALE_PASS = true; };
 
 constexpr int round_up2(int x) { return (x + 1) & ~1; }
@@ -25,8 +44,8 @@ struct LdsLayout {
   static constexpr int M = 0;                                         // Ghimj | XS | 0.0 | 1.0 | trash | -1.0 | R | temps
   static constexpr int X = M + round_up2(MT::NNZ + 2 * MT::NVAR + 4 + MT::MAX_TEMPS);  // V | F | consts
   static constexpr int AB = X + round_up2(MT::NVAR + MT::NFIX + MT::NCONST);           // A or B products
-  static constexpr int AB_TRASH = max_i(MT::NREACT, MT::NB);                           // spare cell: products no reaction owns land here
-  static constexpr int RED = AB + round_up2(AB_TRASH + 1);                             // per-wave partial sums
+  static constexpr int AB_TRASH = max_i(MT::NREACT, MT::NB);                           // spare cells, one per lane: products no reaction owns land here
+  static constexpr int RED = AB + round_up2(AB_TRASH + 64);                            // (one shared cell: every such store of a wave hit the same address, and LDS serialises those)                             // per-wave partial sums
   static constexpr int FLAGS = RED + 32;
   static constexpr int DINFO = FLAGS + 2;                                               // dense tail block: row table, 192 x 16 bytes (schedule.hpp: DenseTail)
   static constexpr int TOTAL = DINFO + (MT::DENSE_ND > 0 ? 192 * 2 : 0);

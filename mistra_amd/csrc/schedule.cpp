@@ -767,8 +767,9 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   const uint64_t one = (uint64_t)(m.nvar + m.nfix);       // X slot of the constant 1.0
 
   // ---- Fun_x products
-  const uint64_t ab_trash = (uint64_t)std::max(m.nreact, m.nb);     // spare cell behind the A/B product array (LdsLayout::AB_TRASH)
-  S.fun_fac.assign((size_t)S.rpt * nt, one | (one << 16) | (one << 32) | (ab_trash << 48));
+  const uint64_t ab_trash = (uint64_t)std::max(m.nreact, m.nb);     // spare cells behind the A/B product array, one per lane (LdsLayout::AB_TRASH)
+  S.fun_fac.resize((size_t)S.rpt * nt);
+  for (size_t i = 0; i < S.fun_fac.size(); i++) S.fun_fac[i] = one | (one << 16) | (one << 32) | ((ab_trash + (i % (size_t)nt) % 64) << 48);
   for (int r = 0; r < m.nreact; r++) {
     uint64_t f[3] = {one, one, one};
     int nf = m.a_ptr[r + 1] - m.a_ptr[r];
@@ -787,7 +788,8 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   }
 
   // ---- Jac_SP_x products, under the owning reaction
-  S.jac_fac.assign((size_t)S.rpt * 3 * nt, one | (one << 16) | (one << 32) | (ab_trash << 48));
+  S.jac_fac.resize((size_t)S.rpt * 3 * nt);
+  for (size_t i = 0; i < S.jac_fac.size(); i++) S.jac_fac[i] = one | (one << 16) | (one << 32) | ((ab_trash + (i % (size_t)nt) % 64) << 48);
   {
     std::vector<int> used((size_t)m.nreact, 0);
     for (int b = 0; b < m.nb; b++) {
