@@ -67,7 +67,7 @@ def build_lib(force=False, verbose=False):
 def ring_register_report(isa_path=None):
     """Checks the one assumption the table look-ahead ring of ros3_kernel.hip rests on (see the comment there): in the
     non-inlined device functions, every register the COMPILER allocates stays below the ring's blocks (v192.. or, in the
-    low placement, v96..), so a
+    low placement, v64..), so a
     table load landing in the ring can never hit a compiler value.  Compiles the kernel source to gfx950 assembly and
     scans it.  Returns {function: highest VGPR named outside inline asm}; raises if a ring-using function reaches its ring."""
     import re
@@ -90,7 +90,7 @@ def ring_register_report(isa_path=None):
                 in_asm = True
             elif "ASMEND" in l:
                 in_asm = False
-            elif in_asm and re.search(r"global_load_dwordx4 v\[(96|192):\d+\], v\[\d+:\d+\], off", l):
+            elif in_asm and re.search(r"global_load_dwordx4 v\[(64|192):\d+\], v\[\d+:\d+\], off", l):
                 ring_users.add(name)         # the function issues ring loads (vm_ring_load) itself; (vm_run's own ring is
                                              # loaded and consumed inside ONE asm statement that lists it as clobbered)
             elif "Folded Spill" in l or "Folded Reload" in l:
@@ -101,7 +101,7 @@ def ring_register_report(isa_path=None):
         report[name] = hi
         low = re.search(r"(gsum_run|tail_solve|scale_run)I.*Lb([01])E+[A-Z]", name)       # last template argument: ring placement LOW
         if low:
-            limit = 96 if low.group(2) == "1" else 192
+            limit = 64 if low.group(2) == "1" else 192
             if hi >= limit:
                 raise RuntimeError("%s: the compiler allocates v%d, inside the look-ahead ring's register blocks (v%d..)" % (name, hi, limit))
         elif name in ring_users and "ros3_integrate_kernel" not in name:

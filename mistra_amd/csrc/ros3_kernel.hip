@@ -80,13 +80,14 @@ __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || 
 // §5.7 item 1).  The ring therefore lives in fixed registers named only by the two statements below; the consume
 // statement waits and copies out in ONE asm (§5.7 form i).  Loads are in flight only inside the two non-inlined functions
 // that use the ring (each drains it before returning), and those functions' own values sit below the ring (they need
-// < 72 registers; tests/test_capi.py checks the generated ISA), so nothing of the compiler's can be hit by a landing
+// < 64 registers; mistra_amd/build.py checks the generated ISA before it links), so nothing of the compiler's can be hit by a landing
 // load; the callers see the blocks as ordinary call-clobbered registers.  Two placements (LOW):
 //   false  v192-199, v208-215, v224-231, v240-247: four caller-saved blocks at the top of the file, nothing to save — for
 //          kernels that run two waves per SIMD and have 256 registers (tot: one cell fills a CU's LDS anyway);
-//   true   v96-127: for kernels held to 128 registers so that FOUR waves per SIMD fit (aer: two cells per CU instead of
-//          one, +39 %; gas: eight instead of four); two of the four blocks are callee-saved there and cost a save/restore
-//          per call (~1 % on tot, which is why tot keeps the high placement).
+//   true   v64-71, v80-87, v96-103, v112-119: four caller-saved blocks again, for kernels held to 128 (aer: FOUR waves per
+//          SIMD, two cells per CU instead of one, +39 %) or 168 registers (gas); the functions' own values stay below v64
+//          (the build checks it).  (Until round 2 this ring was v96-127: two of those blocks are callee-saved, every call
+//          of gsum_run / tail_solve stored and reloaded 16 registers per lane — most of the aer kernel's HBM-side traffic.)
 // Loads return in issue order, hence "at most PENDING outstanding" means the oldest one — the slot about to be
 // consumed — has landed.  (An earlier version kept the ring in AGPRs: any AGPR use halves the compiler's VGPR budget
 // on gfx950, which cost the kernel ~100 spilled registers.)
@@ -96,14 +97,14 @@ __device__ __forceinline__ void vm_ring_load(gptr<u32x4> p) {
   asm volatile("global_load_dwordx4 v[" #R0 ":" #R3 "], %0, off offset:%1" : : "v"(p), "n"(BYTE_OFFSET)             \
                : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3)
   if constexpr (LOW) {
-    if constexpr (K == 0) MISTRA_RING_LOAD(96, 97, 98, 99);
-    else if constexpr (K == 1) MISTRA_RING_LOAD(100, 101, 102, 103);
-    else if constexpr (K == 2) MISTRA_RING_LOAD(104, 105, 106, 107);
-    else if constexpr (K == 3) MISTRA_RING_LOAD(108, 109, 110, 111);
-    else if constexpr (K == 4) MISTRA_RING_LOAD(112, 113, 114, 115);
-    else if constexpr (K == 5) MISTRA_RING_LOAD(116, 117, 118, 119);
-    else if constexpr (K == 6) MISTRA_RING_LOAD(120, 121, 122, 123);
-    else MISTRA_RING_LOAD(124, 125, 126, 127);
+    if constexpr (K == 0) MISTRA_RING_LOAD(64, 65, 66, 67);
+    else if constexpr (K == 1) MISTRA_RING_LOAD(68, 69, 70, 71);
+    else if constexpr (K == 2) MISTRA_RING_LOAD(80, 81, 82, 83);
+    else if constexpr (K == 3) MISTRA_RING_LOAD(84, 85, 86, 87);
+    else if constexpr (K == 4) MISTRA_RING_LOAD(96, 97, 98, 99);
+    else if constexpr (K == 5) MISTRA_RING_LOAD(100, 101, 102, 103);
+    else if constexpr (K == 6) MISTRA_RING_LOAD(112, 113, 114, 115);
+    else MISTRA_RING_LOAD(116, 117, 118, 119);
   } else {
     if constexpr (K == 0) MISTRA_RING_LOAD(192, 193, 194, 195);
     else if constexpr (K == 1) MISTRA_RING_LOAD(196, 197, 198, 199);
@@ -125,14 +126,14 @@ __device__ __forceinline__ u32x4 vm_ring_take() {
                "\n\tv_mov_b32 %2, v" #R2 "\n\tv_mov_b32 %3, v" #R3                                                    \
                : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : "n"(PENDING) : "memory")
   if constexpr (LOW) {
-    if constexpr (K == 0) MISTRA_RING_TAKE(96, 97, 98, 99);
-    else if constexpr (K == 1) MISTRA_RING_TAKE(100, 101, 102, 103);
-    else if constexpr (K == 2) MISTRA_RING_TAKE(104, 105, 106, 107);
-    else if constexpr (K == 3) MISTRA_RING_TAKE(108, 109, 110, 111);
-    else if constexpr (K == 4) MISTRA_RING_TAKE(112, 113, 114, 115);
-    else if constexpr (K == 5) MISTRA_RING_TAKE(116, 117, 118, 119);
-    else if constexpr (K == 6) MISTRA_RING_TAKE(120, 121, 122, 123);
-    else MISTRA_RING_TAKE(124, 125, 126, 127);
+    if constexpr (K == 0) MISTRA_RING_TAKE(64, 65, 66, 67);
+    else if constexpr (K == 1) MISTRA_RING_TAKE(68, 69, 70, 71);
+    else if constexpr (K == 2) MISTRA_RING_TAKE(80, 81, 82, 83);
+    else if constexpr (K == 3) MISTRA_RING_TAKE(84, 85, 86, 87);
+    else if constexpr (K == 4) MISTRA_RING_TAKE(96, 97, 98, 99);
+    else if constexpr (K == 5) MISTRA_RING_TAKE(100, 101, 102, 103);
+    else if constexpr (K == 6) MISTRA_RING_TAKE(112, 113, 114, 115);
+    else MISTRA_RING_TAKE(116, 117, 118, 119);
   } else {
     if constexpr (K == 0) MISTRA_RING_TAKE(192, 193, 194, 195);
     else if constexpr (K == 1) MISTRA_RING_TAKE(196, 197, 198, 199);

@@ -66,12 +66,13 @@ def test_product_does_not_import_oracle():
 
 
 def test_lookahead_ring_registers_are_out_of_the_compilers_reach():
-    """ros3_kernel.hip streams its tables through a ring of fixed VGPRs (v192..v247, or v96..v127 for the mechanisms run at four waves
-    per SIMD) inside two non-inlined device functions; that is only sound while the compiler's own values in those
+    """ros3_kernel.hip streams its tables through a ring of fixed VGPRs (v192..v247, or four blocks from v64 up for the mechanisms run at three or
+    four waves per SIMD) inside two non-inlined device functions; that is only sound while the compiler's own values in those
     functions stay below the ring (build.py scans the
     generated gfx950 assembly).  Cross-compiles, no GPU needed."""
     from mistra_amd.build import ring_register_report
     rep = ring_register_report()          # raises if a function's own registers reach its ring
     dev = {k: v for k, v in rep.items() if "gsum_run" in k or "tail_solve" in k or "scale_run" in k}
     assert len(dev) >= 9, rep
-    assert max(dev.values()) < 96, dev    # today all of them stay clear even of the low placement
+    low = {k: v for k, v in dev.items() if "Lb1E" in k}
+    assert low and max(low.values()) < 64, low      # (ring_register_report has raised already if not)
