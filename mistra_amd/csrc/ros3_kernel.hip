@@ -846,14 +846,27 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       if (s < NVAR) X[s] = v[q];
     }
     lds_barrier();
+    {
+      // every factor read is issued before the first product is stored: X and the product array are one LDS object to the
+      // compiler, so a read behind a store stays behind it, and product by product each one waited out its own LDS round trip
+      double f0[RPT], f1[RPT], f2[RPT];
+      uint32_t slot[RPT];
 #pragma unroll
-    for (int q = 0; q < RPT; q++) {
-      uint64_t w = ffac[q];
-      asm volatile("" : "+v"(w));   // decode here: hoisted out of the step loop, the derived addresses only spill
-      double p = rct[q] * X[w & 0xFFFFu];
-      p = p * X[(w >> 16) & 0xFFFFu];
-      p = p * X[(w >> 32) & 0xFFFFu];
-      AB[(uint32_t)(w >> 48)] = p;            // a slot without a reaction (rct = 0) writes the spare cell: no branch
+      for (int q = 0; q < RPT; q++) {
+        uint64_t w = ffac[q];
+        asm volatile("" : "+v"(w));   // decode here: hoisted out of the step loop, the derived addresses only spill
+        f0[q] = X[w & 0xFFFFu];
+        f1[q] = X[(w >> 16) & 0xFFFFu];
+        f2[q] = X[(w >> 32) & 0xFFFFu];
+        slot[q] = (uint32_t)(w >> 48);
+      }
+#pragma unroll
+      for (int q = 0; q < RPT; q++) {
+        double p = rct[q] * f0[q];
+        p = p * f1[q];
+        p = p * f2[q];
+        AB[slot[q]] = p;            // a slot without a reaction (rct = 0) writes a spare cell: no branch
+      }
     }
     lds_barrier();
     lap(15);
@@ -880,14 +893,21 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     }
     lds_barrier();   // every lane is done reading AB as A
 #pragma unroll
-    for (int q = 0; q < RPT; q++) {
+    for (int q = 0; q < RPT; q++) {      // the three products under one reaction: nine factor reads in flight, then the stores (see fun)
+      double f0[3], f1[3], f2[3];
 #pragma unroll
       for (int b = 0; b < 3; b++) {
         const uint64_t w = jfac[q * 3 + b];
-        double p = rct[q] * X[w & 0xFFFFu];
-        p = p * X[(w >> 16) & 0xFFFFu];
-        p = p * X[(w >> 32) & 0xFFFFu];
-        AB[(uint32_t)(w >> 48)] = p;          // unused product slots write the spare cell: no branch, the products interleave
+        f0[b] = X[w & 0xFFFFu];
+        f1[b] = X[(w >> 16) & 0xFFFFu];
+        f2[b] = X[(w >> 32) & 0xFFFFu];
+      }
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        double p = rct[q] * f0[b];
+        p = p * f1[b];
+        p = p * f2[b];
+        AB[(uint32_t)(jfac[q * 3 + b] >> 48)] = p;          // unused product slots write a spare cell: no branch
       }
     }
     lds_barrier();
