@@ -308,12 +308,104 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
 }
 
+// ---- forward chain over the dense tail block (schedule.hpp: DenseTail), inside the tail chain's wave: lane l holds entry l of
+//      the block's 64 rows, lane row r (16 lanes) = 16x16 block row r.  Per block column J:
+//        1. the 16 unknowns of block J, in lane row J: x(i) -= L(i,j) x(j), j ascending — the pivot value reaches the other lanes of
+//           its lane row inside the multiply-add itself (DPP row_newbcast on v_fmac_f64: measured 10 cycles per dependent step
+//           with one wait state, 14 with the two the ISA manual asks for; the v_readlane -> SGPR -> VALU round trip of the generic
+//           chain costs ~57);
+//        2. the 16 finished values go to all four lane rows (gfx950 v_permlane16_swap / v_permlane32_swap);
+//        3. the lane rows below take their 16 terms, j ascending, again by DPP.
+//      Every row still receives its terms in ascending column order with the operands and the fused multiply-add of the generic
+//      chain: the results are bit-identical.  A row of the block is contiguous in Ghimj (CSR, columns ascending) and only its
+//      first column may be missing (the host checks the row table for that), so the 16 operands of a block column are 16
+//      consecutive cells from one per-lane base address: no index tables, no address arithmetic per column.
+template <int ROW>
+__device__ __forceinline__ double lane_row_to_all(double v) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
+  // permlane16_swap(a, b): a.row1 <-> b.row0, a.row3 <-> b.row2.   From a = b = v: a = [v0 v0 v2 v2], b = [v1 v1 v3 v3]
+  const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const uint32_t a = l16[ROW & 1], b = h16[ROW & 1];
+  // permlane32_swap(a, b): a.upper32 <-> b.lower32.   From a = b: a = [lower lower], b = [upper upper]
+  const auto l32 = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+  const auto h32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  return __builtin_bit_cast(double, (uint64_t)l32[(ROW >> 1) & 1] | ((uint64_t)h32[(ROW >> 1) & 1] << 32));
+}
+// One block column J.  The two phases are ONE asm statement each: between separate statements the compiler adds wait
+// states of its own, and masking the operands of step 1 by lane (v_cmp + 2 v_cndmask per value) cost more issue slots
+// than the steps themselves.  Here the lanes that take step j are selected through EXEC, a scalar move per step that also
+// serves as one of the two wait states the DPP read needs (tools/ubench/dpp.hip): the rows i >= j of the block — row j
+// itself stays enabled because a DPP read of a disabled lane is no read at all; its operand is the diagonal cell, which
+// dense_fwd_chain has set to zero (the diagonal of U is dead once its reciprocal is published), so the step leaves it alone.
+#define MISTRA_DIAG_STEP(J, EXECHALF, MASK) \
+  "s_mov_b32 " EXECHALF ", " MASK "\n\ts_nop 0\n\tv_fmac_f64_dpp %[x], -%[x], %[c" #J "] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
+#define MISTRA_DIAG_PHASE(EXECHALF, OTHERHALF, SH)                                                                             \
+  asm volatile("s_mov_b32 " OTHERHALF ", 0\n\t"                                                                                 \
+               MISTRA_DIAG_STEP(0, EXECHALF, "0xffff" SH) MISTRA_DIAG_STEP(1, EXECHALF, "0xfffe" SH) MISTRA_DIAG_STEP(2, EXECHALF, "0xfffc" SH)   \
+               MISTRA_DIAG_STEP(3, EXECHALF, "0xfff8" SH) MISTRA_DIAG_STEP(4, EXECHALF, "0xfff0" SH) MISTRA_DIAG_STEP(5, EXECHALF, "0xffe0" SH)   \
+               MISTRA_DIAG_STEP(6, EXECHALF, "0xffc0" SH) MISTRA_DIAG_STEP(7, EXECHALF, "0xff80" SH) MISTRA_DIAG_STEP(8, EXECHALF, "0xff00" SH)   \
+               MISTRA_DIAG_STEP(9, EXECHALF, "0xfe00" SH) MISTRA_DIAG_STEP(10, EXECHALF, "0xfc00" SH) MISTRA_DIAG_STEP(11, EXECHALF, "0xf800" SH) \
+               MISTRA_DIAG_STEP(12, EXECHALF, "0xf000" SH) MISTRA_DIAG_STEP(13, EXECHALF, "0xe000" SH) MISTRA_DIAG_STEP(14, EXECHALF, "0xc000" SH) \
+               "s_mov_b64 exec, -1"                                                                                             \
+               : [x] "+v"(x)                                                                                                    \
+               : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), \
+                 [c8] "v"(c[8]), [c9] "v"(c[9]), [c10] "v"(c[10]), [c11] "v"(c[11]), [c12] "v"(c[12]), [c13] "v"(c[13]), [c14] "v"(c[14]))
+#define MISTRA_UPD_STEP(J, ROWMASK) "v_fmac_f64_dpp %[x], -%[xb], %[c" #J "] row_newbcast:" #J " row_mask:" ROWMASK " bank_mask:0xf\n\t"
+#define MISTRA_UPDATE_PHASE(ROWMASK)                                                                                           \
+  asm volatile("s_nop 1\n\t"                                                                                                   \
+               MISTRA_UPD_STEP(0, ROWMASK) MISTRA_UPD_STEP(1, ROWMASK) MISTRA_UPD_STEP(2, ROWMASK) MISTRA_UPD_STEP(3, ROWMASK)   \
+               MISTRA_UPD_STEP(4, ROWMASK) MISTRA_UPD_STEP(5, ROWMASK) MISTRA_UPD_STEP(6, ROWMASK) MISTRA_UPD_STEP(7, ROWMASK)   \
+               MISTRA_UPD_STEP(8, ROWMASK) MISTRA_UPD_STEP(9, ROWMASK) MISTRA_UPD_STEP(10, ROWMASK) MISTRA_UPD_STEP(11, ROWMASK) \
+               MISTRA_UPD_STEP(12, ROWMASK) MISTRA_UPD_STEP(13, ROWMASK) MISTRA_UPD_STEP(14, ROWMASK)                            \
+               "v_fmac_f64_dpp %[x], -%[xb], %[c15] row_newbcast:15 row_mask:" ROWMASK " bank_mask:0xf"                         \
+               : [x] "+v"(x)                                                                                                    \
+               : [xb] "v"(xb), [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]),    \
+                 [c7] "v"(c[7]), [c8] "v"(c[8]), [c9] "v"(c[9]), [c10] "v"(c[10]), [c11] "v"(c[11]), [c12] "v"(c[12]), [c13] "v"(c[13]),          \
+                 [c14] "v"(c[14]), [c15] "v"(c[15]))
+template <int J>
+__device__ __forceinline__ void dense_fwd_block(double& x, const uint32_t base, const uint32_t col0, const int lane) {
+  double c[16];      // this lane's row, columns 16J .. 16J+15: L(i,j) left of the diagonal, 0 on it; to the right U (those lanes sit the step out)
+#pragma unroll
+  for (int j = 0; j < 16; j++) c[j] = lds_ld((J == 0 && j == 0) ? col0 : base + 8u * (uint32_t)(16 * J + j));
+  // 1. lane row J, inside its 16x16 block
+  if constexpr (J == 0) MISTRA_DIAG_PHASE("exec_lo", "exec_hi", "");
+  else if constexpr (J == 1) MISTRA_DIAG_PHASE("exec_lo", "exec_hi", "0000");
+  else if constexpr (J == 2) MISTRA_DIAG_PHASE("exec_hi", "exec_lo", "");
+  else MISTRA_DIAG_PHASE("exec_hi", "exec_lo", "0000");
+  if constexpr (J < 3) {
+    const double xb = lane_row_to_all<J>(x);      // 2.
+    if constexpr (J == 0) MISTRA_UPDATE_PHASE("0xe");      // 3. the lane rows below
+    else if constexpr (J == 1) MISTRA_UPDATE_PHASE("0xc");
+    else MISTRA_UPDATE_PHASE("0x8");
+  }
+}
+#undef MISTRA_DIAG_STEP
+#undef MISTRA_DIAG_PHASE
+#undef MISTRA_UPD_STEP
+#undef MISTRA_UPDATE_PHASE
+__device__ __forceinline__ void dense_fwd_chain(double& x, const uint32_t info_addr, const uint32_t zero_addr, const int lane) {
+  const u32x4 info = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(info_addr + 16u * (uint32_t)lane);
+  const uint32_t absent0 = info.y & 1u;                              // (only column 0 of a row may be missing: schedule.cpp, build_dense_tail)
+  const uint32_t base = 8u * (info.x - absent0);                     // cell of column c >= 1: base + 8 c
+  const uint32_t col0 = absent0 ? zero_addr : 8u * info.x;
+  lds_st(base + 8u * (uint32_t)lane, 0.0);                          // the row's diagonal cell (see dense_fwd_block); the reads below are this wave's own, in order
+  dense_fwd_block<0>(x, base, col0, lane);
+  dense_fwd_block<1>(x, base, col0, lane);
+  dense_fwd_block<2>(x, base, col0, lane);
+  dense_fwd_block<3>(x, base, col0, lane);
+}
+
 // FWD_FROM: first 64-row block of the forward chain.  0: the whole forward chain; R: none (the vector has been
 // forward-swept already — stage 1, inside the LU program); 1 of R = 2: only the columns of the dense tail block, whose
 // rows the LU program leaves without exactly those terms (schedule.cpp: lu_entries, dense_h)
-template <int R, int FWD_FROM, bool LOW>
+// DENSE_INFO: LDS byte address of the dense tail block's row table (0: no such block).  With it, the last 64 columns of the
+// forward chain — the block's own — are dense_fwd_chain's.
+template <int R, int FWD_FROM, bool LOW, uint32_t DENSE_INFO = 0, uint32_t ZERO_CELL = 0>
 __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t xb, uint32_t rb, int lane) {
-  constexpr bool FORWARD = FWD_FROM < R;
+  constexpr int FWD_END = DENSE_INFO ? R - 1 : R;      // 64-row blocks of the forward chain that go through the generic loop
+  constexpr bool FORWARD = FWD_FROM < FWD_END;
   constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
   double x[R], rd[R];
 #pragma unroll
@@ -344,7 +436,7 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
       MISTRA_TAIL_OPERANDS(opa, first)
     }
 #pragma unroll
-    for (int rq = FWD_FROM; rq < R; rq++) {
+    for (int rq = FWD_FROM; rq < FWD_END; rq++) {
       for (int gb = 0; gb < 16; gb += kRingSlots) {
 #define MISTRA_TAIL_FWD(K, CUR, NXT)                                                    \
         {                                                                               \
@@ -363,6 +455,10 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
         tp += kRingSlots * 64;
       }
     }
+  }
+  if constexpr (DENSE_INFO != 0 && FWD_FROM < R) {
+    if constexpr (FORWARD) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");      // the generic loop's look-ahead loads have landed
+    dense_fwd_chain(x[R - 1], DENSE_INFO, ZERO_CELL, lane);
   }
   // ---- backward, on the row-scaled triangle U' = D^-1 U that the LU program's last phase leaves in the tail block
   //      (schedule.cpp: lu_entries): x = R .* x, then for every tail column q descending  x(i) -= U'(i,q) * x(q)  for the
@@ -957,6 +1053,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
 
   // ---- KppSolve_x (gas.f:6206) on a register vector.  swept = true: XS already holds the forward-swept vector (the LU
   //      program carried the stage-1 right-hand side through the elimination), only the backward half is left.
+  constexpr uint32_t kDenseInfo = MT::DENSE_ND == 64 ? 8u * (uint32_t)L::DINFO : 0u, kZeroCell = 8u * (uint32_t)(NNZ + NVAR);
   auto solve = [&](double (&k)[SPT], bool swept) {
     for (int i = t; i < a.n_temps; i += NT) M[NNZ + 2 * NVAR + 4 + i] = 0.0;         // partial-sum cells of the head sweeps
     if (!swept) {
@@ -970,11 +1067,11 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       vm_run<NT>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
       lap(8);
       if (wave == 0)                                                                         // tail chain, one wave
-        tail_solve<MT::TAIL_REGS, 0, MT::RING_LOW>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
+        tail_solve<MT::TAIL_REGS, 0, MT::RING_LOW, kDenseInfo, kZeroCell>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
     } else {
       lap(6);
       if (wave == 0)      // with the dense tail block the forward chain still has the block's own columns to do
-        tail_solve<MT::TAIL_REGS, MT::DENSE_ND ? MT::TAIL_REGS - 1 : MT::TAIL_REGS, MT::RING_LOW>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
+        tail_solve<MT::TAIL_REGS, MT::DENSE_ND ? MT::TAIL_REGS - 1 : MT::TAIL_REGS, MT::RING_LOW, kDenseInfo, kZeroCell>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
     }
     lds_barrier();
     lap(9);

@@ -654,6 +654,9 @@ DenseTail build_dense_tail(const MechTables& m, const VmLayout& lay, int nd, int
   };
   for (int i = 0; i < nd; i++) {
     describe_range(i, D.h + i, D.h, n);
+    // the solves' forward chain over the block (ros3_kernel.hip: dense_fwd_chain) reads a row's columns 1..63 as consecutive cells
+    if ((((uint64_t)D.row_info[(size_t)i * 4 + 1] | ((uint64_t)D.row_info[(size_t)i * 4 + 2] << 32)) & ~1ull) != 0)
+      throw std::logic_error("dense tail: a row of the block lacks a column other than its first");
     describe_range(64 + i, D.h + i, D.jm, D.h);
   }
   for (int r = 0; r < 4 * kb; r++) describe_range(128 + r, D.jm + r, D.h, n);
