@@ -70,6 +70,11 @@ constexpr double kRosGamma2 = 0.24291996454816804366592249683314e+00;
 constexpr double kRosGamma3 = 0.21851380027664058511513169485832e+01;
 constexpr double kRosElo = 3.0;
 
+// Err**(1/ros_ELO) of the step-size controller (gas.f:1303).  Not inlined: the library routine's two dozen polynomial
+// coefficients were hoisted out of the step loop as live registers, and the 128-register kernel spilled them to scratch and
+// read them back every step (most of its HBM-side traffic).  The 256-register kernel keeps the inlined form (0.7 % faster there).
+__device__ __attribute__((noinline)) double err_root(double err) { return pow(err, 1.0 / kRosElo); }
+
 __device__ __forceinline__ double fmin_f(double a, double b) { return (a < b || b != b) ? a : b; }   // Fortran MIN
 __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || b != b) ? a : b; }   // Fortran MAX
 
@@ -872,13 +877,22 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   }
   // Ghimj slots this thread fills in ros_PrepareMatrix (static per mechanism): fetched once, not once per attempt
   // (two 16-bit positions per register)
+  // RESIDENT: the kernels with 256 registers keep these words for the whole call; the 128-register one (aer, four waves per
+  // SIMD) fetches them where they are used — there they were spilled to scratch and came back from it one at a time.
+  constexpr bool RESIDENT = MT::WAVES_PER_SIMD <= MISTRA_RESIDENT_MAX_WPS;
   uint32_t jpos[(JPT + 1) / 2], zpos[(ZPT + 1) / 2];
+  auto load_pos = [&]() {
+    const uint16_t* jp = a.jvs_pos;
+    const uint16_t* zp = a.zero_pos;
+    if constexpr (!RESIDENT) asm volatile("" : "+s"(jp), "+s"(zp));      // opaque: not hoisted out of the step loop
 #pragma unroll
-  for (int q = 0; q < (JPT + 1) / 2; q++)
-    jpos[q] = (uint32_t)G_(a.jvs_pos)[(2 * q) * NT + t] | ((2 * q + 1 < JPT ? (uint32_t)G_(a.jvs_pos)[(2 * q + 1) * NT + t] : (uint32_t)kPosNone) << 16);
+    for (int q = 0; q < (JPT + 1) / 2; q++)
+      jpos[q] = (uint32_t)G_(jp)[(2 * q) * NT + t] | ((2 * q + 1 < JPT ? (uint32_t)G_(jp)[(2 * q + 1) * NT + t] : (uint32_t)kPosNone) << 16);
 #pragma unroll
-  for (int q = 0; q < (ZPT + 1) / 2; q++)
-    zpos[q] = (uint32_t)G_(a.zero_pos)[(2 * q) * NT + t] | ((2 * q + 1 < ZPT ? (uint32_t)G_(a.zero_pos)[(2 * q + 1) * NT + t] : (uint32_t)kPosNone) << 16);
+    for (int q = 0; q < (ZPT + 1) / 2; q++)
+      zpos[q] = (uint32_t)G_(zp)[(2 * q) * NT + t] | ((2 * q + 1 < ZPT ? (uint32_t)G_(zp)[(2 * q + 1) * NT + t] : (uint32_t)kPosNone) << 16);
+  };
+  if constexpr (RESIDENT) load_pos();
   // factor words of the products this thread forms in Fun (one per owned reaction): static per mechanism, kept in registers
   // for the whole integration.  The (up to three per reaction) words of Jac_SP's products are NOT: values that live across
   // the calls of the step loop need callee-saved registers, there are not enough of those, and the compiler's answer was to
@@ -886,8 +900,13 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   // coalesced loads instead (48 KB table, L2-resident; measured: the batch lands in ~380 cycles, Jac_SP's products went from
   // 11 000 to 7 400 cycles per call, the kernel's scratch from 104 to 8 bytes per lane).
   uint64_t ffac[RPT];
+  auto load_ffac = [&]() {
+    const uint64_t* ff = a.fun_fac;
+    if constexpr (!RESIDENT) asm volatile("" : "+s"(ff));
 #pragma unroll
-  for (int q = 0; q < RPT; q++) ffac[q] = G_(a.fun_fac)[q * NT + t];
+    for (int q = 0; q < RPT; q++) ffac[q] = G_(ff)[q * NT + t];
+  };
+  if constexpr (RESIDENT) load_ffac();
   if (t < NFIX) X[NVAR + t] = G_(a.fix)[(size_t)cell * NFIX + t];
   if (t < NCONST) X[NVAR + NFIX + t] = G_(a.consts)[t];
   if constexpr (MT::DENSE_ND > 0) {      // the dense tail block's row table stays in LDS for the whole call
@@ -936,6 +955,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   // ---- Fun_x (gas.f:2043): X <- v; A(r) = RCT(r)*X*X*X; Vdot = signed sums of A
   static_assert(SPT == 1 && JPT * NT <= NNZ, "output cells of the gather-sum machine: one species per thread, JVS sums inside Ghimj");
   auto fun = [&](const double (&v)[SPT], double (&out)[SPT]) {
+    if constexpr (!RESIDENT) load_ffac();
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
       const int s = q * NT + t;
@@ -1018,6 +1038,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   // ---- ros_PrepareMatrix_x (gas.f:1404), first half: Ghimj = -Jac0, diagonal += 1/(H*gamma).
   //      Returns (workgroup-uniform) whether a diagonal is exactly zero, the condition KppDecomp_x tests (gas.f:6157).
   auto prepare = [&](double ghinv, const double (&rhs)[SPT]) -> bool {
+    if constexpr (!RESIDENT) load_pos();
     if (t == 0) flags[0] = 0;
     lds_barrier();   // also: all readers of M from the previous attempt are done
 #pragma unroll
@@ -1232,7 +1253,10 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
         dumping = false;      // the first attempt only
       }
       lap(5);
-      const double Fac = fmin_f(FacMax, fmax_f(FacMin, FacSafe / pow(Err, 1.0 / kRosElo)));
+      double root;
+      if constexpr (MT::WAVES_PER_SIMD > 2) root = err_root(Err);      // register-starved kernels: see err_root
+      else root = pow(Err, 1.0 / kRosElo);
+      const double Fac = fmin_f(FacMax, fmax_f(FacMin, FacSafe / root));
       double Hnew = H * Fac;
       nstp += 1;
       if ((Err <= 1.0) || (H <= Hmin)) {

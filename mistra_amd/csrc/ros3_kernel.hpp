@@ -29,6 +29,9 @@ namespace mistra {
 #ifndef MISTRA_AER_WPS
 #define MISTRA_AER_WPS 4
 #endif
+#ifndef MISTRA_RESIDENT_MAX_WPS      // kernels with more waves per SIMD than this fetch their static per-thread words where they are used (ros3_kernel.hip)
+#define MISTRA_RESIDENT_MAX_WPS 3
+#endif
 constexpr int kGasNT = MISTRA_GAS_NT, kAerNT = MISTRA_AER_NT, kTotNT = MISTRA_TOT_NT;
 
 struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 16, WAVES_PER_SIMD = MISTRA_GAS_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
