@@ -155,7 +155,7 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
     for (int r = rq; r < R; r++)
       for (int lane = 0; lane < 64; lane++) {
         const double l = M[(size_t)idx(T.fwd, q, lane, r)];
-        x[(size_t)r * 64 + lane] = x[(size_t)r * 64 + lane] - l * xq;
+        x[(size_t)r * 64 + lane] = std::fma(-l, xq, x[(size_t)r * 64 + lane]);      // the kernel's tail chain uses the fused form (ros3_kernel.hip: tail_solve)
       }
   }
   // backward on the row-scaled triangle the LU program leaves in the tail block: x = R .* x; x(i) -= U'(i,q) * x(q)
@@ -166,7 +166,7 @@ static int run_solve_split(const KernelSchedule& s, std::vector<double>& M, cons
     for (int r = 0; r <= rq; r++)
       for (int lane = 0; lane < 64; lane++) {
         const double u = M[(size_t)idx(T.bwd, m - 1 - q, lane, r)];
-        x[(size_t)r * 64 + lane] = x[(size_t)r * 64 + lane] - u * xq;
+        x[(size_t)r * 64 + lane] = std::fma(-u, xq, x[(size_t)r * 64 + lane]);
       }
   }
   for (int i = 0; i < m; i++) M[(size_t)nnz + T.h + i] = x[(size_t)i];
@@ -322,6 +322,16 @@ int emu_solve_backward(void* h, const double* LU, double* X) {
   Emu* e = (Emu*)h;
   std::vector<double> M = solve_memory(e, LU, X, false);     // LU comes from emu_lu
   int rc = run_solve_split(e->s, M, e->lay(), false);
+  std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
+  return rc;
+}
+
+// the kernel's whole solve (head forward, tail chain, head backward) on factors in the kernel's own form (from emu_lu, or the
+// GPU's first-step dump)
+int emu_solve_kernel_form(void* h, const double* LU, double* X) {
+  Emu* e = (Emu*)h;
+  std::vector<double> M = solve_memory(e, LU, X, false);
+  int rc = run_solve_split(e->s, M, e->lay());
   std::memcpy(X, M.data() + e->m.nnz, sizeof(double) * e->m.nvar);
   return rc;
 }

@@ -52,6 +52,8 @@ def emu():
     lib.emu_create.argtypes = [C.c_char_p, C.c_int]
     lib.emu_lu.argtypes = [C.c_void_p, dp, dp, dp]
     lib.emu_tail_h.argtypes = [C.c_void_p]
+    lib.emu_solve_backward.argtypes = [C.c_void_p, dp, dp]
+    lib.emu_solve_kernel_form.argtypes = [C.c_void_p, dp, dp]
     return lib
 
 
@@ -121,6 +123,20 @@ def test_phases_of_the_first_step(chem, emu, mech, golden, oracles):
             e = np.abs(got - want).max() / np.abs(want).max()
             worst["k"] = max(worst["k"], e)
             assert e <= 1e-9
+        # ... and bit for bit against the emulated solve programs (head sweeps, tail chain — for tot with the cross-lane chain over
+        # the dense block) run on the GPU's own factors and right-hand sides: same operations, same order, same fused multiply-adds
+        lu_gpu = np.ascontiguousarray(d["lu"][i])
+        e1 = x.copy()                                   # (emu_lu above carried the stage-1 right-hand side through the elimination)
+        assert emu.emu_solve_backward(h_emu, P(lu_gpu), P(e1)) == 0
+        e2 = np.ascontiguousarray((fcn + (C21 / H) * k1) + (H * GAMMA[1]) * 0.0)
+        assert emu.emu_solve_kernel_form(h_emu, P(lu_gpu), P(e2)) == 0
+        e3 = np.ascontiguousarray(((fcn + (C31 / H) * k1) + (C32 / H) * k2) + (H * GAMMA[2]) * 0.0)
+        assert emu.emu_solve_kernel_form(h_emu, P(lu_gpu), P(e3)) == 0
+        if np.array_equal(d["lu"][i], lu_emu):          # (the forward-swept stage-1 vector is the emulator's: exact only on identical factors)
+            assert np.array_equal(k1, e1), "K1 differs from the emulated solve programs"
+        assert np.array_equal(k2, e2), "K2 differs from the emulated solve programs"
+        assert np.array_equal(k3, e3), "K3 differs from the emulated solve programs"
+        worst["k_bitwise"] = worst.get("k_bitwise", 0) + 1
         # ---- ros_ErrorNorm_x (gas.f:1341) on the GPU's K vectors
         ynew = ((v + k1) + 0.61697947043828245592553615689730e+01 * k2) + -0.42772256543218573326238373806514e+00 * k3
         yerr = ((0.0 + E[0] * k1) + E[1] * k2) + E[2] * k3
@@ -129,7 +145,8 @@ def test_phases_of_the_first_step(chem, emu, mech, golden, oracles):
         worst["err"] = max(worst["err"], abs(d["err"][i, 0] - err) / err)
         assert abs(d["err"][i, 0] - err) <= 1e-12 * err
     print("%s phases: Fun and Ghimj bit-exact; LU vs emulated kernel %.1e, vs reference factors %.1e (of row max); "
-          "K vectors %.1e; error norm %.1e" % (mech, worst["lu_vs_emu"], worst["lu_vs_oracle"], worst["k"], worst["err"]))
+          "K vectors %.1e vs the oracle's solve, bit-identical to the emulated solve programs in %d cells; error norm %.1e"
+          % (mech, worst["lu_vs_emu"], worst["lu_vs_oracle"], worst["k"], worst.get("k_bitwise", 0), worst["err"]))
 
 
 def _first_order_losses(t):
