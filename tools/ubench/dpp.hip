@@ -1,5 +1,9 @@
 // Micro-benchmarks for a DPP-based triangular-solve chain (diagnostics only, not product code): v_fmac_f64 with the
 // row_newbcast DPP modifier (a lane's value to its 16-lane row in the same instruction), the gfx950 permlane swaps.
+//   hipcc --offload-arch=gfx950 -O2 -o dpp dpp.hip && ./dpp          (on the GPU box; '-DNOPS=""' drops the wait states of the timing loops)
+// Measured on MI355X: a dependent step 10.1 cycles with one wait state in front of the DPP read (results bit-identical to the
+// host's fma chain), 14.1 with two, WRONG results with none; each further off-chain fmac ~4.3 cycles; a lane row's double to
+// all four rows by v_permlane16_swap + v_permlane32_swap ~70 cycles, by 2 x ds_bpermute_b32 ~66.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
