@@ -328,7 +328,10 @@ def rank_body(args, rank, world, dev, engine):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "traffic_rate_gbs": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9,
-                     "limiter": "latency of one dependency chain per CU (one tot cell owns a CU's LDS): waves parked at s_waitcnt / s_barrier",
+                     "limiter": {"tot": "latency of one dependency chain per CU (one tot cell owns a CU's LDS)",
+                                 "aer": "latency of two dependency chains per CU (two aer cells per CU at 128 registers per lane)",
+                                 "gas": "latency of six dependency chains per CU (six gas cells per CU at 168 registers per lane)"}[args.mech]
+                                + ": waves parked at s_waitcnt / s_barrier",
                      "kernel": "ros3_integrate_kernel", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_cell": ALG_BYTES[args.mech],
                      "fp64_tflops": flops / 1e12, "fp64_frac_of_vector_peak": flops / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
