@@ -1,7 +1,8 @@
 ! TEST INFRASTRUCTURE (fixture capture only; built by oracle/build_ref.sh `model`, never shipped, never timed).
 !
-! A stripped time loop that sequences the reference's own, unmodified, compiled routines for ONE configuration
-! class: 1-D column, microphysics on, chemistry on, no nucleation, water surface, fresh start.  It exists because
+! A stripped time loop that sequences the reference's own, unmodified, compiled routines for TWO configuration
+! classes: 1-D column, or box (box=T: one level, src/str.f90:183-186, 215, 305, 410-424) — microphysics on, chemistry on,
+! no nucleation, water surface, fresh start.  It exists because
 ! the reference's main program (src/str.f90:72-560) calls write_grid (src/str.f90:216) unconditionally, and that
 ! routine lives in src/out_netCDF.f which needs netcdf.inc/libnetcdf — absent from this image.  Instead of faking
 ! that library, this harness simply never calls any output routine (netCDF, binary plots, restart files): those
@@ -11,7 +12,7 @@
 ! Purpose: reach realistic cloudy-layer chemistry states so that oracle/capture_wrap.c can record real
 ! INTEGRATE_g/a/t inputs and outputs (/GDATA_x/) for tests/golden/.
 program mistra_column_capture
-  use config, only: read_config, box, chamber, chem, mic, nuc, rst, isurf, lstmax, z_box, lpJoyce14bc, lpBuys13_0D
+  use config, only: read_config, box, chamber, chem, mic, nuc, rst, isurf, lstmax, z_box, lpJoyce14bc, lpBuys13_0D, nlevbox, BL_box
   use global_params, only: n, nf, nm, nphrxn, nrlay, mbs
   use precision, only: dp
   implicit none
@@ -25,9 +26,9 @@ program mistra_column_capture
 
   real(dp), parameter :: dt_slow = 60._dp, dt_fast = 10._dp
   character(len=1), parameter :: tag = 'a'
-  integer :: minutes, sub, k, nbl, max_minutes, envstat
+  integer :: minutes, sub, k, nbl, max_minutes, envstat, nz_box
   character(len=32) :: envbuf
-  real(dp) :: xra, u0_floor
+  real(dp) :: xra, u0_floor, box_switch
   logical :: daylight
 
   ! the handful of reference COMMON members this loop has to advance itself
@@ -44,18 +45,20 @@ program mistra_column_capture
   common /band_rat/ photol_j(nphrxn, n)
 
   call read_config
-  if (box .or. chamber .or. nuc .or. rst .or. (.not. chem) .or. (.not. mic) .or. isurf /= 0) then
-     write (0, *) 'mistra_column_capture: only 1-D, mic=T, chem=T, nuc=F, rst=F, isurf=0 namelists are supported'
+  if (chamber .or. nuc .or. rst .or. (.not. chem) .or. (.not. mic) .or. isurf /= 0) then
+     write (0, *) 'mistra_column_capture: only 1-D or box, mic=T, chem=T, nuc=F, rst=F, isurf=0 namelists are supported'
      stop 2
   end if
-  nbl = nf
+  nbl = merge(2, nf, box)                 ! src/str.f90:183-196
   xra = 0._dp
+  nz_box = 0
 
   ! ---- start-up
   call grid
   call openm(tag)
   call openc(tag)
   call mk_interface
+  if (box) call get_n_box(z_box, nz_box)   ! src/str.f90:215
   call initm(tag, rst)
   call initc(nbl)
   call atk0
@@ -70,6 +73,10 @@ program mistra_column_capture
   call photol
   call out_mass
   time = 0._dp
+  if (box) then                           ! src/str.f90:305-306
+     call box_init(nlevbox, nz_box, nbl, BL_box)
+     box_switch = 1._dp
+  end if
   u0_floor = merge(1.75e-2_dp, 3.48e-2_dp, lpBuys13_0D)
 
   ! ---- minutes
@@ -91,6 +98,13 @@ program mistra_column_capture
      call partdep(xra)
      do sub = 1, 6
         time = time + dt_fast
+        if (box) then                     ! src/str.f90:410-424: no dynamics, microphysics or radiation in a box run
+           call box_update(box_switch, sub, nlevbox, nz_box, nbl, BL_box)
+           call sedc_box(dt_fast, z_box, nbl)
+           call box_partdep(dt_fast, z_box, nbl)
+           call stem_kpp(dt_fast, xra, z_box, nbl, box, chamber, nuc)
+           cycle
+        end if
         call difm(dt_fast)
         call difc(dt_fast)
         call difp(dt_fast)
@@ -105,7 +119,7 @@ program mistra_column_capture
         call sedl(dt_fast)
         call stem_kpp(dt_fast, xra, z_box, nbl, box, chamber, nuc)
      end do
-     call radiation(.false.)
+     if (.not. box) call radiation(.false.)
      ! photolysis refresh rule of the reference loop
      if (lpJoyce14bc) then
         daylight = u0 > 1.0e-2_dp
@@ -115,7 +129,10 @@ program mistra_column_capture
            photol_j(:, :) = 0._dp
         end if
      else if (u0 > u0_floor) then
-        if (mod(lmin, 2) == 0) call photol
+        if (mod(lmin, 2) == 0) then
+           call photol
+           if (box .and. BL_box) call ave_j(nz_box, nbl)
+        end if
      else
         photol_j(:, :) = 0._dp
      end if

@@ -22,8 +22,9 @@ def golden():
 
 
 # further captured sets, (set, mechanism): "day" = the BTZ96 run at model hours 6.5-8 (after sunrise: photolysis reactions
-# switched on), "base1" = the reference's cloud-free namelist.base1 (no tot calls in it)
-EXTRA_SETS = [("day", "gas"), ("day", "aer"), ("day", "tot"), ("base1", "gas"), ("base1", "aer")]
+# switched on), "base1" = the reference's cloud-free namelist.base1 (no tot calls in it), "buys13" = the box-model run of
+# namelist.Buys13_0D (BASELINE.json configs[0]: aerosol mechanism only)
+EXTRA_SETS = [("day", "gas"), ("day", "aer"), ("day", "tot"), ("base1", "gas"), ("base1", "aer"), ("buys13", "aer")]
 
 
 def load_golden(mech, suffix=""):

@@ -37,6 +37,11 @@ SETS = {
                "chemistry); oracle/capture_run.sh base1 2 MISTRA_CAPTURE_SKIP_t=200 MISTRA_CAPTURE_EVERY_t=997 MISTRA_CAPTURE_MAX_t=12 "
                "MISTRA_CAPTURE_SKIP_a=500 MISTRA_CAPTURE_EVERY_a=2003 MISTRA_CAPTURE_MAX_a=16 "
                "MISTRA_CAPTURE_SKIP_g=500 MISTRA_CAPTURE_EVERY_g=3001 MISTRA_CAPTURE_MAX_g=12"),
+    # BASELINE.json configs[0], the reference's own CPU-runnable case: a box-model run (one level, aerosol mechanism, 360
+    # INTEGRATE_a calls per model hour), sequenced by oracle/column_driver.f90's box branch
+    "_buys13": (os.path.join(REF, "capture_Buys13_0D.bin"),
+                "reference namelist.Buys13_0D (box=T as shipped, netcdf=F, lstmax=1: first model hour of the box run, 32 steps per call); "
+                "oracle/capture_run.sh Buys13_0D 1 MISTRA_CAPTURE_SKIP_a=20 MISTRA_CAPTURE_EVERY_a=11 MISTRA_CAPTURE_MAX_a=32"),
 }
 
 
@@ -58,12 +63,17 @@ COLUMN_SETS = {
 
 
 def main():
+    only = set(sys.argv[1:])          # e.g. `make_golden.py _buys13 BTZ96`: just these sets (default: all whose capture exists)
     for suffix, (capture, cmd) in SETS.items():
+        if only and suffix not in only:
+            continue
         if os.path.exists(capture):
             convert(suffix, capture, cmd)
         else:
             print("no capture", capture, "- skipped")
     for name, (capture, cmd) in COLUMN_SETS.items():
+        if only and name not in only:
+            continue
         if os.path.exists(capture) and os.path.getsize(capture):
             convert_column(name, capture, cmd)
         else:
