@@ -11,8 +11,7 @@ REFROOT="${MISTRA_REFERENCE:-/root/reference}"
 CASE="$1"; HOURS="$2"; shift 2
 RUN="$HERE/_ref/run_${CASE}${MISTRA_RUN_TAG:-}"
 rm -rf "$RUN/out"; mkdir -p "$RUN/out"
-# MISTRA_NAMELIST_SED: one more sed expression for the copy, e.g. 's/^\( *nuc *= *\)T/\1F/' for a case that ships with nucleation
-# on (oracle/column_driver.f90 sequences the model without the nucleation module)
+# MISTRA_NAMELIST_SED: one more sed expression for the copy (e.g. to switch a module of a shipped case off)
 sed -e 's/^\( *netcdf *= *\)T/\1F/' -e 's/^\( *chem *= *\)F/\1T/' -e "s/^\( *lstmax *= *\)[0-9]*/\1$HOURS/" \
     -e "${MISTRA_NAMELIST_SED:-s/^$//}" "$REFROOT/namelists/namelist.$CASE" > "$RUN/namelist"
 cd "$RUN"

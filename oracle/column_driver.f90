@@ -2,7 +2,7 @@
 !
 ! A stripped time loop that sequences the reference's own, unmodified, compiled routines for TWO configuration
 ! classes: 1-D column, or box (box=T: one level, src/str.f90:183-186, 215, 305, 410-424) — microphysics on, chemistry on,
-! no nucleation, water surface, fresh start.  It exists because
+! with or without the nucleation module (src/str.f90:206-210, 397-402), water surface, fresh start.  It exists because
 ! the reference's main program (src/str.f90:72-560) calls write_grid (src/str.f90:216) unconditionally, and that
 ! routine lives in src/out_netCDF.f which needs netcdf.inc/libnetcdf — absent from this image.  Instead of faking
 ! that library, this harness simply never calls any output routine (netCDF, binary plots, restart files): those
@@ -12,7 +12,8 @@
 ! Purpose: reach realistic cloudy-layer chemistry states so that oracle/capture_wrap.c can record real
 ! INTEGRATE_g/a/t inputs and outputs (/GDATA_x/) for tests/golden/.
 program mistra_column_capture
-  use config, only: read_config, box, chamber, chem, mic, nuc, rst, isurf, lstmax, z_box, lpJoyce14bc, lpBuys13_0D, nlevbox, BL_box
+  use config, only: read_config, box, chamber, chem, mic, nuc, rst, isurf, lstmax, z_box, lpJoyce14bc, lpBuys13_0D, nlevbox, BL_box, &
+                    Napari, Lovejoy, iod
   use global_params, only: n, nf, nm, nphrxn, nrlay, mbs
   use precision, only: dp
   implicit none
@@ -29,7 +30,7 @@ program mistra_column_capture
   integer :: minutes, sub, k, nbl, max_minutes, envstat, nz_box
   character(len=32) :: envbuf
   real(dp) :: xra, u0_floor, box_switch
-  logical :: daylight
+  logical :: daylight, llnucboth
 
   ! the handful of reference COMMON members this loop has to advance itself
   real(dp) :: u0, albedo, thk
@@ -45,8 +46,8 @@ program mistra_column_capture
   common /band_rat/ photol_j(nphrxn, n)
 
   call read_config
-  if (chamber .or. nuc .or. rst .or. (.not. chem) .or. (.not. mic) .or. isurf /= 0) then
-     write (0, *) 'mistra_column_capture: only 1-D or box, mic=T, chem=T, nuc=F, rst=F, isurf=0 namelists are supported'
+  if (chamber .or. rst .or. (.not. chem) .or. (.not. mic) .or. isurf /= 0) then
+     write (0, *) 'mistra_column_capture: only 1-D or box, mic=T, chem=T, rst=F, isurf=0 namelists are supported'
      stop 2
   end if
   nbl = merge(2, nf, box)                 ! src/str.f90:183-196
@@ -58,6 +59,11 @@ program mistra_column_capture
   call openm(tag)
   call openc(tag)
   call mk_interface
+  llnucboth = .false.
+  if (nuc) then                           ! src/str.f90:206-210
+     call nuc_init(Napari, Lovejoy, iod)
+     llnucboth = Napari .and. Lovejoy
+  end if
   if (box) call get_n_box(z_box, nz_box)   ! src/str.f90:215
   call initm(tag, rst)
   call initc(nbl)
@@ -118,6 +124,13 @@ program mistra_column_capture
         call sedc(dt_fast)
         call sedl(dt_fast)
         call stem_kpp(dt_fast, xra, z_box, nbl, box, chamber, nuc)
+        if (nuc) then                     ! src/str.f90:397-402
+           if (llnucboth) then
+              call appnucl2(dt_fast, llnucboth)
+           else
+              call appnucl(dt_fast, Napari, Lovejoy, llnucboth)
+           end if
+        end if
      end do
      if (.not. box) call radiation(.false.)
      ! photolysis refresh rule of the reference loop

@@ -48,10 +48,10 @@ SETS = {
 # whole column steps: EVERY INTEGRATE_x call of kpp_driver's layer loop (kpp.f90:4310-4470) for one or two 10-s steps, in
 # the model's call order, whatever mechanism each layer ran (BASELINE.json configs[4]: 148 cells per step)
 COLUMN_SETS = {
-    "Joyce2014": (os.path.join(REF, "capture_Joyce2014_basecase_col.bin"),
-                  "reference namelist.Joyce2014_basecase (netcdf=F; nuc=T -> F: oracle/column_driver.f90 sequences the model without the "
-                  "nucleation module; lstmax=1), column steps 180 and 181 of the first model hour (all 148 layers run the gas mechanism); "
-                  "MISTRA_RUN_TAG=_col MISTRA_NAMELIST_SED='s/^\\( *nuc *= *\\)T/\\1F/' oracle/capture_run.sh Joyce2014_basecase 1 "
+    "Joyce2014": (os.path.join(REF, "capture_Joyce2014_basecase_nuc.bin"),
+                  "reference namelist.Joyce2014_basecase as shipped (nuc=T, Napari and Lovejoy nucleation; only netcdf=F and lstmax=1), "
+                  "column steps 180 and 181 of the first model hour (all 148 layers run the gas mechanism); "
+                  "MISTRA_RUN_TAG=_nuc MISTRA_COLUMN_MINUTES=31 oracle/capture_run.sh Joyce2014_basecase 1 "
                   "MISTRA_CAPTURE_SEQ_FROM=26640 MISTRA_CAPTURE_SEQ_TO=26936"),
     "base1": (os.path.join(REF, "capture_base1_col.bin"),
               "reference namelist.base1 (netcdf=F, lstmax=1), column step 300 of the first model hour (79 layers run gas, 69 aer); "
