@@ -143,109 +143,125 @@ __device__ double fhet_d(const Env& v, double xliq, double xhet, int a0, int b0,
 
 __global__ __launch_bounds__(256) void update_rconst_kernel(const RatesDev R, const double* __restrict__ env, double* __restrict__ rconst,
                                                             int ncell) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long long)ncell * R.nreact) return;
-  const int cell = (int)(gid / R.nreact), r = (int)(gid % R.nreact);
+  // lane = cell, wave = a contiguous run of reactions: the 64 lanes of a wave interpret the SAME program (no divergence in
+  // the op / rate-law switches, program words and literals are wave-uniform loads); a thread per (cell, reaction) had every
+  // lane on another program.  blockIdx.x: group of 64 cells; blockIdx.y * 4 + wave: chunk of reactions.
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nchunk = 4 * (int)gridDim.y, chunk = (int)blockIdx.y * 4 + wave, per = (R.nreact + nchunk - 1) / nchunk;
+  const int r_begin = chunk * per, r_end = r_begin + per < R.nreact ? r_begin + per : R.nreact;
+  const int cell_raw = (int)blockIdx.x * 64 + lane;
+  const bool live = cell_raw < ncell;
+  const int cell = live ? cell_raw : ncell - 1;      // (idle lanes repeat the last cell and do not store)
   const double* e = env + (size_t)cell * R.nenv;
   const Cb1 cb{e[0], e[1], e[2], e[3]};
   const Env ev{e, R.fslot};
   constexpr double dclim = 1.0e10;      // the reaction-rate ceiling of dmin2 / uplim / uparm / uplip / uparp
-  double st[12];
+  // operand stack of the postfix programs: one LDS column per thread (a private array indexed by the stack pointer would live in
+  // scratch memory: a global round trip per push and pop)
+  __shared__ double stack_cells[12][256];
+#define st_at(i) stack_cells[(i)][threadIdx.x]
+  for (int r = r_begin; r < r_end; r++) {
   int sp = 0;
   for (int w = R.offs[r]; w < R.offs[r + 1]; w++) {
     const int word = R.words[w], op = word & 0xFF, arg = word >> 8;
     switch (op) {
-      case 0: st[sp++] = R.consts[arg]; break;
-      case 1: st[sp++] = e[arg]; break;
-      case 2: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
-      case 3: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
-      case 4: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
-      case 5: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
-      case 6: st[sp - 1] = -st[sp - 1]; break;
+      case 0: st_at(sp++) = R.consts[arg]; break;
+      case 1: st_at(sp++) = e[arg]; break;
+      case 2: sp--; st_at(sp - 1) = st_at(sp - 1) + st_at(sp); break;
+      case 3: sp--; st_at(sp - 1) = st_at(sp - 1) - st_at(sp); break;
+      case 4: sp--; st_at(sp - 1) = st_at(sp - 1) * st_at(sp); break;
+      case 5: sp--; st_at(sp - 1) = st_at(sp - 1) / st_at(sp); break;
+      case 6: st_at(sp - 1) = -st_at(sp - 1); break;
       default: {      // call: arguments are the top of the stack, first argument deepest
         double v = 0.0;
         switch (arg) {
-          case 0: sp -= 2; v = farr(cb, st[sp], st[sp + 1]); break;
-          case 1: sp -= 4; v = farr_sp(cb, st[sp], st[sp + 1], st[sp + 2], st[sp + 3]); break;
-          case 2: sp -= 5; v = troe(cb, st[sp], st[sp + 1], st[sp + 2], st[sp + 3], st[sp + 4], 300.0); break;       // ATK_3
-          case 3: sp -= 5; v = troe(cb, st[sp], st[sp + 1], st[sp + 2], st[sp + 3], st[sp + 4], 298.0); break;       // ATK_3f
-          case 4: sp -= 6; v = shno3(cb, st[sp], st[sp + 1], st[sp + 2], st[sp + 3], st[sp + 4], st[sp + 5]); break;
-          case 5: sp -= 7; v = troe(cb, st[sp], st[sp + 1], st[sp + 2], st[sp + 3], st[sp + 4], 300.0) / (st[sp + 5] * exp(st[sp + 6] / cb.te)); break;   // fbck
-          case 6: sp -= 6; v = troe(cb, st[sp], st[sp + 1], st[sp + 2], st[sp + 3], 0.6, 300.0) / (st[sp + 4] * exp(st[sp + 5] / cb.te)); break;        // fbckJ
+          case 0: sp -= 2; v = farr(cb, st_at(sp), st_at(sp + 1)); break;
+          case 1: sp -= 4; v = farr_sp(cb, st_at(sp), st_at(sp + 1), st_at(sp + 2), st_at(sp + 3)); break;
+          case 2: sp -= 5; v = troe(cb, st_at(sp), st_at(sp + 1), st_at(sp + 2), st_at(sp + 3), st_at(sp + 4), 300.0); break;       // ATK_3
+          case 3: sp -= 5; v = troe(cb, st_at(sp), st_at(sp + 1), st_at(sp + 2), st_at(sp + 3), st_at(sp + 4), 298.0); break;       // ATK_3f
+          case 4: sp -= 6; v = shno3(cb, st_at(sp), st_at(sp + 1), st_at(sp + 2), st_at(sp + 3), st_at(sp + 4), st_at(sp + 5)); break;
+          case 5: sp -= 7; v = troe(cb, st_at(sp), st_at(sp + 1), st_at(sp + 2), st_at(sp + 3), st_at(sp + 4), 300.0) / (st_at(sp + 5) * exp(st_at(sp + 6) / cb.te)); break;   // fbck
+          case 6: sp -= 6; v = troe(cb, st_at(sp), st_at(sp + 1), st_at(sp + 2), st_at(sp + 3), 0.6, 300.0) / (st_at(sp + 4) * exp(st_at(sp + 5) / cb.te)); break;        // fbckJ
           case 7: {   // fbck2 (kpp.f90:7411): ak=5.44d-9, bk=14192.d0; 0 where ck = 0
             sp -= 6;
-            const double x1 = troe(cb, st[sp], st[sp + 1], st[sp + 2], st[sp + 3], st[sp + 4], 300.0), ck = st[sp + 5];
+            const double x1 = troe(cb, st_at(sp), st_at(sp + 1), st_at(sp + 2), st_at(sp + 3), st_at(sp + 4), 300.0), ck = st_at(sp + 5);
             v = ck != 0.0 ? x1 / (((((5.44e-9 * exp(14192.0 / cb.te)) * kR8314) / 101325.0) * cb.te) / ck) : 0.0;
             break;
           }
-          case 8: sp -= 2; v = st[sp] * (1.0 + cb.aircc / st[sp + 1]); break;                                         // sp_17
-          case 9: sp -= 6; v = sp_23(cb, st[sp], st[sp + 1], st[sp + 2], st[sp + 3], st[sp + 4], st[sp + 5]); break;
-          case 10: sp -= 1; v = fcn(cb, st[sp]); break;
+          case 8: sp -= 2; v = st_at(sp) * (1.0 + cb.aircc / st_at(sp + 1)); break;                                         // sp_17
+          case 9: sp -= 6; v = sp_23(cb, st_at(sp), st_at(sp + 1), st_at(sp + 2), st_at(sp + 3), st_at(sp + 4), st_at(sp + 5)); break;
+          case 10: sp -= 1; v = fcn(cb, st_at(sp)); break;
           case 11: v = dms_add(cb); break;
-          case 12: sp -= 2; v = fdhet(ev, (int)st[sp], (int)st[sp + 1]); break;
-          case 13: sp -= 2; v = farr2(cb, st[sp], st[sp + 1]); break;
-          case 14: sp -= 3; v = fhet_t(ev, (int)st[sp], (int)st[sp + 1], (int)st[sp + 2]); break;
-          case 15: sp -= 5; v = fhet_d(ev, st[sp], st[sp + 1], (int)st[sp + 2], (int)st[sp + 3], (int)st[sp + 4]); break;
+          case 12: sp -= 2; v = fdhet(ev, (int)st_at(sp), (int)st_at(sp + 1)); break;
+          case 13: sp -= 2; v = farr2(cb, st_at(sp), st_at(sp + 1)); break;
+          case 14: sp -= 3; v = fhet_t(ev, (int)st_at(sp), (int)st_at(sp + 1), (int)st_at(sp + 2)); break;
+          case 15: sp -= 5; v = fhet_d(ev, st_at(sp), st_at(sp + 1), (int)st_at(sp + 2), (int)st_at(sp + 3), (int)st_at(sp + 4)); break;
           case 16: {   // fliq_60 (kpp.f90:7662): a1*exp(dble(b1)*(1.d0/te-3.3557d-3))*c/(c+0.1d0/d)
             sp -= 4;
-            const double a1 = st[sp], b1 = st[sp + 1], c = st[sp + 2], d = st[sp + 3];
+            const double a1 = st_at(sp), b1 = st_at(sp + 1), c = st_at(sp + 2), d = st_at(sp + 3);
             v = d > 0.0 ? ((a1 * exp(b1 * (1.0 / cb.te - 3.3557e-3))) * c) / (c + 0.1 / d) : 0.0;
             break;
           }
-          case 17: sp -= 1; v = st[sp] < dclim ? st[sp] : dclim; break;                    // dmin2 = dmin1(a, 1.d10)
-          case 18: sp -= 1; v = st[sp] < dclim * 2.0 ? st[sp] : dclim * 2.0; break;        // dmin3 = dmin1(a, 2.d10)
+          case 17: sp -= 1; v = st_at(sp) < dclim ? st_at(sp) : dclim; break;                    // dmin2 = dmin1(a, 1.d10)
+          case 18: sp -= 1; v = st_at(sp) < dclim * 2.0 ? st_at(sp) : dclim * 2.0; break;        // dmin3 = dmin1(a, 2.d10)
           case 19: {   // flsc4 = a*b*c**3 (kpp.f90:7755); c**3 as the compiler expands it: c*c*c
             sp -= 3;
-            const double c = st[sp + 2];
-            v = c > 0.0 ? (st[sp] * st[sp + 1]) * ((c * c) * c) : 0.0;
+            const double c = st_at(sp + 2);
+            v = c > 0.0 ? (st_at(sp) * st_at(sp + 1)) * ((c * c) * c) : 0.0;
             break;
           }
           case 20: {   // flsc5 = a*b**2*c**4 (kpp.f90:7778); c**4 as the reference's compiler expands it: ((c*c)*c)*c
             sp -= 3;
-            const double b = st[sp + 1], c = st[sp + 2];
-            v = c > 0.0 ? (st[sp] * (b * b)) * (((c * c) * c) * c) : 0.0;
+            const double b = st_at(sp + 1), c = st_at(sp + 2);
+            v = c > 0.0 ? (st_at(sp) * (b * b)) * (((c * c) * c) * c) : 0.0;
             break;
           }
-          case 21: sp -= 2; v = st[sp + 1] > 1.0e-15 ? st[sp] / st[sp + 1] : 0.0; break;    // flsc6 (kpp.f90:7801)
+          case 21: sp -= 2; v = st_at(sp + 1) > 1.0e-15 ? st_at(sp) / st_at(sp + 1) : 0.0; break;    // flsc6 (kpp.f90:7801)
           case 22: {   // uplim = a/(1 + b/dclim*max(c,0)*d) (kpp.f90:7862)
             sp -= 4;
-            const double a = st[sp], b = st[sp + 1], c = st[sp + 2], d = st[sp + 3];
+            const double a = st_at(sp), b = st_at(sp + 1), c = st_at(sp + 2), d = st_at(sp + 3);
             v = d > 0.0 ? a / (1.0 + ((b / dclim) * fmax_fortran(c, 0.0)) * d) : 0.0;
             break;
           }
           case 23: {   // uparm = a0*exp(dble(b0)*(1/te-3.3557d-3))/(1+c/dclim*d*e) (kpp.f90:7888)
             sp -= 5;
-            const double a0 = st[sp], b0 = st[sp + 1], c = st[sp + 2], d = st[sp + 3], ee = st[sp + 4];
+            const double a0 = st_at(sp), b0 = st_at(sp + 1), c = st_at(sp + 2), d = st_at(sp + 3), ee = st_at(sp + 4);
             v = d > 0.0 ? (a0 * exp(b0 * (1.0 / cb.te - 3.3557e-3))) / (1.0 + ((c / dclim) * d) * ee) : 0.0;
             break;
           }
           case 24: {   // uplip = a/(1 + a/dclim*max(b,0)*c)*c**2 (kpp.f90:7916)
             sp -= 3;
-            const double a = st[sp], b = st[sp + 1], c = st[sp + 2];
+            const double a = st_at(sp), b = st_at(sp + 1), c = st_at(sp + 2);
             v = c > 0.0 ? (a / (1.0 + ((a / dclim) * fmax_fortran(b, 0.0)) * c)) * (c * c) : 0.0;
             break;
           }
           case 25: {   // uparp = k/(1 + k/dclim*c*d)*d**2, k = a0*exp(dble(b0)*(1/te-3.3557d-3)) (kpp.f90:7942)
             sp -= 4;
-            const double a0 = st[sp], b0 = st[sp + 1], c = st[sp + 2], d = st[sp + 3];
+            const double a0 = st_at(sp), b0 = st_at(sp + 1), c = st_at(sp + 2), d = st_at(sp + 3);
             const double k = a0 * exp(b0 * (1.0 / cb.te - 3.3557e-3));
             v = d > 0.0 ? (k / (1.0 + ((k / dclim) * c) * d)) * (d * d) : 0.0;
             break;
           }
         }
-        st[sp++] = v;
+        st_at(sp++) = v;
       }
     }
   }
-  rconst[(size_t)cell * R.nreact + r] = st[0];
+  if (live) rconst[(size_t)cell * R.nreact + r] = st_at(0);
+  }
 }
+#undef st_at
 
 }  // namespace
 
 hipError_t launch_update_rconst(const RatesDev& R, const double* d_env, double* d_rconst, int ncell, hipStream_t stream) {
   if (ncell <= 0) return hipSuccess;
-  const long long total = (long long)ncell * R.nreact;
-  hipLaunchKernelGGL(update_rconst_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, R, d_env, d_rconst, ncell);
+  // enough workgroups to fill the chip even for a column's worth of cells: the reactions are cut into 4 * gy chunks
+  const unsigned gx = (unsigned)((ncell + 63) / 64);
+  unsigned gy = gx >= 2048 ? 1u : (2048u + gx - 1) / gx;
+  const unsigned gy_max = (unsigned)((R.nreact + 15) / 16);      // at least four reactions per wave
+  if (gy > gy_max) gy = gy_max;
+  hipLaunchKernelGGL(update_rconst_kernel, dim3(gx, gy), dim3(256), 0, stream, R, d_env, d_rconst, ncell);
   return hipGetLastError();
 }
 
