@@ -44,6 +44,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MistraChemError("HIP library %s is missing: run `python -m mistra_amd.build` (or __graft_entry__.build())"
                                   % LIB_PATH)
+        try:
+            # PyTorch ships its own libamdhip64 / libhsa-runtime64.  Loaded first, the library below binds to those by soname and the
+            # process has ONE HIP runtime; loaded after this library (which then has pulled in /opt/rocm's), the process has two,
+            # and the one that initialises second sees no device (found with __graft_entry__.build() followed by smoke()).
+            import torch  # noqa: F401
+        except ImportError:      # a caller without PyTorch (numpy buffers only): the system runtime alone
+            pass
         L = C.CDLL(LIB_PATH)
         L.mistra_chem_init.argtypes = [C.c_int]
         L.mistra_chem_init_devices.argtypes = [C.c_int, _ip]
