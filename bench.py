@@ -330,7 +330,7 @@ def rank_body(args, rank, world, dev, engine):
                      "traffic_rate_gbs": None if traffic is None else traffic / (kernel_ms * 1e-3) / 1e9,
                      "limiter": {"tot": "latency of one dependency chain per CU (one tot cell owns a CU's LDS)",
                                  "aer": "latency of two dependency chains per CU (two aer cells per CU at 128 registers per lane)",
-                                 "gas": "latency of six dependency chains per CU (six gas cells per CU at 168 registers per lane)"}[args.mech]
+                                 "gas": "instruction issue and the latency of eight dependency chains per CU (eight gas cells per CU at 128 registers per lane)"}[args.mech]
                                 + ": waves parked at s_waitcnt / s_barrier",
                      "kernel": "ros3_integrate_kernel", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_cell": ALG_BYTES[args.mech],

@@ -66,14 +66,22 @@ constexpr double kRosE1 = 0.5e+00;
 constexpr double kRosE2 = -0.29079558716805469821718236208017e+01;
 constexpr double kRosE3 = 0.22354069897811569627360909276199e+00;
 constexpr double kRosGamma1 = 0.43586652150845899941601945119356e+00;
-constexpr double kRosGamma2 = 0.24291996454816804366592249683314e+00;
-constexpr double kRosGamma3 = 0.21851380027664058511513169485832e+01;
+[[maybe_unused]] constexpr double kRosGamma2 = 0.24291996454816804366592249683314e+00;
+[[maybe_unused]] constexpr double kRosGamma3 = 0.21851380027664058511513169485832e+01;
 constexpr double kRosElo = 3.0;
 
 // Err**(1/ros_ELO) of the step-size controller (gas.f:1303).  Not inlined: the library routine's two dozen polynomial
 // coefficients were hoisted out of the step loop as live registers, and the 128-register kernel spilled them to scratch and
 // read them back every step (most of its HBM-side traffic).  The 256-register kernel keeps the inlined form (0.7 % faster there).
 __device__ __attribute__((noinline)) double err_root(double err) { return pow(err, 1.0 / kRosElo); }
+
+// A value every lane of the wave holds identically (time, step size: sums reduced in a fixed order, the same in all lanes),
+// moved to scalar registers: the register-starved kernels spilled these to scratch at the head of the step loop.
+__device__ __forceinline__ double wave_uniform(double v) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
 
 __device__ __forceinline__ double fmin_f(double a, double b) { return (a < b || b != b) ? a : b; }   // Fortran MIN
 __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || b != b) ? a : b; }   // Fortran MAX
@@ -89,8 +97,8 @@ __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || 
 // load; the callers see the blocks as ordinary call-clobbered registers.  Two placements (LOW):
 //   false  v192-199, v208-215, v224-231, v240-247: four caller-saved blocks at the top of the file, nothing to save — for
 //          kernels that run two waves per SIMD and have 256 registers (tot: one cell fills a CU's LDS anyway);
-//   true   v64-71, v80-87, v96-103, v112-119: four caller-saved blocks again, for kernels held to 128 (aer: FOUR waves per
-//          SIMD, two cells per CU instead of one, +39 %) or 168 registers (gas); the functions' own values stay below v64
+//   true   v64-71, v80-87, v96-103, v112-119: four caller-saved blocks again, for the kernels held to 128 registers (FOUR waves
+//          per SIMD — aer: two cells per CU instead of one, +39 %; gas: eight cells per CU); the functions' own values stay below v64
 //          (the build checks it).  (Until round 2 this ring was v96-127: two of those blocks are callee-saved, every call
 //          of gsum_run / tail_solve stored and reloaded 16 registers per lane — most of the aer kernel's HBM-side traffic.)
 // Loads return in issue order, hence "at most PENDING outstanding" means the oldest one — the slot about to be
@@ -673,8 +681,7 @@ __device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const int P, c
 #endif
 ) {
   const int K = P >> 2, S = P & 3, J0P = 4 * P, K2 = (J0P + 4) >> 4;
-  constexpr uint32_t NNZ = MT::NNZ, NVAR = MT::NVAR, H = NVAR - 64, ZERO = 8u * (NNZ + NVAR);
-  constexpr uint32_t PB = 8u * (uint32_t)LdsLayout<MT, NT>::PANEL, BC = PB + 8192u, INFO = 8u * (uint32_t)LdsLayout<MT, NT>::DINFO;
+  constexpr uint32_t PB = 8u * (uint32_t)LdsLayout<MT, NT>::PANEL, BC = PB + 8192u;
   const uint32_t PL = PB + (uint32_t)(P & 1) * 4096u, PU = PL + 2048u;
   const int I = wave >> 1, J0 = 2 * (wave & 1);
   const uint32_t lrow = (uint32_t)(lane >> 4), lcol = (uint32_t)(lane & 15);
@@ -870,15 +877,20 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     const int s = q * NT + t;
     y[q] = s < NVAR ? G_(a.var_in)[(size_t)cell * NVAR + s] : 0.0;
   }
+  auto load_rct = [&](bool opaque) {      // this thread's rate constants (the register-starved kernel fetches them per use, like its factor words)
+    const double* rc = a.rconst;
+    if (opaque) asm volatile("" : "+s"(rc));
 #pragma unroll
-  for (int q = 0; q < RPT; q++) {
-    const int r = q * NT + t;
-    rct[q] = r < NREACT ? G_(a.rconst)[(size_t)cell * NREACT + r] : 0.0;
-  }
+    for (int q = 0; q < RPT; q++) {
+      const int r = q * NT + t;
+      rct[q] = r < NREACT ? G_(rc)[(size_t)cell * NREACT + r] : 0.0;
+    }
+  };
+  load_rct(false);
   // Ghimj slots this thread fills in ros_PrepareMatrix (static per mechanism): fetched once, not once per attempt
   // (two 16-bit positions per register)
-  // RESIDENT: the kernels with 256 registers keep these words for the whole call; the 128-register one (aer, four waves per
-  // SIMD) fetches them where they are used — there they were spilled to scratch and came back from it one at a time.
+  // RESIDENT: the kernel with 256 registers (tot) keeps these words for the whole call; the 128-register ones (aer, gas: four
+  // waves per SIMD) fetch them where they are used — there they were spilled to scratch and came back from it one at a time.
   constexpr bool RESIDENT = MT::WAVES_PER_SIMD <= MISTRA_RESIDENT_MAX_WPS;
   uint32_t jpos[(JPT + 1) / 2], zpos[(ZPT + 1) / 2];
   auto load_pos = [&]() {
@@ -955,7 +967,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   // ---- Fun_x (gas.f:2043): X <- v; A(r) = RCT(r)*X*X*X; Vdot = signed sums of A
   static_assert(SPT == 1 && JPT * NT <= NNZ, "output cells of the gather-sum machine: one species per thread, JVS sums inside Ghimj");
   auto fun = [&](const double (&v)[SPT], double (&out)[SPT]) {
-    if constexpr (!RESIDENT) load_ffac();
+    if constexpr (!RESIDENT) { load_ffac(); load_rct(true); }
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
       const int s = q * NT + t;
@@ -1006,6 +1018,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       asm volatile("" : "+s"(jf));      // opaque: loads through it are not hoisted out of the step loop (and spilled there)
 #pragma unroll
       for (int q = 0; q < 3 * RPT; q++) jfac[q] = G_(jf)[q * NT + t];
+      if constexpr (!RESIDENT) load_rct(true);
     }
     lds_barrier();   // every lane is done reading AB as A
 #pragma unroll
@@ -1131,7 +1144,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
 
   // ---- RosenbrockIntegrator_x (gas.f:1180-1336); option values are the ones INTEGRATE_x/Rosenbrock_x fix
   const double Tstart = a.tin, Tend = a.tout;
-  const double Roundoff = 2.220446049250313e-16, Hmin = 0.0, Hmax = fabs(Tend - Tstart);
+  const double Roundoff = 2.220446049250313e-16, Hmin = 0.0, Hmax = wave_uniform(fabs(Tend - Tstart));
   const double FacMin = 0.2, FacMax = 6.0, FacRej = 0.1, FacSafe = 0.9;
   const double Direction = (Tend >= Tstart) ? 1.0 : -1.0;
   double T = Tstart, Hexit = 0.0;
@@ -1140,6 +1153,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   const double hstart0 = (a.hstart && G_(a.hstart)[cell] > 0.0) ? G_(a.hstart)[cell] : 1.0e-3;
   double H = fmin_f(fmin_f(hstart0, fabs(Tend - Tstart)), Hmax);
   if (fabs(H) <= 10.0 * Roundoff) H = 1.0e-5;
+  H = wave_uniform(H);
   bool RejectLastH = false, RejectMoreH = false;
   int nfun = 0, njac = 0, nstp = 0, nacc = 0, nrej = 0, ndec = 0, nsol = 0, nsng = 0;
   int ierr = 1;
@@ -1150,7 +1164,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     if (nstp > 100000) { ierr = -6; break; }
     if (((T + 0.1 * H) == T) || (H <= Roundoff)) { ierr = -7; break; }
     Hexit = H;
-    H = fmin_f(H, fabs(Tend - T));
+    H = wave_uniform(fmin_f(H, fabs(Tend - T)));
 
     lap(6);
     fun(y, fcn0);
@@ -1172,7 +1186,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
         int nconsecutive = 0;
         bool singular = true;
         while (singular) {
-          const double ghinv = 1.0 / (Direction * H * kRosGamma1);
+          const double ghinv = wave_uniform(1.0 / (Direction * H * kRosGamma1));
           singular = prepare(ghinv, k1);
           dump_matrix(NVAR);      // Ghimj = 1/(H*gamma) - Jac0
           ndec += 1;
@@ -1181,7 +1195,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
             lds_barrier();   // everyone has read flags[0] before the retry clears it
             nsng += 1;
             nconsecutive += 1;
-            if (nconsecutive <= 5) H = H * 0.5;
+            if (nconsecutive <= 5) H = wave_uniform(H * 0.5);
             else { ierr = -8; break; }
           } else {
             vm_run<NT>(a.lu, wave, lane);
@@ -1208,7 +1222,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
         }
         if (ierr == -8) break;
       }
-      const double dh = Direction * H;
+      const double dh = wave_uniform(Direction * H);
       // stage 1: its right-hand side went through the LU program above, only the backward half of the solve is left
       lap(6);
       solve(k1, true);
@@ -1222,9 +1236,9 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       lap(0);
       nfun += 1;
       {
-        const double hc = kRosC1 / dh;
+        const double hc = wave_uniform(kRosC1 / dh);
 #pragma unroll
-        for (int q = 0; q < SPT; q++) k2[q] = (fcn[q] + hc * k1[q]) + (dh * kRosGamma2) * 0.0;
+        for (int q = 0; q < SPT; q++) k2[q] = (fcn[q] + hc * k1[q]) + dh * 0.0;      // + HG*dFdT with dFdT = +0.0: (dh*gamma2)*0.0, a zero of dh's sign (gamma2 > 0)
       }
       lap(6);
       solve(k2, false);
@@ -1232,9 +1246,9 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       lap(4);
       // stage 3 reuses the stage-2 function value
       {
-        const double hc1 = kRosC2 / dh, hc2 = kRosC3 / dh;
+        const double hc1 = wave_uniform(kRosC2 / dh), hc2 = wave_uniform(kRosC3 / dh);
 #pragma unroll
-        for (int q = 0; q < SPT; q++) k3[q] = ((fcn[q] + hc1 * k1[q]) + hc2 * k2[q]) + (dh * kRosGamma3) * 0.0;
+        for (int q = 0; q < SPT; q++) k3[q] = ((fcn[q] + hc1 * k1[q]) + hc2 * k2[q]) + dh * 0.0;      // (dh*gamma3)*0.0 likewise (gamma3 > 0)
       }
       lap(6);
       solve(k3, false);
@@ -1263,18 +1277,18 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
         nacc += 1;
 #pragma unroll
         for (int q = 0; q < SPT; q++) y[q] = ynew[q];
-        T = T + dh;
+        T = wave_uniform(T + dh);
         Hnew = fmax_f(Hmin, fmin_f(Hnew, Hmax));
         if (RejectLastH) Hnew = fmin_f(Hnew, H);
         RejectLastH = false;
         RejectMoreH = false;
-        H = Hnew;
+        H = wave_uniform(Hnew);
         accepted = true;
       } else {
         if (RejectMoreH) Hnew = H * FacRej;
         RejectMoreH = RejectLastH;
         RejectLastH = true;
-        H = Hnew;
+        H = wave_uniform(Hnew);
         if (nacc >= 1) nrej += 1;
       }
     }

@@ -24,7 +24,7 @@ namespace mistra {
 #define MISTRA_TOT_NT 512
 #endif
 #ifndef MISTRA_GAS_WPS
-#define MISTRA_GAS_WPS 3
+#define MISTRA_GAS_WPS 4
 #endif
 #ifndef MISTRA_AER_WPS
 #define MISTRA_AER_WPS 4
