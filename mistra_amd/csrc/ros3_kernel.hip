@@ -1134,7 +1134,11 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
     lds_barrier();   // red[] may still be read from the previous step
-    if (lane == 0) red[wave] = part;
+    {
+      int wv = wave;
+      asm volatile("" : "+v"(wv));      // (the cell's address is formed here: kept across the step loop it was one more spilled register)
+      if (lane == 0) red[wv] = part;
+    }
     lds_barrier();
     double sum = 0.0;
 #pragma unroll
