@@ -2,7 +2,7 @@
 # TEST INFRASTRUCTURE — CPU validation of the two-pass kpp_driver patch (shim/kpp_two_pass.patch).
 # Builds oracle/_ref/mistra_two_pass: the reference model with
 #   * scratch copies of kpp.f90 / gas.f / aer.f / tot.f carrying the patch (oracle/two_pass_patch.py; copies live under
-#     oracle/_ref/two_pass/, git-ignored, never in the repo),
+#     oracle/_ref/two_pass/src only while this script runs),
 #   * the UNMODIFIED shim of shim/ (mistra_kpp_batch.f90, mistra_kpp_shim.f90) taking over INTEGRATE_x by --wrap,
 #   * oracle/two_pass_standin.c in the place of libmistra_chem.so: the batched calls are served by the reference's own
 #     integrator, one cell after the other (there is no GPU in the build container),
@@ -41,4 +41,5 @@ BUD="bud_g bud_a bud_t bud_s_g bud_s_a bud_s_t"
 objs=""; for m in $MODS $BUD $REST; do objs="$objs $O/$m.o"; done
 "$FC" -o "$OUT/mistra_two_pass" "$O/column_driver.o" $objs gas.o aer.o tot.o kpp.o "$O/str_lib.o" mistra_kpp_batch.o shim_wrap.o \
     capture_fn.o standin.o -Wl,--wrap=integrate_g_ -Wl,--wrap=integrate_a_ -Wl,--wrap=integrate_t_ -Wl,--unresolved-symbols=ignore-all
+rm -rf "$TP/src"      # the patched scratch copies are build inputs only: nothing of the reference's text stays under the repo
 echo "oracle/_ref/mistra_two_pass ready"
