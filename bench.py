@@ -52,6 +52,62 @@ def _cpu_worker(job):
     return time.perf_counter() - t0, nstp
 
 
+def _parity_worker(job):
+    """Forked before the parent touched the GPU: the CPU checker's answer for a few cells (inputs exactly as the GPU saw them)."""
+    kind, mech, var, fix, rconst = job
+    import numpy as np
+    from oracle.oracle import Oracle, Reference
+    if kind == "reference":
+        ref = Reference(mech)
+        out, stats = np.empty_like(var), np.zeros((var.shape[0], 8), np.int32)
+        for c in range(var.shape[0]):
+            out[c], stats[c], _, _ = ref.integrate(var[c], fix[c], rconst[c], 0.0, 10.0)
+        return out, stats
+    out, _, stats = Oracle(mech).integrate_batch(var, fix, rconst, 0.0, 10.0)
+    return out, stats
+
+
+class ParityChecker:
+    """The second half of BASELINE.json's metric ("... ; max |dc|/|c| vs ref") for the workload that was just timed: a fixed
+    strided sample of the batch, integrated by the CPU checker (the compiled reference where oracle/_ref holds it, else the
+    plain-C restatement) in worker processes that were forked BEFORE this process initialised the GPU, compared with what the
+    kernel left in `out`.  The checker is only ever the thing compared against."""
+    CELLS = 256
+
+    def __init__(self, mech):
+        import multiprocessing as mp
+        from oracle.oracle import Reference, build_oracle
+        self.mech = mech
+        self.kind = "reference" if Reference.available() else "port"
+        if self.kind == "port":
+            build_oracle()
+        self.workers = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("MISTRA_BENCH_CPU_CORES", "16"))))
+        self.pool = mp.get_context("fork").Pool(self.workers)
+
+    def check(self, var, fix, rconst, out, stats):
+        import numpy as np
+        import torch
+        n = var.shape[0]
+        k = min(self.CELLS, n)
+        sel = torch.arange(k, device=var.device, dtype=torch.int64) * (n // k)
+        v, f, r = (x[sel].cpu().numpy() for x in (var, fix, rconst))
+        got, got_stats = out[sel].cpu().numpy(), stats[sel].cpu().numpy()
+        per = -(-k // self.workers)
+        jobs = [(self.kind, self.mech, v[i:i + per], f[i:i + per], r[i:i + per]) for i in range(0, k, per)]
+        res = self.pool.map(_parity_worker, jobs)
+        self.pool.close()
+        want = np.concatenate([x[0] for x in res])
+        want_stats = np.concatenate([x[1] for x in res])
+        floor = 1e-12 * np.abs(want).max(axis=1, keepdims=True)
+        rel = np.abs(got - want) / (np.abs(want) + floor)
+        major = np.abs(want) >= 1e-4 * np.abs(want).max(axis=1, keepdims=True)
+        return {"max_rel_all": float(rel.max()), "max_rel_major": float(np.where(major, rel, 0.0).max()),
+                "stats_identical": bool(np.array_equal(got_stats, want_stats)), "cells": int(k), "against": self.kind,
+                "what": "every %d-th cell of the timed batch against the CPU %s on the inputs the GPU saw: max over cells and species of "
+                        "|dc| / (|c| + 1e-12 max|c| of the cell); major = species above 1e-4 of the cell maximum; stats = COMMON /Statistics/ "
+                        "(Nfun Njac Nstp Nacc Nrej Ndec Nsol Nsng) of every sampled cell" % (n // k, "reference (oracle/_ref)" if self.kind == "reference" else "restatement (oracle/kpp_ros3.c)")}
+
+
 def kernel_source_hash():
     """Identifies the kernel a PMC pass was taken on: sha256 over the device code and the schedule compiler."""
     import hashlib
@@ -105,6 +161,10 @@ def cpu_baseline(mech, budget_s=15.0):
     wall = time.perf_counter() - t0
     nstp = sum(r[1] for r in res)
     return {"value": ncell / wall, "unit": "chemistry-timesteps/s", "cores": cores, "cores_available": cores_available, "kind": kind,
+            "extrapolated_all_cores": {"value": ncell / wall / cores * cores_available,
+                                       "what": "per-core rate x cores_available (%d): NOT measured — a one-GPU job is granted %d cores; "
+                                               "an upper bound that assumes the serial reference scales linearly over every logical CPU of the host"
+                                               % (cores_available, cores)},
             "sample": "%d cells of the same synthetic %s workload (cells 0..%d), %d processes x 1 thread, %.1f s wall, "
                       "%.1f internal steps/cell, %.0f timesteps/s/core" % (ncell, mech, ncell - 1, cores, wall,
                                                                          nstp / ncell, ncell / wall / cores)}
@@ -171,6 +231,11 @@ def root_io_leg(args, dist, dev, world, rank, engine, make_batch, shard):
         for q in reqs:
             q.wait()
         ok = int(sum(int((g[:, shapes[0]] == 1).sum().item()) for g in gathered))
+        if getattr(args, "dump_root_io", None):
+            import numpy as np
+            allr = torch.cat([g.cpu() for g in gathered]).numpy()
+            np.savez(args.dump_root_io, var_out=allr[:, :shapes[0]], ierr=allr[:, shapes[0]].astype(np.int32),
+                     stats=allr[:, shapes[0] + 1:].astype(np.int32))
     else:
         dist.send(packed, dst=0)
         ok = 0
@@ -194,6 +259,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL; gloo only for rehearsing the rank logic)")
+    ap.add_argument("--dump-root-io", default=None,
+                    help="tests only: rank 0 writes what the root-I/O leg gathered (VAR_out, ierr, stats of all shards) to this .npz")
+    ap.add_argument("--no-parity", action="store_true", help="skip the post-run parity sample against the CPU checker")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (requires --backend gloo)")
     args = ap.parse_args()
@@ -205,9 +273,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
 
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.mech)          # before any GPU initialisation in this process (forks workers)
+    if rank == 0 and world == 1 and not args.no_parity:
+        parity = ParityChecker(args.mech)      # idle worker processes, forked before any GPU initialisation
 
     import torch
     import torch.distributed as dist
@@ -226,7 +296,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-    line = rank_body(args, rank, world, dev, GpuEngine(local_rank))
+    line = rank_body(args, rank, world, dev, GpuEngine(local_rank), parity)
     if rank == 0:
         if cpu is not None:
             line["cpu_baseline"] = cpu
@@ -260,7 +330,7 @@ class GpuEngine:
         return a.elapsed_time(b)
 
 
-def rank_body(args, rank, world, dev, engine):
+def rank_body(args, rank, world, dev, engine, parity=None):
     """What one rank does (the process group, if any, is up): build its shard in place, warm up, time `steps` passes between
     barrier + synchronize on both sides, reduce (max of the time, sums of the counters), run the root-I/O leg; returns the
     JSON line on rank 0.  `engine` is the product (GpuEngine); tests/test_partition_gloo.py drives this same function on two
@@ -308,6 +378,7 @@ def rank_body(args, rank, world, dev, engine):
     root_io = root_io_leg(args, dist, dev, world, rank, engine, make_batch, shard)
     if rank != 0:
         return None
+    parity_line = parity.check(var, fix, rconst, out, stats) if parity is not None else None      # outside the timed region
     value = total_cells * args.steps / elapsed
     steps_per_cell = nstp_total / cells_done
     achieved = ncell * ALG_BYTES[args.mech] / (kernel_ms * 1e-3) / 1e9
@@ -317,6 +388,7 @@ def rank_body(args, rank, world, dev, engine):
         "metric": "chemistry-timesteps/sec (%s mechanism)" % args.mech, "value": value, "unit": "chemistry-timesteps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "parity": parity_line,
         "config": {"workload": "%s mechanism, %d synthetic cells per GPU (%d total), INTEGRATE_%s(0,10 s), Ros3 rtol 1e-3; "
                                "perturbed captured BTZ96 cloud states" % (args.mech, args.cells_per_gpu, total_cells, args.mech[0]),
                    "cells_per_gpu": args.cells_per_gpu, "mean_internal_steps_per_cell": steps_per_cell,

@@ -39,7 +39,9 @@ int mistra_chem_init(int device);
  * serial, kpp.f90:4168): mistra_chem_integrate then cuts the batch into contiguous blocks of cells, one block and one host
  * thread per device — the layer loop of kpp_driver (kpp.f90:4310-4470) carries nothing from one k to the next, so
  * nothing is exchanged.  device_ids = NULL means devices 0 .. n_devices-1; the first one listed is the primary device
- * (one-cell entry points, mistra_chem_describe).  Replaces a previous init. */
+ * (one-cell entry points, mistra_chem_describe).  A device may be listed more than once: every listing is a slot of its
+ * own (tables, staging buffers, host thread), so the blocks that share a GPU overlap one block's copies with the other's
+ * kernel — and the split can be exercised on a one-GPU box.  Replaces a previous init. */
 int mistra_chem_init_devices(int n_devices, const int* device_ids);
 
 /* Number of devices the library is initialised on (0 before init). */

@@ -38,7 +38,7 @@ def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
     headers.append(os.path.join(PKG, "..", "include", "mistra_chem.h"))
     headers.append(os.path.abspath(__file__))
     objs = []

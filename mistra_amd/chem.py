@@ -144,6 +144,33 @@ def integrate(mech, var, fix, rconst, tin=0.0, tout=10.0, device=None):
     return IntegrateResult(out, ierr, stats)
 
 
+def integrate_ex(mech, var, fix, rconst, tin=0.0, tout=10.0):
+    """mistra_chem_integrate_ex on host buffers: what `integrate` returns plus t_h [ncell, 3] — per cell the exit time (-> TIN,
+    gas.f:769), the last accepted step (-> STEPMIN, gas.f:770) and H when the integrator returned.  This is the call the batched
+    Fortran surface makes (shim/mistra_kpp_shim.f90: INTEGRATE_BATCH_x); with several devices initialised (init_devices) the
+    library cuts the batch into one block per device."""
+    mid, name = _mech_id(mech)
+    nvar, nfix, nreact, _ = DIMS[name]
+    if _inited_device is None:
+        init(0)
+    v = np.ascontiguousarray(var, np.float64).reshape(-1, nvar)
+    ncell = v.shape[0]
+    f = np.ascontiguousarray(fix, np.float64).reshape(ncell, nfix)
+    r = np.ascontiguousarray(rconst, np.float64).reshape(ncell, nreact)
+    out = np.empty_like(v)
+    ierr = np.zeros(ncell, np.int32)
+    stats = np.zeros((ncell, 8), np.int32)
+    th = np.zeros((ncell, 3))
+    _check(lib().mistra_chem_integrate_ex(mid, ncell, v.ctypes.data_as(_dp), f.ctypes.data_as(_dp), r.ctypes.data_as(_dp),
+                                         float(tin), float(tout), out.ctypes.data_as(_dp), ierr.ctypes.data_as(_ip),
+                                         stats.ctypes.data_as(_ip), th.ctypes.data_as(_dp)))
+    return IntegrateResult(out, ierr, stats), th
+
+
+def device_count():
+    return lib().mistra_chem_device_count()
+
+
 def _integrate_torch(mid, name, var, fix, rconst, tin, tout, out=None, ierr=None, stats=None, texit_hexit=None, hstart=None):
     import torch
     nvar, nfix, nreact, _ = DIMS[name]

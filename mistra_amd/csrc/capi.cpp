@@ -294,13 +294,13 @@ int init_locked(int n, const int* ids) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) return fail("no HIP device available (this library has no CPU path)");
-  if (n <= 0 || n > count) return fail("device count out of range");
+  if (n <= 0 || n > 64) return fail("device count out of range");      // (more slots than GPUs is legal: a device may be listed more than once)
   std::vector<int> want((size_t)n);
   for (int i = 0; i < n; i++) {
     want[(size_t)i] = ids ? ids[i] : i;
     if (want[(size_t)i] < 0 || want[(size_t)i] >= count) return fail("device index out of range");
-    for (int j = 0; j < i; j++)
-      if (want[(size_t)j] == want[(size_t)i]) return fail("a device is listed twice");
+    // (a device may be listed more than once: every listing is a slot of its own — tables, staging buffers, host thread —
+    //  so two blocks of one batch overlap their copies with each other's kernel on that GPU; include/mistra_chem.h)
   }
   bool same = g_inited && g_devs.size() == want.size();
   for (size_t i = 0; same && i < want.size(); i++) same = g_devs[i].id == want[i];
@@ -340,9 +340,14 @@ int integrate_host_on(DeviceState& D, int mech, int ncell, const double* var_in,
   HIP_TRY(hipMemcpy(S.s_rct.p, rconst, nc * nr * sizeof(double), hipMemcpyHostToDevice));
   KernelArgs a = make_args(S, ncell, S.s_var.p, S.s_fix.p, S.s_rct.p, tin, tout, S.s_var.p, S.s_ierr.p, S.s_stats.p, t_h ? S.s_th.p : nullptr);
   if (t_h) a.h_last = S.s_th.p + 2 * nc;
-  // diagnostics: MISTRA_CHEM_PROFILE=1 prints where wave 0 of the workgroups spent its cycles (mean over the cells of the call)
+  // diagnostic builds only (-DMISTRA_DIAG_ENV, tools/diag_dense.sh env): MISTRA_CHEM_PROFILE=1 prints where wave 0 of the
+  // workgroups spent its cycles (mean over the cells of the call).  The product library does not read the environment here.
   DevBuf<unsigned long long> prof;
+#ifdef MISTRA_DIAG_ENV
   const bool profile = std::getenv("MISTRA_CHEM_PROFILE") != nullptr;
+#else
+  const bool profile = false;
+#endif
   if (profile) {
     HIP_TRY(prof.reserve(nc * kProfSlots));
     a.prof = prof.p;

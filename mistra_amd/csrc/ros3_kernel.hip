@@ -10,7 +10,8 @@
 //   HBM        read VAR, FIX, RCONST once (coalesced, cell-major), write VAR once; schedule words stream from L2
 //
 // gfx950 only.  Built with -ffp-contract=off: every multiply and add/subtract rounds once, as in the reference
-// built without FMA contraction.  No MFMA: there is no dense contraction in this path.
+// built without FMA contraction.  MFMA (v_mfma_f64_16x16x4_f64) is used in ONE place: the last 64x64 block of the tot
+// mechanism's LU, which fill-in makes completely dense (dense_lu below); everything else is sparse gather arithmetic.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -162,109 +163,22 @@ __device__ __forceinline__ u32x4 vm_ring_take() {
 }
 static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots");
 
-// ---- the LDS VM executor (schedule.hpp), hand-scheduled: one asm statement holds the whole program loop.
-// Measured on the C++ executor it replaces: a round in which every wave has a single record cost ~1000 cycles, ~370 of
-// them plain instruction issue of a lone wave (ring copies, mark decoding, branches) — 89 LU rounds and 33 solve rounds
-// per Rosenbrock step.  Here a plain record is 23 instructions:
-//   * records land straight in VGPRs: a 4-record ring in v48-55 / v64-71 / v80-87 / v96-103 (caller-saved blocks), named
-//     only inside this statement, so no compiler copy can get between a load and its counted wait (cdna_hip_programming.md
-//     §5.7); a slot is refilled (row + 4) as soon as its ds_reads have been ISSUED (they take their addresses at issue);
+// ---- the LDS VM executor (schedule.hpp), hand-scheduled: one asm statement holds the whole program loop; its instruction
+// stream is generated (tools/gen_vm_asm.py -> vm_exec_asm.inc, where the pipeline and the wait counts are explained).
+//   * records land straight in VGPRs: a ring of N 8-register slots in caller-saved blocks (v48-55, v64-71, ...: N = 4 for the
+//     kernels held to 128 registers, 8 for tot), named only inside this statement, so no compiler copy can get between a load
+//     and its counted wait (cdna_hip_programming.md §5.7); a slot is refilled (row + N) behind its record's store;
 //   * d0, d2..d7 of a record are LDS byte addresses as they stand (M starts at LDS address 0, checked at kernel entry);
-//     every mark sits on d1: one v_readfirstlane per record, then s_bitcmp on the row marks;
-//   * table addresses are SGPR base + 32-bit VGPR offset + immediate: two v_add per four records;
-//   * marked rows (aux operand: scale by a pivot reciprocal, or publish one) and null rows run out of line.
+//     every mark sits on d1: one v_readfirstlane per record, one scalar test for "any mark" on the main line;
+//   * round 3: the six operand gathers of record S+1 are issued at the head of record S (two operand register sets), so a
+//     lone wave no longer waits out an LDS round trip per record: measured ~250 cycles per record row before, the record's
+//     own instruction issue now.  The arithmetic and its order are unchanged (bit-identical results);
+//   * marked rows (aux operand: scale by a pivot reciprocal, or publish one; end of round; null rows) run out of line.
 // A continuation record reloads its target: its lane's previous record stored it, and LDS is in-order within a wave.
 // The IEEE reciprocal is the sequence hipcc emits for 1.0/x (v_div_scale, v_rcp, two Newton steps, v_div_fmas, v_div_fixup).
-#define MISTRA_VM_REFILL(LO, HI, VX, OFF_LO, OFF_HI)                                   \
-  "global_load_dwordx4 " LO ", " VX ", %[base] offset:" OFF_LO "\n\t"                   \
-  "global_load_dwordx4 " HI ", " VX ", %[base] offset:" OFF_HI "\n\t"
-#define MISTRA_VM_UPDATES                                                              \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                            \
-  "v_mul_f64 %[a1], %[a1], %[r1]\n\t"                                                   \
-  "s_waitcnt lgkmcnt(3)\n\t"                                                            \
-  "v_mul_f64 %[a1], %[a1], %[u1]\n\t"                                                   \
-  "s_waitcnt lgkmcnt(1)\n\t"                                                            \
-  "v_mul_f64 %[a2], %[a2], %[r2]\n\t"                                                   \
-  "v_add_f64 %[acc], %[acc], -%[a1]\n\t"                                                \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                            \
-  "v_mul_f64 %[a2], %[a2], %[u2]\n\t"                                                   \
-  "v_add_f64 %[acc], %[acc], -%[a2]\n\t"
-// main line of one ring slot: S = slot tag for labels, D0..D7 = the slot's registers
-#define MISTRA_VM_RECORD(S, D0, D1, D2, D3, D4, D5, D6, D7, LO, HI, VX, OFF_LO, OFF_HI) \
-  "s_waitcnt vmcnt(6)\n\t"                      /* 8 loads in flight, the two oldest are this slot's */ \
-  "v_readfirstlane_b32 %[fl], " D1 "\n\t"                                               \
-  "s_bitcmp1_b32 %[fl], 25\n\t"                 /* VM_ROW_NULL */                       \
-  "s_cbranch_scc1 Lvm_null" S "_%=\n\t"                                                 \
-  "ds_read_b64 %[acc], " D0 "\n\t"                                                      \
-  "ds_read_b64 %[a1], " D2 "\n\t"                                                       \
-  "ds_read_b64 %[r1], " D3 "\n\t"                                                       \
-  "ds_read_b64 %[u1], " D4 "\n\t"                                                       \
-  "ds_read_b64 %[a2], " D5 "\n\t"                                                       \
-  "ds_read_b64 %[r2], " D6 "\n\t"                                                       \
-  "ds_read_b64 %[u2], " D7 "\n\t"                                                       \
-  "v_mov_b32 %[tg], " D0 "\n\t"                                                         \
-  "s_bitcmp1_b32 %[fl], 26\n\t"                 /* VM_ROW_AUX */                        \
-  "s_cbranch_scc1 Lvm_aux" S "_%=\n\t"                                                  \
-  MISTRA_VM_REFILL(LO, HI, VX, OFF_LO, OFF_HI)                                          \
-  MISTRA_VM_UPDATES                                                                     \
-  "ds_write_b64 %[tg], %[acc]\n"                                                        \
-  "Lvm_done" S "_%=:\n\t"                                                               \
-  "s_bitcmp1_b32 %[fl], 24\n\t"                 /* VM_ROW_EOR */                        \
-  "s_cbranch_scc0 Lvm_next" S "_%=\n\t"                                                 \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                            \
-  "s_barrier\n\t"                                                                       \
-  "s_sub_u32 %[rounds], %[rounds], 1\n\t"                                               \
-  "s_cmp_eq_u32 %[rounds], 0\n\t"                                                       \
-  "s_cbranch_scc1 Lvm_exit_%=\n"                                                        \
-  "Lvm_next" S "_%=:\n\t"
-// out of line: a row whose lanes scale by M[aux] (aux = d1 & VM_AUX_MASK) or publish the reciprocal of their result there
-#define MISTRA_VM_RECORD_TAIL(S, D0, D1, LO, HI, VX, OFF_LO, OFF_HI)                    \
-  "Lvm_aux" S "_%=:\n\t"                                                                \
-  "v_and_b32 %[ax], 0xfffff8, " D1 "\n\t"                                               \
-  "v_and_b32 %[t], 1, " D1 "\n\t"                                                       \
-  "ds_read_b64 %[sc], %[ax]\n\t"                                                        \
-  "v_cmp_eq_u32 vcc, 1, %[t]\n\t"               /* lanes that publish (VM_D1_RCP) */    \
-  MISTRA_VM_REFILL(LO, HI, VX, OFF_LO, OFF_HI)                                          \
-  "s_waitcnt lgkmcnt(5)\n\t"                                                            \
-  "v_mul_f64 %[a1], %[a1], %[r1]\n\t"                                                   \
-  "s_waitcnt lgkmcnt(4)\n\t"                                                            \
-  "v_mul_f64 %[a1], %[a1], %[u1]\n\t"                                                   \
-  "s_waitcnt lgkmcnt(2)\n\t"                                                            \
-  "v_mul_f64 %[a2], %[a2], %[r2]\n\t"                                                   \
-  "v_add_f64 %[acc], %[acc], -%[a1]\n\t"                                                \
-  "s_waitcnt lgkmcnt(1)\n\t"                                                            \
-  "v_mul_f64 %[a2], %[a2], %[u2]\n\t"                                                   \
-  "v_add_f64 %[acc], %[acc], -%[a2]\n\t"                                                \
-  "s_mov_b64 %[sv], exec\n\t"                                                           \
-  "s_andn2_b64 %[sm], exec, vcc\n\t"                                                    \
-  "s_mov_b64 exec, %[sm]\n\t"                   /* lanes that scale */                  \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                            \
-  "v_mul_f64 %[sc], %[acc], %[sc]\n\t"                                                  \
-  "ds_write_b64 %[tg], %[sc]\n\t"                                                       \
-  "s_and_b64 exec, %[sv], vcc\n\t"              /* lanes that publish */                \
-  "s_cbranch_execz Lvm_auxe" S "_%=\n\t"                                                \
-  "ds_write_b64 %[tg], %[acc]\n\t"                                                      \
-  "v_div_scale_f64 %[a1], vcc, %[acc], %[acc], 1.0\n\t"                                 \
-  "v_rcp_f64 %[r1], %[a1]\n\t"                                                          \
-  "v_div_scale_f64 %[u1], vcc, 1.0, %[acc], 1.0\n\t"                                    \
-  "v_fma_f64 %[a2], -%[a1], %[r1], 1.0\n\t"                                             \
-  "v_fma_f64 %[r1], %[r1], %[a2], %[r1]\n\t"                                            \
-  "v_fma_f64 %[a2], -%[a1], %[r1], 1.0\n\t"                                             \
-  "v_fma_f64 %[r1], %[r1], %[a2], %[r1]\n\t"                                            \
-  "v_mul_f64 %[a2], %[u1], %[r1]\n\t"                                                   \
-  "v_fma_f64 %[a1], -%[a1], %[a2], %[u1]\n\t"                                           \
-  "s_nop 1\n\t"                                                                         \
-  "v_div_fmas_f64 %[a1], %[a1], %[r1], %[a2]\n\t"                                       \
-  "v_div_fixup_f64 %[a1], %[a1], %[acc], 1.0\n\t"                                       \
-  "ds_write_b64 %[ax], %[a1]\n"                                                         \
-  "Lvm_auxe" S "_%=:\n\t"                                                               \
-  "s_mov_b64 exec, %[sv]\n\t"                                                           \
-  "s_branch Lvm_done" S "_%=\n"                                                         \
-  "Lvm_null" S "_%=:\n\t"                                                               \
-  MISTRA_VM_REFILL(LO, HI, VX, OFF_LO, OFF_HI)                                          \
-  "s_branch Lvm_done" S "_%=\n"
+#include "vm_exec_asm.inc"
 
-template <int NT>
+template <int NT, bool WIDE>
 __device__ __attribute__((noinline)) void vm_run(const VmDev P, int wave, int lane) {
   const uint64_t recs = reinterpret_cast<uint64_t>(P.recs);      // the same in every lane: move it to SGPRs
   const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs) |
@@ -272,44 +186,28 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev P, int wave, int la
   uint32_t va = (uint32_t)G_(P.wave_base)[wave] * 2048u + (uint32_t)lane * 16u;     // this lane's first record (planar rows: lo plane, hi plane + 1024), bytes
   uint32_t vb = va + 4096u;                                                          // rows +2, +3
   int rounds = __builtin_amdgcn_readfirstlane(P.nrounds);
-  double acc, a1, r1, u1, a2, r2, u2, sc;
-  uint32_t tg, ax, t, fl;
+  double acc, a1A, r1A, u1A, a2A, r2A, u2A, a1B, r1B, u1B, a2B, r2B, u2B, sc;
+  uint32_t ax, t, flA, flB, tmp;
   uint64_t sv, sm;
-  asm volatile(
-      "s_waitcnt vmcnt(0)\n\t"                  // nothing of the caller's may sit between the counted loads
-      "s_nop 4\n\t"
-      MISTRA_VM_REFILL("v[48:51]", "v[52:55]", "%[va]", "0", "1024")
-      MISTRA_VM_REFILL("v[64:67]", "v[68:71]", "%[va]", "2048", "3072")
-      MISTRA_VM_REFILL("v[80:83]", "v[84:87]", "%[vb]", "0", "1024")
-      MISTRA_VM_REFILL("v[96:99]", "v[100:103]", "%[vb]", "2048", "3072")
-      "v_add_u32 %[va], 0x2000, %[va]\n\t"
-      "v_add_u32 %[vb], 0x2000, %[vb]\n"
-      "Lvm_loop_%=:\n\t"
-      MISTRA_VM_RECORD("0", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[48:51]", "v[52:55]", "%[va]", "0", "1024")
-      MISTRA_VM_RECORD("1", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v[64:67]", "v[68:71]", "%[va]", "2048", "3072")
-      MISTRA_VM_RECORD("2", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v[80:83]", "v[84:87]", "%[vb]", "0", "1024")
-      MISTRA_VM_RECORD("3", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v[96:99]", "v[100:103]", "%[vb]", "2048", "3072")
-      "v_add_u32 %[va], 0x2000, %[va]\n\t"
-      "v_add_u32 %[vb], 0x2000, %[vb]\n\t"
-      "s_branch Lvm_loop_%=\n"
-      MISTRA_VM_RECORD_TAIL("0", "v48", "v49", "v[48:51]", "v[52:55]", "%[va]", "0", "1024")
-      MISTRA_VM_RECORD_TAIL("1", "v64", "v65", "v[64:67]", "v[68:71]", "%[va]", "2048", "3072")
-      MISTRA_VM_RECORD_TAIL("2", "v80", "v81", "v[80:83]", "v[84:87]", "%[vb]", "0", "1024")
-      MISTRA_VM_RECORD_TAIL("3", "v96", "v97", "v[96:99]", "v[100:103]", "%[vb]", "2048", "3072")
-      "Lvm_exit_%=:\n\t"
-      "s_waitcnt vmcnt(0)"                      // the look-ahead loads must have landed before the ring registers are reused
-      : [acc] "=&v"(acc), [a1] "=&v"(a1), [r1] "=&v"(r1), [u1] "=&v"(u1), [a2] "=&v"(a2), [r2] "=&v"(r2), [u2] "=&v"(u2),
-        [sc] "=&v"(sc), [tg] "=&v"(tg), [ax] "=&v"(ax), [t] "=&v"(t), [fl] "=&s"(fl), [sv] "=&s"(sv), [sm] "=&s"(sm),
-        [va] "+v"(va), [vb] "+v"(vb), [rounds] "+s"(rounds)
-      : [base] "s"(base)
-      : "memory", "vcc", "scc", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v64", "v65", "v66", "v67", "v68",
-        "v69", "v70", "v71", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v96", "v97", "v98", "v99", "v100",
-        "v101", "v102", "v103");
+  if constexpr (WIDE) {
+    uint32_t vc = va + 8192u, vd = va + 12288u;                                      // rows +4, +5 and +6, +7
+    asm volatile(MISTRA_VM_ASM_N8
+                 : [acc] "=&v"(acc), [a1A] "=&v"(a1A), [r1A] "=&v"(r1A), [u1A] "=&v"(u1A), [a2A] "=&v"(a2A), [r2A] "=&v"(r2A), [u2A] "=&v"(u2A),
+                   [a1B] "=&v"(a1B), [r1B] "=&v"(r1B), [u1B] "=&v"(u1B), [a2B] "=&v"(a2B), [r2B] "=&v"(r2B), [u2B] "=&v"(u2B),
+                   [sc] "=&v"(sc), [ax] "=&v"(ax), [t] "=&v"(t), [flA] "=&s"(flA), [flB] "=&s"(flB), [tmp] "=&s"(tmp), [sv] "=&s"(sv), [sm] "=&s"(sm),
+                   [va] "+v"(va), [vb] "+v"(vb), [vc] "+v"(vc), [vd] "+v"(vd), [rounds] "+s"(rounds)
+                 : [base] "s"(base)
+                 : "memory", "vcc", "scc", MISTRA_VM_CLOBBER_N8);
+  } else {
+    asm volatile(MISTRA_VM_ASM_N4
+                 : [acc] "=&v"(acc), [a1A] "=&v"(a1A), [r1A] "=&v"(r1A), [u1A] "=&v"(u1A), [a2A] "=&v"(a2A), [r2A] "=&v"(r2A), [u2A] "=&v"(u2A),
+                   [a1B] "=&v"(a1B), [r1B] "=&v"(r1B), [u1B] "=&v"(u1B), [a2B] "=&v"(a2B), [r2B] "=&v"(r2B), [u2B] "=&v"(u2B),
+                   [sc] "=&v"(sc), [ax] "=&v"(ax), [t] "=&v"(t), [flA] "=&s"(flA), [flB] "=&s"(flB), [tmp] "=&s"(tmp), [sv] "=&s"(sv), [sm] "=&s"(sm),
+                   [va] "+v"(va), [vb] "+v"(vb), [rounds] "+s"(rounds)
+                 : [base] "s"(base)
+                 : "memory", "vcc", "scc", MISTRA_VM_CLOBBER_N4);
+  }
 }
-#undef MISTRA_VM_REFILL
-#undef MISTRA_VM_UPDATES
-#undef MISTRA_VM_RECORD
-#undef MISTRA_VM_RECORD_TAIL
 
 // ---- tail chain of the triangular solves (schedule.hpp: TailSolve), run by ONE wave: lane l holds rows h+l and
 //      h+64+l of the solution in registers, the pivot value travels by v_readlane, matrix entries are gathered from
@@ -1098,7 +996,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       }
       lds_barrier();
       lap(6);
-      vm_run<NT>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
+      vm_run<NT, !MT::RING_LOW>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
       lap(8);
       if (wave == 0)                                                                         // tail chain, one wave
         tail_solve<MT::TAIL_REGS, 0, MT::RING_LOW, kDenseInfo, kZeroCell>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
@@ -1109,7 +1007,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     }
     lds_barrier();
     lap(9);
-    vm_run<NT>(a.solve_head_bwd, wave, lane);
+    vm_run<NT, !MT::RING_LOW>(a.solve_head_bwd, wave, lane);
     lap(10);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
@@ -1202,7 +1100,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
             if (nconsecutive <= 5) H = wave_uniform(H * 0.5);
             else { ierr = -8; break; }
           } else {
-            vm_run<NT>(a.lu, wave, lane);
+            vm_run<NT, !MT::RING_LOW>(a.lu, wave, lane);
             if constexpr (MT::SCALE_PASS) {      // else the scaling is the LU program's last round
               lap(3);
               scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);      // L(k,j) *= R(j); tail block: U(i,c) *= R(i)

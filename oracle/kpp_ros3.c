@@ -6,7 +6,7 @@
  *
  * Parity status: PINNED — bit-exact against the reference itself (oracle/_ref/libmistra_ref.so, flang -O2
  * -ffp-contract=off, built from /root/reference/src by oracle/build_ref.sh) on every function below and on whole
- * INTEGRATE_x calls captured from the running reference model; see tests/test_oracle_vs_reference.py and
+ * INTEGRATE_x calls captured from the running reference model; see tests/test_oracle.py and
  * tests/golden/ (the reference ships no golden vectors of its own).
  *
  * The mechanism (reaction products, stoichiometric sums, LU sparsity) comes from the committed tables
@@ -356,5 +356,21 @@ void kpp_integrate_batch(const kpp_mech *m, int ncell, double *var, const double
     ierr[c] = kpp_integrate(m, var + (size_t)c * m->nvar, fix + (size_t)c * m->nfix, rconst + (size_t)c * m->nreact, tin,
                             tout, stats + (size_t)c * 8, &te, &he, work);
   }
+  free(work);
+}
+
+/* The same with a first step size per cell (hstart[c] <= 0: INTEGRATE_x's 1e-3) — the checker's side of the kernel's OPT-IN
+ * Hstart-reuse mode (include/mistra_chem.h: mistra_chem_integrate_device_hstart; NOT the reference's behaviour, gas.f:743). */
+void kpp_integrate_batch_hstart(const kpp_mech *m, int ncell, double *var, const double *fix, const double *rconst, double tin,
+                                double tout, const double *hstart, int32_t *ierr, int32_t *stats /* [ncell][8] */) {
+  double *work = (double *)malloc(sizeof(double) * kpp_work_doubles(m));
+  const double saved = opt_hstart;
+  for (int c = 0; c < ncell; c++) {
+    double te, he;
+    opt_hstart = hstart[c] > 0.0 ? hstart[c] : 0.0;
+    ierr[c] = kpp_integrate(m, var + (size_t)c * m->nvar, fix + (size_t)c * m->nfix, rconst + (size_t)c * m->nreact, tin,
+                            tout, stats + (size_t)c * 8, &te, &he, work);
+  }
+  opt_hstart = saved;
   free(work);
 }

@@ -56,6 +56,7 @@ def _oracle_lib():
         lib.kpp_set_variant.argtypes = [C.c_int]
         lib.kpp_set_options.argtypes = [C.c_double, C.c_double, C.c_double]
         lib.kpp_integrate_batch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _ip]
+        lib.kpp_integrate_batch_hstart.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip]
         _lib = lib
     return _lib
 
@@ -113,12 +114,18 @@ class Oracle:
                                       C.byref(te), C.byref(he), _d(self.work))
         return v, ierr, st, te.value, he.value
 
-    def integrate_batch(self, var, fix, rconst, tin=0.0, tout=10.0):
-        """cell-major arrays [ncell, n*] -> (var_out, ierr[ncell], stats[ncell,8])"""
+    def integrate_batch(self, var, fix, rconst, tin=0.0, tout=10.0, hstart=None):
+        """cell-major arrays [ncell, n*] -> (var_out, ierr[ncell], stats[ncell,8]).  hstart [ncell]: a first step size per cell
+        instead of INTEGRATE_x's 1e-3 (entries <= 0: the reference's value) — the kernel's opt-in mode, not the reference's."""
         v = np.array(var, np.float64, order="C")
         ncell = v.shape[0]
         ierr = np.zeros(ncell, np.int32)
         st = np.zeros((ncell, 8), np.int32)
+        if hstart is not None:
+            h = np.ascontiguousarray(hstart, np.float64).reshape(ncell)
+            self.lib.kpp_integrate_batch_hstart(self.h, ncell, _d(v), _d(np.ascontiguousarray(fix, np.float64)),
+                                                _d(np.ascontiguousarray(rconst, np.float64)), tin, tout, _d(h), _i(ierr), _i(st))
+            return v, ierr, st
         self.lib.kpp_integrate_batch(self.h, ncell, _d(v), _d(np.ascontiguousarray(fix, np.float64)),
                                      _d(np.ascontiguousarray(rconst, np.float64)), tin, tout, _i(ierr), _i(st))
         return v, ierr, st

@@ -73,8 +73,70 @@ def draw_generic(rng, names, n):
     return env
 
 
+def read_rates_capture(path):
+    """records of oracle/capture_rates_wrap.c -> list of dicts (mech, callno, env, c, rconst)"""
+    raw = open(path, "rb").read()
+    off, recs = 0, []
+    while off < len(raw):
+        h = np.frombuffer(raw, np.int32, 6, off)
+        off += 24
+        assert h[0] == 0x52415445
+        mech, nenv, nspec, nreact, callno = (int(x) for x in h[1:6])
+        d = np.frombuffer(raw, np.float64, nenv + nspec + nreact, off)
+        off += 8 * (nenv + nspec + nreact)
+        recs.append(dict(mech=("gas", "aer", "tot")[mech], callno=callno, env=d[:nenv].copy(), c=d[nenv:nenv + nspec].copy(),
+                         rconst=d[nenv + nspec:].copy()))
+    return recs
+
+
+# Update_RCONST_x calls of the RUNNING reference model (oracle/capture_rates_wrap.c): the env vector as the product's Fortran routine
+# MISTRA_RATES_ENV_x (shim/mistra_kpp_rates.f90) packed it from the model's COMMON blocks, C = VAR | FIX of that layer, and the
+# RCONST the reference's Update_RCONST_x made of them.  name -> (capture file, what was run)
+MODEL_SETS = {
+    "BTZ96": ("capture_rates_BTZ96.bin",
+              "reference namelist.BTZ96 (chem=F -> T, netcdf=F), model minutes 1-12 (night, stratus: gas, aer and tot layers); "
+              "MISTRA_RUN_TAG=_rates MISTRA_COLUMN_MINUTES=12 oracle/capture_run.sh BTZ96 1 MISTRA_CAPTURE_RATES_FILE=... "
+              "MISTRA_CAPTURE_RATES_SKIP_g=500 _EVERY_g=131 _MAX_g=24 _SKIP_a=300 _EVERY_a=61 _MAX_a=24 _SKIP_t=500 _EVERY_t=97 _MAX_t=24"),
+    "base1": ("capture_rates_base1.bin",
+              "reference namelist.base1 (netcdf=F), model minutes 1-40 (cloud-free: gas and aer layers); "
+              "MISTRA_RUN_TAG=_rates MISTRA_COLUMN_MINUTES=40 oracle/capture_run.sh base1 1 MISTRA_CAPTURE_RATES_FILE=... "
+              "MISTRA_CAPTURE_RATES_SKIP_g=3000 _EVERY_g=997 _MAX_g=16 _SKIP_a=3000 _EVERY_a=811 _MAX_a=16"),
+}
+NVAR = {"gas": 102, "aer": 257, "tot": 417}
+
+
+def model_sets():
+    """tests/golden/rates_model_<mech>.npz from the captures above (all sets of a mechanism in one file, `source` says which)"""
+    ref = os.path.join(HERE, "..", "..", "oracle", "_ref")
+    info = open(os.path.join(ref, "BUILD_INFO")).read().replace("\n", "; ")
+    per = {"gas": [], "aer": [], "tot": []}
+    prov = []
+    for name, (fname, what) in MODEL_SETS.items():
+        path = os.path.join(ref, fname)
+        if not os.path.exists(path):
+            print("no capture", path, "- skipped")
+            continue
+        prov.append(name + ": " + what)
+        for r in read_rates_capture(path):
+            r["source"] = name
+            per[r["mech"]].append(r)
+    for mech, rs in per.items():
+        if not rs:
+            continue
+        nv = NVAR[mech]
+        out = dict(env=np.stack([r["env"] for r in rs]), var=np.stack([r["c"][:nv] for r in rs]), fix=np.stack([r["c"][nv:] for r in rs]),
+                   rconst=np.stack([r["rconst"] for r in rs]), callno=np.array([r["callno"] for r in rs], np.int32),
+                   source=np.array([r["source"] for r in rs]), provenance=np.array(" | ".join(prov) + "; " + info))
+        path = os.path.join(HERE, "rates_model_%s.npz" % mech)
+        np.savez_compressed(path, **out)
+        print(path, os.path.getsize(path), "bytes;", len(rs), "captured Update_RCONST_%s calls;" % mech[0],
+              "photolysis on in", int((out["rconst"] != 0).sum(axis=1).max() > (out["rconst"] != 0).sum(axis=1).min()), "(0/1)")
+
+
 def main():
     import json
+    if "model" in sys.argv[1:]:
+        return model_sets()
     info = open(os.path.join(HERE, "..", "..", "oracle", "_ref", "BUILD_INFO")).read().replace("\n", "; ")
     for mech, n in (("gas", 96), ("aer", 48), ("tot", 48)):
         rng = np.random.default_rng(20261004)

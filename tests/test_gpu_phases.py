@@ -100,8 +100,8 @@ def test_phases_of_the_first_step(chem, emu, mech, golden, oracles):
         rowmax = np.array([np.abs(lu_emu[t.crow[r]:t.crow[r + 1]]).max() for r in range(o.nvar)])
         scale = np.repeat(rowmax, np.diff(t.crow))
         worst["lu_vs_emu"] = max(worst["lu_vs_emu"], (np.abs(d["lu"][i] - lu_emu) / scale).max())
-        assert (np.abs(d["lu"][i] - lu_emu) / scale).max() <= 1e-13, "factors differ from the emulated kernel programs"
-        assert np.allclose(d["r"][i], r_emu, rtol=1e-13, atol=0)
+        assert np.array_equal(d["lu"][i], lu_emu), "factors differ from the emulated kernel programs (max %.1e of the row maximum)" % (np.abs(d["lu"][i] - lu_emu) / scale).max()
+        assert np.array_equal(d["r"][i], r_emu), "pivot reciprocals differ from the emulated kernel programs"
         # ... and KppDecomp_x itself: the reference's factors, un-scaling the rows the kernel keeps row-scaled
         lu_ref, ier = o.decomp(G)
         assert ier == 0
@@ -132,8 +132,7 @@ def test_phases_of_the_first_step(chem, emu, mech, golden, oracles):
         assert emu.emu_solve_kernel_form(h_emu, P(lu_gpu), P(e2)) == 0
         e3 = np.ascontiguousarray(((fcn + (C31 / H) * k1) + (C32 / H) * k2) + (H * GAMMA[2]) * 0.0)
         assert emu.emu_solve_kernel_form(h_emu, P(lu_gpu), P(e3)) == 0
-        if np.array_equal(d["lu"][i], lu_emu):          # (the forward-swept stage-1 vector is the emulator's: exact only on identical factors)
-            assert np.array_equal(k1, e1), "K1 differs from the emulated solve programs"
+        assert np.array_equal(k1, e1), "K1 differs from the emulated solve programs"      # (the forward-swept stage-1 vector is the emulator's: its factors are the GPU's, bit for bit — asserted above)
         assert np.array_equal(k2, e2), "K2 differs from the emulated solve programs"
         assert np.array_equal(k3, e3), "K3 differs from the emulated solve programs"
         worst["k_bitwise"] = worst.get("k_bitwise", 0) + 1

@@ -43,23 +43,39 @@ def test_device_rate_constants_match_the_reference(chem, mech):
     assert plain.sum() > 100 and np.array_equal(got[:, plain], want[:, plain])
 
 
-def test_rates_feed_the_integrator_on_the_device(chem, golden, oracles):
-    """Update_RCONST_g -> INTEGRATE_g without the rate constants leaving the GPU: same results as integrating with the
-    reference's RCONST of the same inputs (oracle), same step bookkeeping."""
+@pytest.mark.parametrize("mech", ["gas", "aer", "tot"])
+def test_model_captured_calls_on_the_device(chem, mech):
+    """The env vectors the product's Fortran routine MISTRA_RATES_ENV_x packed INSIDE the running reference model
+    (tests/golden/rates_model_<mech>.npz) through the device evaluator, against the RCONST the reference's Update_RCONST_x left in
+    COMMON /GDATA_x/ for the same layer."""
+    g = np.load(os.path.join(REPO, "tests", "golden", "rates_model_%s.npz" % mech))
+    got, want = chem.update_rconst(mech, g["env"]), g["rconst"]
+    assert np.array_equal(got == 0.0, want == 0.0)
+    nz = want != 0.0
+    rel = np.abs(got[nz] - want[nz]) / np.abs(want[nz])
+    print("%s RCONST of %d model layers on the device: %.1f %% bit-identical, max rel diff %.2e" % (mech, len(want), 100 * float((got[nz] == want[nz]).mean()), rel.max()))
+    assert rel.max() <= 1e-13
+
+
+@pytest.mark.parametrize("mech", ["gas", "aer", "tot"])
+def test_rates_feed_the_integrator_on_the_device(chem, mech, oracles):
+    """Update_RCONST_x -> INTEGRATE_x without the rate constants leaving the GPU, on layers captured from the running model (env,
+    VAR, FIX as they stood at the reference's Update_RCONST_x call): same results as the oracle integrating with the REFERENCE's
+    RCONST of that call, identical step bookkeeping, every layer succeeding."""
     import torch
     dev = torch.device("cuda", 0)
-    g = np.load(os.path.join(REPO, "tests", "golden", "rates_gas.npz"))
-    n = 16
+    g = np.load(os.path.join(REPO, "tests", "golden", "rates_model_%s.npz" % mech))
+    n = min(16, g["env"].shape[0])
     env = torch.tensor(g["env"][:n], device=dev)
-    var, fix = golden["gas"]["var_in"][:n], g["env"][:n, 58:61]          # FIX as Update_RCONST_g saw it
-    rconst = chem.update_rconst("gas", env)
+    var, fix = g["var"][:n], g["fix"][:n]
+    rconst = chem.update_rconst(mech, env)
     assert rconst.is_cuda
-    res = chem.integrate("gas", torch.tensor(var, device=dev), torch.tensor(fix, device=dev), rconst, 0.0, 10.0)
+    res = chem.integrate(mech, torch.tensor(var, device=dev), torch.tensor(fix, device=dev), rconst, 0.0, 10.0)
     torch.cuda.synchronize()
-    want, ierr, st = oracles["gas"].integrate_batch(var, fix, g["rconst"][:n], 0.0, 10.0)
-    assert np.array_equal(res.ierr.cpu().numpy(), ierr)
-    ok = ierr == 1
-    assert ok.sum() >= n // 2
-    assert np.array_equal(res.stats.cpu().numpy()[ok], st[ok])
+    want, ierr, st = oracles[mech].integrate_batch(var, fix, g["rconst"][:n], 0.0, 10.0)
+    assert np.all(ierr == 1) and np.array_equal(res.ierr.cpu().numpy(), ierr)
+    assert np.array_equal(res.stats.cpu().numpy(), st), "/Statistics/ differ"
     floor = 1e-12 * np.abs(want).max(axis=1, keepdims=True)
-    assert (np.abs(res.var.cpu().numpy() - want) / (np.abs(want) + floor))[ok].max() <= 2e-5
+    rel = np.abs(res.var.cpu().numpy() - want) / (np.abs(want) + floor)
+    print("%s: rates -> integrator on the device, %d model layers, max rel diff %.2e, steps %s" % (mech, n, rel.max(), st[:, 2].tolist()))
+    assert rel.max() <= 2e-5

@@ -37,6 +37,30 @@ def test_extracted_rate_table_reproduces_the_reference(mech):
 
 
 @pytest.mark.parametrize("mech", MECHS)
+def test_model_captured_calls(mech):
+    """Update_RCONST_x calls of the RUNNING reference model (tests/golden/rates_model_<mech>.npz, oracle/capture_rates_wrap.c): the
+    inputs were packed inside the model by the product's own Fortran routine MISTRA_RATES_ENV_x (shim/mistra_kpp_rates.f90,
+    generated from the env list), the RCONST are what the reference's Update_RCONST_x made of the same COMMON blocks.  The table +
+    restated rate laws reproduce them bit for bit — which checks the table, the laws AND the Fortran packing in the model's state."""
+    from oracle.rates_py import evaluate
+    path = os.path.join(REPO, "tests", "golden", "rates_model_%s.npz" % mech)
+    g = np.load(path)
+    table, names, fslot, _, _ = _load(mech)
+    slot = {n: i for i, n in enumerate(names)}
+    env, want = g["env"], g["rconst"]
+    assert env.shape[1] == len(names) and env.shape[0] >= 16
+    # the packed vector is consistent with the layer's C = VAR | FIX recorded beside it
+    for i, nm in enumerate(names):
+        if nm.startswith("fix("):
+            assert np.array_equal(env[:, i], g["fix"][:, int(nm[4:-1]) - 1])
+        elif nm.startswith("c("):
+            assert np.array_equal(env[:, i], g["var"][:, int(nm[2:-1]) - 1])
+    for i in range(env.shape[0]):
+        got = evaluate(table, slot, env[i], fslot)
+        assert np.array_equal(got, want[i]), "%s call %d (%s)" % (mech, int(g["callno"][i]), str(g["source"][i]))
+
+
+@pytest.mark.parametrize("mech", MECHS)
 def test_binary_table_matches_json(mech):
     """mistra_amd/mech/<mech>.rates (what the library loads) holds the same programs as the JSON form."""
     import sys

@@ -1,7 +1,8 @@
 """Diagnostic: first-step dumps (mistra_chem_debug_first_step) of two builds of the library, compared bit for bit per section:
-   python tools/diag_compare_dump.py libA.so libB.so [mech] [ncell]       (libraries in mistra_amd/lib/; one process per library)"""
+   python tools/diag_compare_dump.py libA.so libB.so [mech] [ncell]       (libmistra_chem.so = the product, other names in tools/diaglib/; one process per library)"""
 import os, subprocess, sys
-REPO = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import REPO, diag_env
 if len(sys.argv) > 1 and sys.argv[1] == '--child':
     sys.path.insert(0, REPO)
     import numpy as np
@@ -29,7 +30,7 @@ n = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 outs = []
 for lib in (a, b):
     out = '/tmp/dump_%s.npz' % lib
-    env = dict(os.environ, MISTRA_CHEM_LIB=os.path.join(REPO, 'mistra_amd', 'lib', lib))
+    env = diag_env(lib)
     subprocess.run([sys.executable, os.path.abspath(__file__), '--child', mech, str(n), out], check=True, env=env)
     outs.append(np.load(out))
 sys.path.insert(0, REPO)

@@ -1,8 +1,8 @@
 """Diagnostic: where wave 0 spends its cycles inside dense_lu (library built by `tools/diag_dense.sh stamps`)."""
 import ctypes as C, os, sys
-REPO = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
-sys.path.insert(0, REPO)
-os.environ['MISTRA_CHEM_LIB'] = os.path.join(REPO, 'mistra_amd', 'lib', os.environ.get('DIAG_LIB', 'libdiag_stamps.so'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import use_diag_lib
+use_diag_lib(os.environ.get('DIAG_LIB', 'libdiag_stamps.so'))
 import numpy as np
 from mistra_amd import chem
 from mistra_amd.workload import make_batch

@@ -1,7 +1,8 @@
 """Where the LU program's time goes, by rounds: runs the profiling kernel with the LU program cut after n rounds
 (MISTRA_DIAG_LU_ROUNDS, numerically meaningless) and prints LU cycles per LU call.  GPU box: python tools/profile_lu_rounds.py"""
 import os, re, subprocess, sys
-ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import REPO as ROOT, diag_env
 code = r'''
 import os, sys
 sys.path.insert(0, %r)
@@ -14,8 +15,7 @@ res = chem.integrate('tot', var.numpy(), fix.numpy(), rconst.numpy())
 print('NDEC', res.stats[:, 5].mean())
 ''' % ROOT
 for n in [int(x) for x in sys.argv[1:]] or [1, 5, 10, 16, 17, 18, 19, 30, 45, 57, 70, 88, 89]:
-    env = dict(os.environ, MISTRA_DIAG_LU_ROUNDS=str(n),
-               MISTRA_CHEM_LIB=os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'mistra_amd', 'lib', 'libdiag_env.so'))   # tools/diag_dense.sh env
+    env = diag_env('libdiag_env.so', MISTRA_DIAG_LU_ROUNDS=str(n))   # tools/diag_dense.sh env
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
     lu = re.search(r' lu=(\d+)', r.stderr)
     nd = re.search(r'NDEC ([\d.]+)', r.stdout)
