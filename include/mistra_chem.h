@@ -99,6 +99,14 @@ int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tou
 int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, double* tout, int32_t* ierr, double* t_err,
                                         double* h_err, int32_t* nsng);
 
+/* The rows of the zero pivots a cell met: what KppDecomp_x returns in IER — the first row k whose diagonal is exactly zero when the
+ * elimination reaches it (gas.f:6157) — and ros_PrepareMatrix_x prints once per failed decomposition ("Warning: LU Decomposition
+ * returned ising = k", gas.f:1456) before it halves H.  rows8[0 .. min(Nsng, 8)-1] = row numbers (1-based, = species numbers) in
+ * order of occurrence for cell `cell` (0-based index into the batch) of the LAST host-buffer integration of this mechanism
+ * (mistra_chem_integrate[_ex], mistra_chem_integrate_common[_status]); entries past Nsng are undefined.  The rows stay on the
+ * device until asked for: call it only for cells whose statistics report Nsng > 0 (the Fortran shim does, to print the line). */
+int mistra_chem_singular_rows(int mech, int cell, int32_t* rows8);
+
 /* Update_RCONST_x for ncell cells (gas.f:275 | aer.f:304 | tot.f:1040; called by x_drive right before INTEGRATE_x, gas.f:172):
  * rconst[cell][NREACT] from env[cell][mistra_chem_rates_env_size(mech)], the per-cell inputs the generated routine and its
  * rate laws (kpp.f90:7127-8601) read from COMMON /cb_1/, /kpp_rate_x/, /ph_r_x/ and C.  Sizes: gas 74 doubles, aer 330,

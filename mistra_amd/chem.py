@@ -68,6 +68,7 @@ def lib():
         L.mistra_chem_update_rconst.argtypes = [C.c_int, C.c_int, _dp, _dp]
         L.mistra_chem_update_rconst_device.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mistra_chem_integrate_common.argtypes = [C.c_int, C.c_void_p, _dp, _dp]
+        L.mistra_chem_singular_rows.argtypes = [C.c_int, C.c_int, _ip]
         L.mistra_chem_last_error.restype = C.c_char_p
         L.mistra_chem_describe.restype = C.c_char_p
         L.mistra_chem_describe.argtypes = [C.c_int]
@@ -165,6 +166,15 @@ def integrate_ex(mech, var, fix, rconst, tin=0.0, tout=10.0):
                                          float(tin), float(tout), out.ctypes.data_as(_dp), ierr.ctypes.data_as(_ip),
                                          stats.ctypes.data_as(_ip), th.ctypes.data_as(_dp)))
     return IntegrateResult(out, ierr, stats), th
+
+
+def singular_rows(mech, cell):
+    """Rows (1-based) of the zero pivots cell `cell` of the last host-buffer integrate call met (include/mistra_chem.h:
+    mistra_chem_singular_rows); meaningful for the first min(Nsng, 8) entries."""
+    mid, _ = _mech_id(mech)
+    rows = np.zeros(8, np.int32)
+    _check(lib().mistra_chem_singular_rows(mid, int(cell), rows.ctypes.data_as(_ip)))
+    return rows
 
 
 def device_count():

@@ -132,7 +132,12 @@ struct MechState {
   int lu_scale_slots = 0;
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
-  DevBuf<int32_t> s_ierr, s_stats;
+  DevBuf<int32_t> s_ierr, s_stats, s_sing;
+  // where the zero-pivot rows of the LAST host-buffer call of this slot are (mistra_chem_singular_rows): cells [sing_start,
+  // sing_start + sing_count) of the caller's batch in s_sing, or the one cell of the COMMON-block call in one_sing
+  size_t sing_start = 0, sing_count = 0;
+  bool sing_one = false;
+  int32_t one_sing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // one-cell calls (the Fortran shim): one contiguous device block in, one out, pinned host mirrors, a private stream
   double* one_dev = nullptr;      // [C(NSPEC) | RCONST(NREACT)]  then  [VAR out | Texit Hexit | 8 stats + ierr as int32]
   double* one_host = nullptr;
@@ -142,7 +147,8 @@ struct MechState {
     vdot.release(); jvs.release(); lu.release(); solve_head_fwd.release(); solve_head_bwd.release();
     tail_fwd.release(); tail_bwd.release(); lu_scale.release();
     dense_rows.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); rates_fslot.release(); s_env.release(); rates_ready = false;
-    s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release();
+    s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release(); s_sing.release();
+    sing_count = 0; sing_one = false;
     if (one_dev) (void)hipFree(one_dev);
     if (one_host) (void)hipHostFree(one_host);
     if (one_stream) (void)hipStreamDestroy(one_stream);
@@ -268,7 +274,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* th) {
   KernelArgs a;
   a.var_in = var_in; a.fix = fix; a.rconst = rconst; a.var_out = var_out; a.ierr = ierr; a.stats = stats;
-  a.texit_hexit = th; a.h_last = nullptr; a.hstart = nullptr; a.prof = nullptr; a.dump = nullptr; a.n_temps = S.n_temps; a.tin = tin; a.tout = tout; a.ncell = ncell;
+  a.texit_hexit = th; a.h_last = nullptr; a.hstart = nullptr; a.prof = nullptr; a.dump = nullptr; a.sing_rows = nullptr; a.n_temps = S.n_temps; a.tin = tin; a.tout = tout; a.ncell = ncell;
   a.consts = S.consts.p; a.fun_fac = S.fun_fac.p; a.jac_fac = S.jac_fac.p; a.jvs_pos = S.jvs_pos.p;
   a.zero_pos = S.zero_pos.p; a.diag_pos = S.diag_pos.p;
   a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev();
@@ -325,7 +331,7 @@ int init_locked(int n, const int* ids) {
 
 // one device's share of a host-buffer call: upload, integrate, download (synchronous on that device)
 int integrate_host_on(DeviceState& D, int mech, int ncell, const double* var_in, const double* fix, const double* rconst, double tin,
-                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h) {
+                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h, size_t batch_start = 0) {
   HIP_TRY(hipSetDevice(D.id));
   MechState& S = D.mech[mech];
   const size_t nv = (size_t)kDims[mech][0], nf = (size_t)kDims[mech][1], nr = (size_t)kDims[mech][2], nc = (size_t)ncell;
@@ -334,12 +340,15 @@ int integrate_host_on(DeviceState& D, int mech, int ncell, const double* var_in,
   HIP_TRY(S.s_rct.reserve(nc * nr));
   HIP_TRY(S.s_ierr.reserve(nc));
   HIP_TRY(S.s_stats.reserve(nc * 8));
+  HIP_TRY(S.s_sing.reserve(nc * 8));
   if (t_h) HIP_TRY(S.s_th.reserve(nc * 3));
   HIP_TRY(hipMemcpy(S.s_var.p, var_in, nc * nv * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(S.s_fix.p, fix, nc * nf * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(S.s_rct.p, rconst, nc * nr * sizeof(double), hipMemcpyHostToDevice));
   KernelArgs a = make_args(S, ncell, S.s_var.p, S.s_fix.p, S.s_rct.p, tin, tout, S.s_var.p, S.s_ierr.p, S.s_stats.p, t_h ? S.s_th.p : nullptr);
   if (t_h) a.h_last = S.s_th.p + 2 * nc;
+  a.sing_rows = S.s_sing.p;      // stays on the device: fetched by mistra_chem_singular_rows, i.e. only when a cell reports Nsng > 0
+  S.sing_start = batch_start; S.sing_count = nc; S.sing_one = false;
   // diagnostic builds only (-DMISTRA_DIAG_ENV, tools/diag_dense.sh env): MISTRA_CHEM_PROFILE=1 prints where wave 0 of the
   // workgroups spent its cycles (mean over the cells of the call).  The product library does not read the environment here.
   DevBuf<unsigned long long> prof;
@@ -540,6 +549,7 @@ int mistra_chem_integrate_ex(int mech, int ncell, const double* var_in, const do
   std::lock_guard<std::mutex> lock(g_mu);
   const size_t nv = (size_t)kDims[mech][0], nf = (size_t)kDims[mech][1], nr = (size_t)kDims[mech][2];
   const int ndev = (int)g_devs.size();
+  for (auto& d : g_devs) d.mech[mech].sing_count = 0;
   if (ndev == 1 || ncell < 2 * ndev) {
     int rc = integrate_host_on(g_devs[0], mech, ncell, var_in, fix, rconst, tin, tout, var_out, ierr, stats, t_h);
     (void)hipSetDevice(g_devs[0].id);
@@ -556,7 +566,7 @@ int mistra_chem_integrate_ex(int mech, int ncell, const double* var_in, const do
     const int count = per + (d < rem ? 1 : 0);
     workers.emplace_back([=, &rcs, &errs]() {
       rcs[(size_t)d] = integrate_host_on(g_devs[(size_t)d], mech, count, var_in + start * nv, fix + start * nf, rconst + start * nr, tin, tout,
-                                         var_out + start * nv, ierr ? ierr + start : nullptr, stats ? stats + start * 8 : nullptr, t_h ? t_h + start * 3 : nullptr);
+                                         var_out + start * nv, ierr ? ierr + start : nullptr, stats ? stats + start * 8 : nullptr, t_h ? t_h + start * 3 : nullptr, start);
       if (rcs[(size_t)d]) errs[(size_t)d] = g_err;      // g_err is thread-local: carry the text to the caller's thread
     });
   }
@@ -603,7 +613,7 @@ int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, doub
     // stream with a single wait (seven blocking calls before: 340 us per gas call, of which the kernel is a fraction).
     std::lock_guard<std::mutex> lock(g_mu);
     HIP_TRY(hipSetDevice(D.id));
-    const size_t n_in = (size_t)(nv + nf + nr), n_out = (size_t)nv + 2 + 1 + 5;       // VAR | Texit Hexit | H at exit | 9 int32 in 5 doubles
+    const size_t n_in = (size_t)(nv + nf + nr), n_out = (size_t)nv + 2 + 1 + 5 + 4;   // VAR | Texit Hexit | H at exit | 9 int32 in 5 doubles | 8 zero-pivot rows in 4
     if (!S.one_dev) {
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&S.one_dev), (n_in + n_out) * sizeof(double)));
       HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S.one_host), (n_in + n_out) * sizeof(double), hipHostMallocDefault));
@@ -615,6 +625,7 @@ int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, doub
     int32_t* d_stats = reinterpret_cast<int32_t*>(d_out + nv + 3);
     KernelArgs a = make_args(S, 1, S.one_dev, S.one_dev + nv, S.one_dev + nv + nf, *tin, *tout, d_out, d_stats + 8, d_stats, d_out + nv);
     a.h_last = d_out + nv + 2;
+    a.sing_rows = d_stats + 10;
     if (int rc = launch(D, mech, a, S.one_stream)) return rc;
     double* h_out = S.one_host + n_in;
     HIP_TRY(hipMemcpyAsync(h_out, d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, S.one_stream));
@@ -624,6 +635,9 @@ int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, doub
     std::memcpy(&ierr, st + 8, sizeof ierr);
     if (ierr_out) *ierr_out = ierr;
     if (nsng) *nsng = st[7];
+    for (auto& d : g_devs) d.mech[mech].sing_count = 0;
+    std::memcpy(S.one_sing, st + 10, sizeof S.one_sing);
+    S.sing_one = true;
     if (t_err) *t_err = h_out[nv];         // T when the integrator returned
     if (h_err) *h_err = h_out[nv + 2];     // H when the integrator returned (what ros_ErrorMsg_x prints)
     *tin = h_out[nv];          // TIN = RPAR(11), exit time
@@ -632,11 +646,36 @@ int mistra_chem_integrate_common_status(int mech, void* gdata, double* tin, doub
   return 0;
 }
 
+int mistra_chem_singular_rows(int mech, int cell, int32_t* rows8) {
+  if (int rc = check_call(mech, 1)) return rc;
+  if (!rows8 || cell < 0) return fail("bad argument");
+  std::lock_guard<std::mutex> lock(g_mu);
+  for (auto& D : g_devs) {
+    MechState& S = D.mech[mech];
+    if (S.sing_one && cell == 0 && &D == &g_devs[0]) {
+      std::memcpy(rows8, S.one_sing, sizeof S.one_sing);
+      return 0;
+    }
+    if (!S.sing_one && S.sing_count > 0 && (size_t)cell >= S.sing_start && (size_t)cell < S.sing_start + S.sing_count) {
+      HIP_TRY(hipSetDevice(D.id));
+      HIP_TRY(hipMemcpy(rows8, S.s_sing.p + ((size_t)cell - S.sing_start) * 8, 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+      (void)hipSetDevice(g_devs[0].id);
+      return 0;
+    }
+  }
+  return fail("no host-buffer integration of this mechanism holds that cell");
+}
+
 int mistra_chem_integrate_common(int mech, void* gdata, double* tin, double* tout) {
   int32_t ierr = 1, nsng = 0;
   double t_err = 0.0, h_err = 0.0;
   const double tin_in = tin ? *tin : 0.0;
   if (int rc = mistra_chem_integrate_common_status(mech, gdata, tin, tout, &ierr, &t_err, &h_err, &nsng)) return rc;
+  if (nsng > 0) {      // ros_PrepareMatrix_x's warning, one per failed decomposition (gas.f:1456)
+    int32_t rows[8] = {0};
+    (void)mistra_chem_singular_rows(mech, 0, rows);
+    for (int i = 0; i < nsng; i++) std::printf(" Warning: LU Decomposition returned ising =  %d\n", rows[i < 8 ? i : 7]);
+  }
   if (ierr < 0) {   // the reference prints and continues (ros_ErrorMsg_x gas.f:1474-1509, INTEGRATE_x gas.f:764-767);
                     // a Fortran caller gets the same lines from unit 6 through shim/mistra_kpp_shim.f90
     const char sfx = "gat"[mech];

@@ -45,6 +45,8 @@ struct KernelArgs {
   double* texit_hexit;         // [ncell][2] or null: what INTEGRATE_x leaves in TIN and STEPMIN
   const double* hstart;        // [ncell] or null: first step size per cell instead of INTEGRATE_x's 1e-3 (opt-in, not the reference's behaviour)
   double* h_last;              // [ncell] or null: the step size H when the integrator returned (ros_ErrorMsg_x prints it, gas.f:1506)
+  int32_t* sing_rows;          // [ncell][8] or null: rows (1-based) of the zero pivots KppDecomp_x met in this call, in order of occurrence — the
+                               //   IER it returns and ros_PrepareMatrix_x prints (gas.f:6157, 1456); entries past min(Nsng, 8) are not written
   double* dump;                // [ncell][5*NVAR + 2*LU_NONZERO + 2] or null: first-step dump (kernel VARIANT 2): Fcn0 | Ghimj prepared |
                                //   Ghimj factorised (kernel form) | R | K1 | K2 | K3 | Err, H  of the first attempt of the first step
   unsigned long long* prof;    // [ncell][kProfSlots] or null: shader-clock cycles per phase (diagnostics, see capi.cpp)

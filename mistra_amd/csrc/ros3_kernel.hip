@@ -165,8 +165,7 @@ static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots")
 
 // ---- the LDS VM executor (schedule.hpp), hand-scheduled: one asm statement holds the whole program loop; its instruction
 // stream is generated (tools/gen_vm_asm.py -> vm_exec_asm.inc, where the pipeline and the wait counts are explained).
-//   * records land straight in VGPRs: a ring of N 8-register slots in caller-saved blocks (v48-55, v64-71, ...: N = 4 for the
-//     kernels held to 128 registers, 8 for tot), named only inside this statement, so no compiler copy can get between a load
+//   * records land straight in VGPRs: a ring of N 8-register slots in caller-saved blocks (v48-55, v64-71, ...: N = MT::VM_SLOTS), named only inside this statement, so no compiler copy can get between a load
 //     and its counted wait (cdna_hip_programming.md §5.7); a slot is refilled (row + N) behind its record's store;
 //   * d0, d2..d7 of a record are LDS byte addresses as they stand (M starts at LDS address 0, checked at kernel entry);
 //     every mark sits on d1: one v_readfirstlane per record, one scalar test for "any mark" on the main line;
@@ -178,8 +177,9 @@ static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots")
 // The IEEE reciprocal is the sequence hipcc emits for 1.0/x (v_div_scale, v_rcp, two Newton steps, v_div_fmas, v_div_fixup).
 #include "vm_exec_asm.inc"
 
-template <int NT, bool WIDE>
+template <int NT, int SLOTS>
 __device__ __attribute__((noinline)) void vm_run(const VmDev P, int wave, int lane) {
+  static_assert(SLOTS == 4 || SLOTS == 6 || SLOTS == 8, "ring depths vm_exec_asm.inc is generated for");
   const uint64_t recs = reinterpret_cast<uint64_t>(P.recs);      // the same in every lane: move it to SGPRs
   const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs) |
                         ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(recs >> 32)) << 32);
@@ -187,26 +187,23 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev P, int wave, int la
   uint32_t vb = va + 4096u;                                                          // rows +2, +3
   int rounds = __builtin_amdgcn_readfirstlane(P.nrounds);
   double acc, a1A, r1A, u1A, a2A, r2A, u2A, a1B, r1B, u1B, a2B, r2B, u2B, sc;
-  uint32_t ax, t, flA, flB, tmp;
+  uint32_t tg, ax, t, flA, flB, tmp;
   uint64_t sv, sm;
-  if constexpr (WIDE) {
+#define MISTRA_VM_OPERANDS                                                                                                                             \
+  [acc] "=&v"(acc), [a1A] "=&v"(a1A), [r1A] "=&v"(r1A), [u1A] "=&v"(u1A), [a2A] "=&v"(a2A), [r2A] "=&v"(r2A), [u2A] "=&v"(u2A), [a1B] "=&v"(a1B),      \
+      [r1B] "=&v"(r1B), [u1B] "=&v"(u1B), [a2B] "=&v"(a2B), [r2B] "=&v"(r2B), [u2B] "=&v"(u2B), [sc] "=&v"(sc), [tg] "=&v"(tg), [ax] "=&v"(ax),          \
+      [t] "=&v"(t), [flA] "=&s"(flA), [flB] "=&s"(flB), [tmp] "=&s"(tmp), [sv] "=&s"(sv), [sm] "=&s"(sm), [rounds] "+s"(rounds), [va] "+v"(va),         \
+      [vb] "+v"(vb)
+  if constexpr (SLOTS == 8) {
     uint32_t vc = va + 8192u, vd = va + 12288u;                                      // rows +4, +5 and +6, +7
-    asm volatile(MISTRA_VM_ASM_N8
-                 : [acc] "=&v"(acc), [a1A] "=&v"(a1A), [r1A] "=&v"(r1A), [u1A] "=&v"(u1A), [a2A] "=&v"(a2A), [r2A] "=&v"(r2A), [u2A] "=&v"(u2A),
-                   [a1B] "=&v"(a1B), [r1B] "=&v"(r1B), [u1B] "=&v"(u1B), [a2B] "=&v"(a2B), [r2B] "=&v"(r2B), [u2B] "=&v"(u2B),
-                   [sc] "=&v"(sc), [ax] "=&v"(ax), [t] "=&v"(t), [flA] "=&s"(flA), [flB] "=&s"(flB), [tmp] "=&s"(tmp), [sv] "=&s"(sv), [sm] "=&s"(sm),
-                   [va] "+v"(va), [vb] "+v"(vb), [vc] "+v"(vc), [vd] "+v"(vd), [rounds] "+s"(rounds)
-                 : [base] "s"(base)
-                 : "memory", "vcc", "scc", MISTRA_VM_CLOBBER_N8);
+    asm volatile(MISTRA_VM_ASM_N8 : MISTRA_VM_OPERANDS, [vc] "+v"(vc), [vd] "+v"(vd) : [base] "s"(base) : "memory", "vcc", "scc", MISTRA_VM_CLOBBER_N8);
+  } else if constexpr (SLOTS == 6) {
+    uint32_t vc = va + 8192u;
+    asm volatile(MISTRA_VM_ASM_N6 : MISTRA_VM_OPERANDS, [vc] "+v"(vc) : [base] "s"(base) : "memory", "vcc", "scc", MISTRA_VM_CLOBBER_N6);
   } else {
-    asm volatile(MISTRA_VM_ASM_N4
-                 : [acc] "=&v"(acc), [a1A] "=&v"(a1A), [r1A] "=&v"(r1A), [u1A] "=&v"(u1A), [a2A] "=&v"(a2A), [r2A] "=&v"(r2A), [u2A] "=&v"(u2A),
-                   [a1B] "=&v"(a1B), [r1B] "=&v"(r1B), [u1B] "=&v"(u1B), [a2B] "=&v"(a2B), [r2B] "=&v"(r2B), [u2B] "=&v"(u2B),
-                   [sc] "=&v"(sc), [ax] "=&v"(ax), [t] "=&v"(t), [flA] "=&s"(flA), [flB] "=&s"(flB), [tmp] "=&s"(tmp), [sv] "=&s"(sv), [sm] "=&s"(sm),
-                   [va] "+v"(va), [vb] "+v"(vb), [rounds] "+s"(rounds)
-                 : [base] "s"(base)
-                 : "memory", "vcc", "scc", MISTRA_VM_CLOBBER_N4);
+    asm volatile(MISTRA_VM_ASM_N4 : MISTRA_VM_OPERANDS : [base] "s"(base) : "memory", "vcc", "scc", MISTRA_VM_CLOBBER_N4);
   }
+#undef MISTRA_VM_OPERANDS
 }
 
 // ---- tail chain of the triangular solves (schedule.hpp: TailSolve), run by ONE wave: lane l holds rows h+l and
@@ -950,7 +947,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   //      Returns (workgroup-uniform) whether a diagonal is exactly zero, the condition KppDecomp_x tests (gas.f:6157).
   auto prepare = [&](double ghinv, const double (&rhs)[SPT]) -> bool {
     if constexpr (!RESIDENT) load_pos();
-    if (t == 0) flags[0] = 0;
+    if (t == 0) { flags[0] = 0; flags[1] = 0x7fffffff; }
     lds_barrier();   // also: all readers of M from the previous attempt are done
 #pragma unroll
     for (int q = 0; q < SPT; q++) {      // stage-1 right-hand side: the LU program forward-sweeps it while it factorises
@@ -996,7 +993,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       }
       lds_barrier();
       lap(6);
-      vm_run<NT, !MT::RING_LOW>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
+      vm_run<NT, MT::VM_SLOTS>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
       lap(8);
       if (wave == 0)                                                                         // tail chain, one wave
         tail_solve<MT::TAIL_REGS, 0, MT::RING_LOW, kDenseInfo, kZeroCell>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
@@ -1007,7 +1004,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     }
     lds_barrier();
     lap(9);
-    vm_run<NT, !MT::RING_LOW>(a.solve_head_bwd, wave, lane);
+    vm_run<NT, MT::VM_SLOTS>(a.solve_head_bwd, wave, lane);
     lap(10);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
@@ -1094,13 +1091,22 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
           ndec += 1;
           lap(2);
           if (singular) {
-            lds_barrier();   // everyone has read flags[0] before the retry clears it
+            // which row: KppDecomp_x returns the FIRST row whose diagonal is exactly zero as it reaches it (IER = k, gas.f:6157 — rows are
+            // untouched until their own turn, so the test sees the prepared value); ros_PrepareMatrix_x prints it (gas.f:1456).  Rare
+            // path: Ghimj is still as prepared (no LU ran), every species' thread looks at its diagonal slot.
+            if (a.sing_rows && nsng < 8) {
+              const uint32_t dp = t < NVAR ? (uint32_t)G_(a.diag_pos)[t] : (uint32_t)kPosNone;
+              if (dp != kPosNone && M[dp] == 0.0) atomicMin(&flags[1], t + 1);
+              lds_barrier();
+              if (t == 0) GM_(a.sing_rows)[(size_t)cell * 8 + nsng] = flags[1];
+            }
+            lds_barrier();   // everyone has read flags[0] (and flags[1]) before the retry clears them
             nsng += 1;
             nconsecutive += 1;
             if (nconsecutive <= 5) H = wave_uniform(H * 0.5);
             else { ierr = -8; break; }
           } else {
-            vm_run<NT, !MT::RING_LOW>(a.lu, wave, lane);
+            vm_run<NT, MT::VM_SLOTS>(a.lu, wave, lane);
             if constexpr (MT::SCALE_PASS) {      // else the scaling is the LU program's last round
               lap(3);
               scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);      // L(k,j) *= R(j); tail block: U(i,c) *= R(i)

@@ -29,14 +29,17 @@ namespace mistra {
 #ifndef MISTRA_AER_WPS
 #define MISTRA_AER_WPS 4
 #endif
+#ifndef MISTRA_TOT_VM_SLOTS          // ring depth of the LDS VM executor (table rows in flight per lane): 4, 6 or 8 slots of 8 registers from v48 up
+#define MISTRA_TOT_VM_SLOTS 4        // (the kernels held to 128 registers have room for 4)
+#endif
 #ifndef MISTRA_RESIDENT_MAX_WPS      // kernels with more waves per SIMD than this fetch their static per-thread words where they are used (ros3_kernel.hip)
 #define MISTRA_RESIDENT_MAX_WPS 3
 #endif
 constexpr int kGasNT = MISTRA_GAS_NT, kAerNT = MISTRA_AER_NT, kTotNT = MISTRA_TOT_NT;
 
-struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 16, WAVES_PER_SIMD = MISTRA_GAS_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
-struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2, MAX_TEMPS = 192, WAVES_PER_SIMD = MISTRA_AER_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; };
-struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2, MAX_TEMPS = 768, WAVES_PER_SIMD = 2, DENSE_ND = 64, DENSE_KB = 14; static constexpr bool RING_LOW = false, SCALE_PASS = true; };
+struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 16, WAVES_PER_SIMD = MISTRA_GAS_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; static constexpr int VM_SLOTS = 4; };
+struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2, MAX_TEMPS = 192, WAVES_PER_SIMD = MISTRA_AER_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; static constexpr int VM_SLOTS = 4; };
+struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2, MAX_TEMPS = 768, WAVES_PER_SIMD = 2, DENSE_ND = 64, DENSE_KB = 14; static constexpr bool RING_LOW = false, SCALE_PASS = true; static constexpr int VM_SLOTS = MISTRA_TOT_VM_SLOTS; };
 
 constexpr int round_up2(int x) { return (x + 1) & ~1; }
 constexpr int max_i(int a, int b) { return a > b ? a : b; }

@@ -12,9 +12,8 @@
 ! link-time alternative that needs no source edit).  Behaviour kept from the reference: VAR is advanced in place,
 ! TIN returns the exit time, STEPMIN the last step, RTOL/ATOL are (re)set to 1e-3 / 1e-25, an unsuccessful
 ! integration writes the lines of ros_ErrorMsg_x (gas.f:1474-1509) and of INTEGRATE_x (gas.f:764-767) to unit 6 and the
-! model carries on.  Not reproduced: the 'Warning: LU Decomposition returned ising =' line of ros_PrepareMatrix_x
-! (gas.f:1456) names the row of the zero pivot, which the kernel does not report; the shim prints the line once per
-! occurrence without the row.
+! model carries on; so does ros_PrepareMatrix_x's 'Warning: LU Decomposition returned ising =' line with the row of the zero
+! pivot (gas.f:1456; the kernel records the rows, mistra_chem_singular_rows hands them out), once per failed decomposition.
 module mistra_chem_c_api
   use iso_c_binding
   implicit none
@@ -43,6 +42,12 @@ module mistra_chem_c_api
        type(c_ptr), value :: device_ids
        integer(c_int) :: rc
      end function mistra_chem_init_devices
+     function mistra_chem_singular_rows(mech, cell, rows8) bind(C, name="mistra_chem_singular_rows") result(rc)
+       import :: c_int, c_int32_t
+       integer(c_int), value :: mech, cell
+       integer(c_int32_t) :: rows8(8)
+       integer(c_int) :: rc
+     end function mistra_chem_singular_rows
      function mistra_chem_last_error() bind(C, name="mistra_chem_last_error") result(msg)
        import :: c_ptr
        type(c_ptr) :: msg
@@ -72,14 +77,20 @@ contains
 
   ! The reference's messages for an unsuccessful integration, statement by statement: ros_ErrorMsg_x (gas.f:1474-1509)
   ! and the PRINT of INTEGRATE_x (gas.f:764-767).  sfx = 'g' | 'a' | 't'.
-  subroutine mistra_chem_report(sfx, code, t, h, tin, nsng)
+  ! mech, cell (0-based index into the last batch): where the rows of the zero pivots are asked for
+  subroutine mistra_chem_report(sfx, code, t, h, tin, nsng, mech, cell)
     character(len=1), intent(in) :: sfx
-    integer, intent(in) :: code, nsng
+    integer, intent(in) :: code, nsng, mech, cell
     double precision, intent(in) :: t, h, tin
     integer :: i
-    do i = 1, nsng
-       print *, 'Warning: LU Decomposition returned ising /= 0'
-    end do
+    integer(c_int32_t) :: rows(8)
+    if (nsng > 0) then
+       rows = 0
+       if (mistra_chem_singular_rows(int(mech, c_int), int(cell, c_int), rows) /= 0) call mistra_chem_fail('mistra_chem_singular_rows')
+       do i = 1, nsng       ! (the kernel keeps the first eight rows of a call; a ninth failed decomposition repeats the eighth)
+          print *, 'Warning: LU Decomposition returned ising = ', int(rows(min(i, 8)))
+       end do
+    end if
     if (code >= 0) return
     write (6, *) 'Forced exit from Rosenbrock_'//sfx//' due to the following error:'
     if (code == -1) then
@@ -118,7 +129,7 @@ contains
     tin_in = TIN
     if (mistra_chem_integrate_common_status(int(mech, c_int), gdata, TIN, TOUT, ierr, t_err, h_err, nsng) /= 0) &
          call mistra_chem_fail('INTEGRATE_'//sfx)
-    if (ierr < 0 .or. nsng > 0) call mistra_chem_report(sfx, int(ierr), t_err, h_err, tin_in, int(nsng))
+    if (ierr < 0 .or. nsng > 0) call mistra_chem_report(sfx, int(ierr), t_err, h_err, tin_in, int(nsng), mech, 0)
   end subroutine integrate_one
 
   subroutine integrate_batch(mech, sfx, NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
@@ -136,7 +147,7 @@ contains
     do k = 1, NCELL            ! the messages in layer order, as the serial loop would have written them
        TEXIT(k) = th(1, k)
        HEXIT(k) = th(2, k)
-       if (IERR(k) < 0 .or. ISTAT(8, k) > 0) call mistra_chem_report(sfx, int(IERR(k)), th(1, k), th(3, k), TIN, int(ISTAT(8, k)))
+       if (IERR(k) < 0 .or. ISTAT(8, k) > 0) call mistra_chem_report(sfx, int(IERR(k)), th(1, k), th(3, k), TIN, int(ISTAT(8, k)), mech, k - 1)
     end do
     deallocate (th)
   end subroutine integrate_batch

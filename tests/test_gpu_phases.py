@@ -192,6 +192,12 @@ def test_zero_pivot_paths(chem, mech, golden, oracles):
         assert np.array_equal(res.stats, st), (res.stats, st)
         assert int(st[0, 7]) == (1 if nzero == 1 else 6)                       # Nsng
         assert np.allclose(res.var, want, rtol=1e-9, atol=1e-300)
+        # the row KppDecomp_x reports (IER = first row with an exactly zero diagonal, gas.f:6157) and ros_PrepareMatrix_x prints
+        # (gas.f:1456): at H/2**i the loss of species losses[i] cancels 1/(H*gamma)
+        rows = chem.singular_rows(mech, 0)
+        assert list(rows[:nzero]) == [losses[i][1] + 1 for i in range(nzero)], rows
+        _, ier = o.decomp(G)
+        assert ier == rows[0]
     print(mech, "zero-pivot paths: Nsng = 1 continues, six in a row end with IERR = -8; statistics identical to the oracle's")
 
 

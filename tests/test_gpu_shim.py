@@ -64,6 +64,26 @@ def test_fortran_prints_the_reference_messages_on_failure(golden, tmp_path):
     assert rel_diff(out[1:, :102], g["var_out"][1:2]).max() <= 2e-5      # the second cell is integrated as if nothing had happened
 
 
+@needs_flang
+def test_fortran_prints_the_zero_pivot_row(golden, tmp_path):
+    """ros_PrepareMatrix_x's "Warning: LU Decomposition returned ising = <row>" (gas.f:1456) from the Fortran shim, with the row
+    KppDecomp_x would return (gas.f:6157): a first-order loss with rate constant -1/(Hstart*gamma) puts an exact zero on that
+    species' diagonal at the first attempt; H is halved and the integration goes on."""
+    from mistra_amd.mechtab import load
+    from test_gpu_phases import GAMMA, _first_order_losses
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "shim")], check=True)
+    t, g = load("gas"), golden["gas"]
+    r, s = _first_order_losses(t)[0]
+    K = np.zeros((1, t.nreact))
+    K[0, r] = -1.0 / (1.0e-3 * GAMMA[0])
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    _write_cells(fin, g["var_in"][:1], g["fix"][:1], K)
+    out = subprocess.run([DRIVER, "g", str(fin), str(fout)], check=True, timeout=300, capture_output=True, text=True).stdout
+    m = re.search(r"Warning: LU Decomposition returned ising =\s+(\d+)", out)
+    assert m, out
+    assert int(m.group(1)) == s + 1
+
+
 def _column(name):
     return dict(np.load(os.path.join(REPO, "tests", "golden", "column_%s.npz" % name)))
 

@@ -28,7 +28,7 @@ OUT = os.path.join(HERE, "..", "mistra_amd", "csrc", "vm_exec_asm.inc")
 
 # ring slots: 8-register blocks that are CALLER-saved in the AMDGPU calling convention (v0-39, then every other block of
 # 8: 48-55, 64-71, ...), so the non-inlined executor has nothing to save; the kernels held to 128 registers stop at v103
-BLOCKS = {4: [48, 64, 80, 96], 8: [48, 64, 80, 96, 112, 128, 144, 160]}
+BLOCKS = {4: [48, 64, 80, 96], 6: [48, 64, 80, 96, 112, 128], 8: [48, 64, 80, 96, 112, 128, 144, 160]}
 # table address registers: one per pair of slots (13-bit signed immediate offsets reach 2 rows of 2048 bytes)
 BASES = ["%[va]", "%[vb]", "%[vc]", "%[vd]"]
 
@@ -115,14 +115,15 @@ def variant(n):
         emit("s_and_b32 %%[tmp], %%[fl%s], 0x7000000" % p)       # any mark (end of round, null row, aux operand)?
         emit("s_cbranch_scc1 Lvm_slow%d_%%=" % s)
         emit("ds_read_b64 %%[acc], %s" % d(s, 0))
+        emit("v_mov_b32 %%[tg], %s" % d(s, 0))
         emit("s_waitcnt vmcnt(%d)" % vm_next)
         prefetch(t, q)
+        refill(s)                         # the slot's registers are free: its gathers have been issued, the target address copied
         emit("s_waitcnt lgkmcnt(7)")      # this record's operands (and the lane's previous store) are back
         muls(p)
         emit("s_waitcnt lgkmcnt(6)")      # ... and its target
         adds(p)
-        emit("ds_write_b64 %s, %%[acc]" % d(s, 0))
-        refill(s)
+        emit("ds_write_b64 %[tg], %[acc]")
         if t == 0:
             emit("Lvm_wrap_%=:")
             for b in range(n // 2):
@@ -184,7 +185,7 @@ def variant(n):
 
 def render():
     out = ["// GENERATED by tools/gen_vm_asm.py — do not edit.  Instruction stream of the LDS VM executor (ros3_kernel.hip: vm_run).", ""]
-    for n in (4, 8):
+    for n in (4, 6, 8):
         lines, clob = variant(n)
         out.append("#define MISTRA_VM_ASM_N%d \\" % n)
         for i, ln in enumerate(lines):
