@@ -120,6 +120,56 @@ int mistra_chem_rates_env_size(int mech);
 int mistra_chem_update_rconst(int mech, int ncell, const double* env, double* rconst);
 int mistra_chem_update_rconst_device(int mech, int ncell, const double* d_env, double* d_rconst, void* hip_stream);
 
+/* ---- The hand-over halves of the per-layer drivers on the device: what gas_drive / aer_drive / tot_drive
+ * (gas.f:60-217 | aer.f:59-246 | tot.f:59-982, with aer_mk.dat / aer_km.dat) do around Update_RCONST_x + INTEGRATE_x, for a batch of
+ * layers ("cells") whose data stay in HBM.  Per layer k, cell-major:
+ *   s1 [j1], s3 [j5]          s1(1:j1,k), s3(1:j5,k) of module gas_common (non-radical / radical gases)
+ *   sl1 [nkc][j2]             sl1(1:j2,1:nkc,k) of COMMON /blck17/ (the layer's Fortran slab as it stands in memory), j2 = 121, nkc = 4
+ *   sion1 [nkc][j6]           sion1(1:j6,1:nkc,k), j6 = 55
+ *   scal [6]                  air, h2o, cvv1..cvv4 (the drivers' arguments; gas reads the first two, aer the first four)
+ *   var [NVAR], fix [NFIX]    C = VAR | FIX of COMMON /GDATA_x/
+ *   bg [NREACT][2]            bg(1:2,1:NREACT,kl) of COMMON /budg/ (bud_x.f): [..][0] instantaneous rate, [..][1] += dt * rate
+ *   bgs [122][2]              bgs(1:2,1:122,k) of COMMON /budgs/ (bud_s_x.f); slots the mechanism does not set are left alone
+ * Everything is index work and plain products in the reference's operation order: bit-identical results.
+ *
+ * mistra_chem_set_species_maps: the model's species index maps (module gas_common, built once by mk_interface, utils.f90:82-140, from
+ * the user's species lists) for one mechanism: gas_m2k [j1][2] = gas_m2k_x(1:2,j) (C index, s1 index), gas_k2m [j1] = gas_k2m_x(j)
+ * (C index of s1(j)), rad_* likewise for s3; 1-based as the Fortran holds them.  Host arrays; call once after init.
+ * mistra_chem_drive_dims: j2, j6, nkc (global_params.f90:96-103) and the slot count of bgs.  Any pointer may be NULL. */
+int mistra_chem_set_species_maps(int mech, int j1, const int32_t* gas_m2k, const int32_t* gas_k2m, int j5,
+                                 const int32_t* rad_m2k, const int32_t* rad_k2m);
+int mistra_chem_drive_dims(int mech, int* j2, int* j6, int* nkc, int* nbgs);
+
+/* x_drive up to (not including) Update_RCONST_x (gas.f:132-167 | aer.f:152-214 | tot.f:212-599): C <- s1, s3 through the maps, FIX
+ * from air / h2o / cvv, the liquid-phase species from sl1 / sion1 — which aer_drive and tot_drive first clamp to >= 0 IN PLACE
+ * (tot.f:226-227), so d_sl1 / d_sion1 are in/out.  Entries of VAR that the driver does not set (KPP's dummy products) keep what
+ * d_var holds, as COMMON /GDATA_x/ does in the reference.  Asynchronous on hip_stream. */
+int mistra_chem_pack_device(int mech, int ncell, const double* d_s1, const double* d_s3, double* d_sl1, double* d_sion1,
+                            const double* d_scal, double* d_var, double* d_fix, void* hip_stream);
+
+/* The concentrations Update_RCONST_x reads (C(ind_Hplz), FIX(..) ...: the `c(i)` / `fix(i)` entries of the rate evaluator's input
+ * vector, mistra_amd/mech/<mech>.rates_env.json) copied from the packed C into d_env [ncell][rates_env_size]; the other entries
+ * (/cb_1/, /kpp_rate_x/, ph_rat: MISTRA_RATES_ENV_x of shim/mistra_kpp_rates.f90) are the caller's. */
+int mistra_chem_rates_env_from_c_device(int mech, int ncell, const double* d_var, const double* d_fix, double* d_env, void* hip_stream);
+
+/* bud_x (bud_g.f | bud_a.f | bud_t.f: every reaction's rate RCONST(i) * reactants, called by x_drive for the layers in il(1:nlev),
+ * gas.f:179-184) and bud_s_x (bud_s_g.f | ..: the selected sulphur / DMS rates, every layer, gas.f:187) on the state the integration
+ * left.  d_bg or d_bgs may be NULL (a caller passes to d_bg only the layers that are budget levels). */
+int mistra_chem_budgets_device(int mech, int ncell, const double* d_var, const double* d_fix, const double* d_rconst, double dt,
+                               double* d_bg, double* d_bgs, void* hip_stream);
+
+/* The hand-over after the integration (gas.f:189-215 | aer.f:229-244 | tot.f:619-982): s1, s3 through the inverse maps, sl1 / sion1
+ * from the liquid-phase species. */
+int mistra_chem_unpack_device(int mech, int ncell, const double* d_var, double* d_s1, double* d_s3, double* d_sl1, double* d_sion1,
+                              void* hip_stream);
+
+/* One x_drive per layer for a batch of layers without anything but the model arrays crossing PCIe: pack -> env <- C -> Update_RCONST_x
+ * -> INTEGRATE_x(tin, tin + dt) -> budgets -> hand-over, all on hip_stream.  d_env: the rate evaluator's input with the caller's
+ * part filled in.  d_bg / d_bgs / d_texit_hexit may be NULL. */
+int mistra_chem_drive_device(int mech, int ncell, double* d_s1, double* d_s3, double* d_sl1, double* d_sion1, const double* d_scal,
+                             double* d_env, double* d_var, double* d_fix, double tin, double dt, int32_t* d_ierr, int32_t* d_stats,
+                             double* d_texit_hexit, double* d_bg, double* d_bgs, void* hip_stream);
+
 /* Diagnostics for the phase-level parity tests: integrates the cells like mistra_chem_integrate (results discarded) with the
  * kernel variant that writes out, per cell, the intermediate results of the FIRST attempt of the first Rosenbrock step
  * (gas.f:1201-1262): dump[cell][5*NVAR + 2*LU_NONZERO + 2] = Fcn0 (Fun_x) | Ghimj as ros_PrepareMatrix_x builds it | Ghimj

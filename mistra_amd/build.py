@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libmistra_chem.so")
 ARCH = "gfx950"
 # -ffp-contract=off: one rounding per multiply and per add, as in the reference built without FMA contraction
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-SOURCES = ["mech_tables.cpp", "schedule.cpp", "capi.cpp", "ros3_kernel.hip", "rates.hip"]
+SOURCES = ["mech_tables.cpp", "schedule.cpp", "capi.cpp", "ros3_kernel.hip", "rates.hip", "pack.hip"]
 
 
 def hipcc():
@@ -99,7 +99,7 @@ def ring_register_report(isa_path=None):
                 for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", l):
                     hi = max(hi, int(m.group(1) or m.group(3)))
         report[name] = hi
-        low = re.search(r"(gsum_run|tail_solve|scale_run)I.*Lb([01])E+[A-Z]", name)       # last template argument: ring placement LOW
+        low = re.search(r"(gsum_run|tail_solve|tail_solve_columns|scale_run)I.*Lb([01])E+[A-Z]", name)       # last template argument: ring placement LOW
         if low:
             limit = 64 if low.group(2) == "1" else 192
             if hi >= limit:

@@ -17,6 +17,7 @@
 
 #include "kernel_args.hpp"
 #include "mech_tables.hpp"
+#include "pack.hpp"
 #include "rates.hpp"
 #include "ros3_kernel.hpp"
 #include "schedule.hpp"
@@ -82,6 +83,23 @@ bool mistra::RatesTable::load(const std::string& path, std::string* err) {
   return ok;
 }
 
+bool mistra::PackTable::load(const std::string& path, std::string* err) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) { if (err) *err = "cannot open " + path; return false; }
+  int32_t h[16];
+  bool ok = std::fread(h, sizeof h, 1, f) == 1 && h[0] == 0x4B41504B && h[1] == 1;
+  auto rd = [&](std::vector<int32_t>& v, size_t n) { v.resize(n); return n == 0 || std::fread(v.data(), 4, n, f) == n; };
+  if (ok) {
+    nvar = h[2]; nfix = h[3]; j2 = h[4]; j6 = h[5]; nkc = h[6]; preclamp = h[7];
+    ok = rd(pack, (size_t)h[8] * 4) && rd(fix, (size_t)h[9] * 3) && rd(unpack, (size_t)h[10] * 4) && rd(slot_id, (size_t)h[11]) &&
+         rd(slot_first, (size_t)h[11] + 1) && rd(terms, (size_t)h[12] * 3) && rd(term_words, (size_t)h[13]) && rd(acc, (size_t)h[14] * 2) &&
+         rd(envc, (size_t)h[15] * 2);
+  }
+  std::fclose(f);
+  if (!ok && err) *err = path + ": not a hand-over table";
+  return ok;
+}
+
 namespace {
 
 struct VmBufs {
@@ -124,12 +142,20 @@ struct MechState {
   VmBufs lu, solve_head_fwd, solve_head_bwd;
   DevBuf<uint32_t> tail_fwd, tail_bwd, lu_scale;
   DevBuf<uint32_t> dense_rows;
+  DevBuf<uint16_t> schur_cells;
   // Update_RCONST_x on the device (rates.hip): present for the mechanisms whose table and rate-law functions exist
   bool rates_ready = false;
   int rates_nenv = 0;
   DevBuf<double> rates_consts, s_env;
   DevBuf<int32_t> rates_offs, rates_words, rates_fslot;
   int lu_scale_slots = 0;
+  // the hand-over halves of x_drive on the device (pack.hip): tables of the mechanism + the model's species maps
+  bool pack_ready = false, maps_ready = false;
+  PackTable pack_tab;
+  DevBuf<int32_t> pk_pack, pk_fix, pk_unpack, pk_slot_id, pk_slot_first, pk_terms, pk_words, pk_acc, pk_envc, pk_aptr, pk_afac;
+  DevBuf<int32_t> map_gas_m2k, map_gas_k2m, map_rad_m2k, map_rad_k2m;
+  int map_j1 = 0, map_j5 = 0;
+  DevBuf<double> d_env, d_rct;      // scratch of mistra_chem_drive_device (grow-only)
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
   DevBuf<int32_t> s_ierr, s_stats, s_sing;
@@ -146,7 +172,10 @@ struct MechState {
     consts.release(); fun_fac.release(); jac_fac.release(); jvs_pos.release(); zero_pos.release(); diag_pos.release();
     vdot.release(); jvs.release(); lu.release(); solve_head_fwd.release(); solve_head_bwd.release();
     tail_fwd.release(); tail_bwd.release(); lu_scale.release();
-    dense_rows.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); rates_fslot.release(); s_env.release(); rates_ready = false;
+    pk_pack.release(); pk_fix.release(); pk_unpack.release(); pk_slot_id.release(); pk_slot_first.release(); pk_terms.release(); pk_words.release();
+    pk_acc.release(); pk_envc.release(); pk_aptr.release(); pk_afac.release(); map_gas_m2k.release(); map_gas_k2m.release(); map_rad_m2k.release();
+    map_rad_k2m.release(); d_env.release(); d_rct.release(); pack_ready = maps_ready = false;
+    dense_rows.release(); schur_cells.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); rates_fslot.release(); s_env.release(); rates_ready = false;
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release(); s_sing.release();
     sing_count = 0; sing_one = false;
     if (one_dev) (void)hipFree(one_dev);
@@ -243,6 +272,7 @@ int setup_mech(DeviceState& D, int mech) {
   HIP_TRY(S.tail_bwd.upload(K.tail.bwd));
   HIP_TRY(S.lu_scale.upload(K.lu_scale.recs));
   HIP_TRY(S.dense_rows.upload(K.dense.row_info));
+  HIP_TRY(S.schur_cells.upload(K.dense.schur_cells));
   {   // optional: the rate table (gas today)
     RatesTable T;
     std::string rerr;
@@ -254,6 +284,20 @@ int setup_mech(DeviceState& D, int mech) {
       HIP_TRY(S.rates_fslot.upload(T.fslot));
       S.rates_nenv = T.nenv;
       S.rates_ready = true;
+    }
+  }
+  {   // the drivers' hand-over tables
+    std::string perr;
+    if (S.pack_tab.load(mech_dir() + "/" + kMechName[mech] + ".pack", &perr)) {
+      const PackTable& T = S.pack_tab;
+      if (T.nvar != S.tab.nvar || T.nfix != S.tab.nfix) return fail(std::string(kMechName[mech]) + ".pack does not belong to this mechanism");
+      for (int32_t w : T.term_words)
+        if (w < 0 || w >= T.nvar) return fail(std::string(kMechName[mech]) + ".pack: a budget term reads a fixed species");
+      HIP_TRY(S.pk_pack.upload(T.pack)); HIP_TRY(S.pk_fix.upload(T.fix)); HIP_TRY(S.pk_unpack.upload(T.unpack));
+      HIP_TRY(S.pk_slot_id.upload(T.slot_id)); HIP_TRY(S.pk_slot_first.upload(T.slot_first)); HIP_TRY(S.pk_terms.upload(T.terms));
+      HIP_TRY(S.pk_words.upload(T.term_words)); HIP_TRY(S.pk_acc.upload(T.acc)); HIP_TRY(S.pk_envc.upload(T.envc));
+      HIP_TRY(S.pk_aptr.upload(S.tab.a_ptr)); HIP_TRY(S.pk_afac.upload(S.tab.a_fac));
+      S.pack_ready = true;
     }
   }
   S.lu_scale_slots = K.lu_scale.nslots;
@@ -285,7 +329,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
   a.solve_head_fwd = S.solve_head_fwd.dev(); a.solve_head_bwd = S.solve_head_bwd.dev();
   a.tail = TailDev{S.tail_fwd.p, S.tail_bwd.p};
   a.lu_scale = ScaleDev{S.lu_scale.p, S.lu_scale_slots, S.lu_scale_slots + VM_LOOKAHEAD_ROWS};
-  a.dense = DenseDev{S.dense_rows.p};
+  a.dense = DenseDev{S.dense_rows.p, S.schur_cells.p};
   return a;
 }
 
@@ -492,6 +536,139 @@ int mistra_chem_update_rconst(int mech, int ncell, const double* env, double* rc
   if (int rc = mistra_chem_update_rconst_device(mech, ncell, S.s_env.p, S.s_rct.p, nullptr)) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(rconst, S.s_rct.p, nc * nr * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- the hand-over halves of x_drive (pack.hip)
+static int pack_dev(int mech, const void* any_device_ptr, DeviceState** Dout, PackDev* P) {
+  if (int rc = check_call(mech, 1)) return rc;
+  hipPointerAttribute_t attr;
+  if (!any_device_ptr || hipPointerGetAttributes(&attr, any_device_ptr) != hipSuccess) return fail("not a device pointer");
+  DeviceState* D = device_slot(attr.device);
+  if (!D) return fail("the buffers live on a device mistra_chem_init(_devices) did not set up");
+  MechState& S = D->mech[mech];
+  if (!S.pack_ready) return fail(std::string("no hand-over table for the ") + kMechName[mech] + " mechanism");
+  if (!S.maps_ready) return fail("mistra_chem_set_species_maps has not been called for this mechanism");
+  HIP_TRY(hipSetDevice(D->id));
+  const PackTable& T = S.pack_tab;
+  *P = PackDev{S.pk_pack.p, S.pk_fix.p, S.pk_unpack.p, S.pk_slot_id.p, S.pk_slot_first.p, S.pk_terms.p, S.pk_words.p, S.pk_acc.p, S.pk_envc.p,
+               T.n_pack(), T.n_fix(), T.n_unpack(), T.n_slots(), (int)T.terms.size() / 3, (int)T.term_words.size(), (int)T.acc.size() / 2, T.n_envc(),
+               T.nvar, T.nfix, S.tab.nreact, T.j2, T.j6, T.nkc, T.preclamp,
+               S.map_gas_m2k.p, S.map_gas_k2m.p, S.map_rad_m2k.p, S.map_rad_k2m.p, S.map_j1, S.map_j5, S.pk_aptr.p, S.pk_afac.p, S.consts.p};
+  *Dout = D;
+  return 0;
+}
+#define LAUNCH_TRY(expr)                                                                                 \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e_));          \
+  } while (0)
+
+int mistra_chem_drive_dims(int mech, int* j2, int* j6, int* nkc, int* nbgs) {
+  if (int rc = check_call(mech, 1)) return rc;
+  const MechState& S = g_devs[0].mech[mech];
+  if (!S.pack_ready) return fail(std::string("no hand-over table for the ") + kMechName[mech] + " mechanism");
+  if (j2) *j2 = S.pack_tab.j2;
+  if (j6) *j6 = S.pack_tab.j6;
+  if (nkc) *nkc = S.pack_tab.nkc;
+  if (nbgs) *nbgs = kBudSlots;
+  return 0;
+}
+
+int mistra_chem_set_species_maps(int mech, int j1, const int32_t* gas_m2k, const int32_t* gas_k2m, int j5, const int32_t* rad_m2k,
+                                 const int32_t* rad_k2m) {
+  if (int rc = lazy_init()) return rc;
+  if (int rc = check_call(mech, 1)) return rc;
+  if (j1 < 0 || j5 < 0 || (j1 > 0 && (!gas_m2k || !gas_k2m)) || (j5 > 0 && (!rad_m2k || !rad_k2m))) return fail("bad species maps");
+  const int nvar = kDims[mech][0];
+  std::lock_guard<std::mutex> lock(g_mu);
+  // what the kernels rely on: every map entry names a VARIABLE species, and no species is written twice by the pack (neither by two
+  // map entries nor by a map entry and one of the driver's explicit liquid-phase assignments): the reference assigns in sequence
+  // and the later one wins, the kernel assigns in parallel
+  std::vector<char> seen((size_t)nvar, 0);
+  for (int j = 0; j < j1 + j5; j++) {
+    const int32_t* m = j < j1 ? gas_m2k + 2 * j : rad_m2k + 2 * (j - j1);
+    const int c = m[0], src = m[1], lim = j < j1 ? j1 : j5;
+    if (c < 1 || c > nvar || src < 1 || src > lim) return fail("species map entry out of range");
+    if (seen[(size_t)c - 1]++) return fail("a species is mapped twice");
+    const int back = j < j1 ? gas_k2m[src - 1] : rad_k2m[src - 1];
+    if (back != c) return fail("gas_m2k / gas_k2m (rad_m2k / rad_k2m) are not inverse to each other");
+  }
+  for (auto& D : g_devs) {
+    MechState& S = D.mech[mech];
+    if (!S.pack_ready) return fail(std::string("no hand-over table for the ") + kMechName[mech] + " mechanism");
+    for (int i = 0; i < S.pack_tab.n_pack(); i++) {
+      const int c0 = S.pack_tab.pack[(size_t)4 * i];
+      if (c0 < nvar && seen[(size_t)c0]) return fail("a species of the gas maps is also packed from sl1 / sion1");
+    }
+    HIP_TRY(hipSetDevice(D.id));
+    HIP_TRY(S.map_gas_m2k.upload(std::vector<int32_t>(gas_m2k, gas_m2k + 2 * (size_t)j1)));
+    HIP_TRY(S.map_gas_k2m.upload(std::vector<int32_t>(gas_k2m, gas_k2m + (size_t)j1)));
+    HIP_TRY(S.map_rad_m2k.upload(std::vector<int32_t>(rad_m2k, rad_m2k + 2 * (size_t)j5)));
+    HIP_TRY(S.map_rad_k2m.upload(std::vector<int32_t>(rad_k2m, rad_k2m + (size_t)j5)));
+    S.map_j1 = j1; S.map_j5 = j5;
+    S.maps_ready = true;
+  }
+  (void)hipSetDevice(g_devs[0].id);
+  return 0;
+}
+
+int mistra_chem_pack_device(int mech, int ncell, const double* d_s1, const double* d_s3, double* d_sl1, double* d_sion1, const double* d_scal,
+                            double* d_var, double* d_fix, void* hip_stream) {
+  if (ncell == 0) return 0;
+  if (!d_s1 || !d_s3 || !d_sl1 || !d_sion1 || !d_scal || !d_var || !d_fix) return fail("null device pointer");
+  DeviceState* D; PackDev P;
+  if (int rc = pack_dev(mech, d_var, &D, &P)) return rc;
+  LAUNCH_TRY(launch_pack(P, ncell, d_s1, d_s3, d_sl1, d_sion1, d_scal, d_var, d_fix, static_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
+int mistra_chem_unpack_device(int mech, int ncell, const double* d_var, double* d_s1, double* d_s3, double* d_sl1, double* d_sion1, void* hip_stream) {
+  if (ncell == 0) return 0;
+  if (!d_var || !d_s1 || !d_s3 || !d_sl1 || !d_sion1) return fail("null device pointer");
+  DeviceState* D; PackDev P;
+  if (int rc = pack_dev(mech, d_var, &D, &P)) return rc;
+  LAUNCH_TRY(launch_unpack(P, ncell, d_var, d_s1, d_s3, d_sl1, d_sion1, static_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
+int mistra_chem_budgets_device(int mech, int ncell, const double* d_var, const double* d_fix, const double* d_rconst, double dt, double* d_bg,
+                               double* d_bgs, void* hip_stream) {
+  if (ncell == 0) return 0;
+  if (!d_var || !d_fix || !d_rconst) return fail("null device pointer");
+  DeviceState* D; PackDev P;
+  if (int rc = pack_dev(mech, d_var, &D, &P)) return rc;
+  LAUNCH_TRY(launch_budgets(P, ncell, d_var, d_fix, d_rconst, dt, d_bg, d_bgs, static_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
+int mistra_chem_rates_env_from_c_device(int mech, int ncell, const double* d_var, const double* d_fix, double* d_env, void* hip_stream) {
+  if (ncell == 0) return 0;
+  if (!d_var || !d_fix || !d_env) return fail("null device pointer");
+  DeviceState* D; PackDev P;
+  if (int rc = pack_dev(mech, d_var, &D, &P)) return rc;
+  if (!D->mech[mech].rates_ready) return fail("no device rate table for this mechanism");
+  LAUNCH_TRY(launch_env_from_c(P, ncell, D->mech[mech].rates_nenv, d_var, d_fix, d_env, static_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
+int mistra_chem_drive_device(int mech, int ncell, double* d_s1, double* d_s3, double* d_sl1, double* d_sion1, const double* d_scal, double* d_env,
+                             double* d_var, double* d_fix, double tin, double dt, int32_t* d_ierr, int32_t* d_stats, double* d_texit_hexit,
+                             double* d_bg, double* d_bgs, void* hip_stream) {
+  if (ncell == 0) return 0;
+  if (!d_s1 || !d_s3 || !d_sl1 || !d_sion1 || !d_scal || !d_env || !d_var || !d_fix || !d_ierr || !d_stats) return fail("null device pointer");
+  DeviceState* D; PackDev P;
+  if (int rc = pack_dev(mech, d_var, &D, &P)) return rc;
+  MechState& S = D->mech[mech];
+  if (!S.rates_ready) return fail("no device rate table for this mechanism");
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  HIP_TRY(S.d_rct.reserve((size_t)ncell * (size_t)S.tab.nreact));      // (grow-only: the first call of a size allocates, i.e. synchronises)
+  LAUNCH_TRY(launch_pack(P, ncell, d_s1, d_s3, d_sl1, d_sion1, d_scal, d_var, d_fix, st));
+  LAUNCH_TRY(launch_env_from_c(P, ncell, S.rates_nenv, d_var, d_fix, d_env, st));
+  if (int rc = mistra_chem_update_rconst_device(mech, ncell, d_env, S.d_rct.p, hip_stream)) return rc;
+  if (int rc = mistra_chem_integrate_device(mech, ncell, d_var, d_fix, S.d_rct.p, tin, tin + dt, d_var, d_ierr, d_stats, d_texit_hexit, hip_stream)) return rc;
+  if (d_bg || d_bgs) LAUNCH_TRY(launch_budgets(P, ncell, d_var, d_fix, S.d_rct.p, dt, d_bg, d_bgs, st));
+  LAUNCH_TRY(launch_unpack(P, ncell, d_var, d_s1, d_s3, d_sl1, d_sion1, st));
   return 0;
 }
 

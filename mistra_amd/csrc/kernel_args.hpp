@@ -31,7 +31,8 @@ struct TailDev {               // tail chain of the triangular solves (schedule.
 };
 
 struct DenseDev {              // dense tail block (schedule.hpp: DenseTail); null where the mechanism has none
-  const uint32_t* row_info;    // [192][4]: first M cell of a row's column range, absent-column mask lo / hi, 0
+  const uint32_t* row_info;    // [192][4]: first M cell of a row's column range, absent-column mask lo / hi, 0 (the kernel keeps rows 0..63)
+  const uint16_t* schur_cells; // [8 * DENSE_KB * 64]: operand cells of the Schur steps in MFMA lane order (schedule.hpp: DenseTail)
 };
 
 struct KernelArgs {

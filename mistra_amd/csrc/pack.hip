@@ -1,0 +1,146 @@
+// The hand-over halves of the reference's per-layer drivers on the device, one workgroup per layer ("cell"):
+//   pack     what x_drive does before Update_RCONST_x: C <- s1 / s3 through the species maps (gas.f:132-138), FIX from air, h2o and
+//            the liquid water contents (gas.f:146-148 | tot.f:221-248), the liquid-phase species from sl1 / sion1 (aer_mk.dat,
+//            tot.f:252-599), after clamping the layer's sl1 / sion1 to >= 0 in place where the driver does (aer.f, tot.f:226-227)
+//   budgets  bud_x: bg(1,i) = RCONST(i) * reactants (the rate product A(i) of Fun_x, bud_g.f:67+), bg(2,i) += dt*bg(1,i);
+//            bud_s_x: the selected sulphur / DMS rates bgs(1,slot) and their accumulation (bud_s_g.f:71-98)
+//   unpack   the hand-over after the integration: s1 / s3 through the inverse maps (gas.f:191-197), sl1 / sion1 (aer_km.dat, tot.f:619-982)
+//   env      the concentrations Update_RCONST_x reads (C(ind_Hplz) ...) copied from the packed C into the rate evaluator's input
+// Integer / index work and plain products: every result is bit-identical to the reference's (built with -ffp-contract=off; the
+// float32 literals 0.21, 0.79, 55.55 spelled out).  Memory-bound: a layer is ~10 KB in, ~4 KB out.
+#include "pack.hpp"
+
+namespace mistra {
+
+namespace {
+
+constexpr int kNT = 256;
+
+__global__ __launch_bounds__(kNT) void pack_kernel(const PackDev P, int ncell, const double* __restrict__ s1, const double* __restrict__ s3,
+                                                   double* __restrict__ sl1, double* __restrict__ sion1, const double* __restrict__ scal,
+                                                   double* __restrict__ var, double* __restrict__ fix) {
+  const int cell = blockIdx.x, t = threadIdx.x;
+  if (cell >= ncell) return;
+  const int nl = P.j2 * P.nkc, ni = P.j6 * P.nkc;
+  double* L = sl1 + (size_t)cell * nl;
+  double* I = sion1 + (size_t)cell * ni;
+  double* V = var + (size_t)cell * P.nvar;
+  double* F = fix + (size_t)cell * P.nfix;
+  auto put = [&](int c0, double v) {
+    if (c0 < P.nvar) V[c0] = v;
+    else F[c0 - P.nvar] = v;
+  };
+  if (P.preclamp) {      // sl1(:,:,k)=max(0.d0,sl1(:,:,k)); sion1 likewise (tot.f:226-227): the model's arrays themselves
+    for (int i = t; i < nl; i += kNT) L[i] = L[i] > 0.0 ? L[i] : 0.0;      // max(0.d0, x): NaN -> 0 as flang's MAX does here (first argument wins)
+    for (int i = t; i < ni; i += kNT) I[i] = I[i] > 0.0 ? I[i] : 0.0;
+    __syncthreads();
+  }
+  // C(gas_m2k(1,j)) = s1(gas_m2k(2,j),k); C(rad_m2k(1,j)) = s3(rad_m2k(2,j),k)
+  for (int j = t; j < P.j1; j += kNT) put(P.gas_m2k[2 * j] - 1, s1[(size_t)cell * P.j1 + (P.gas_m2k[2 * j + 1] - 1)]);
+  for (int j = t; j < P.j5; j += kNT) put(P.rad_m2k[2 * j] - 1, s3[(size_t)cell * P.j5 + (P.rad_m2k[2 * j + 1] - 1)]);
+  // FIX: 0.21*air, h2o, 0.79*air, 55.55/cvv (default-REAL literals in a REAL*8 expression)
+  const double* sc = scal + (size_t)cell * 6;      // air, h2o, cvv1..4
+  for (int i = t; i < P.n_fix; i += kNT) {
+    const int c0 = P.fix[3 * i], kind = P.fix[3 * i + 1], kc = P.fix[3 * i + 2];
+    double v;
+    if (kind == 0) v = (double)0.21f * sc[0];
+    else if (kind == 1) v = (double)0.79f * sc[0];
+    else if (kind == 2) v = sc[1];
+    else v = sc[2 + kc] > 0.0 ? (double)55.55f / sc[2 + kc] : 0.0;
+    put(c0, v);
+  }
+  for (int i = t; i < P.n_pack; i += kNT) {
+    const int c0 = P.pack[4 * i], arr = P.pack[4 * i + 1], at = P.pack[4 * i + 2], clamp = P.pack[4 * i + 3];
+    double v = arr == 0 ? L[at] : I[at];
+    if (clamp) v = v > 0.0 ? v : 0.0;
+    put(c0, v);
+  }
+}
+
+__global__ __launch_bounds__(kNT) void unpack_kernel(const PackDev P, int ncell, const double* __restrict__ var, double* __restrict__ s1,
+                                                     double* __restrict__ s3, double* __restrict__ sl1, double* __restrict__ sion1) {
+  const int cell = blockIdx.x, t = threadIdx.x;
+  if (cell >= ncell) return;
+  const double* V = var + (size_t)cell * P.nvar;      // (only VAR entries are handed over: the maps and lists hold no FIX index)
+  for (int j = t; j < P.j1; j += kNT) s1[(size_t)cell * P.j1 + j] = V[P.gas_k2m[j] - 1];
+  for (int j = t; j < P.j5; j += kNT) s3[(size_t)cell * P.j5 + j] = V[P.rad_k2m[j] - 1];
+  double* L = sl1 + (size_t)cell * P.j2 * P.nkc;
+  double* I = sion1 + (size_t)cell * P.j6 * P.nkc;
+  for (int i = t; i < P.n_unpack; i += kNT) {
+    const int arr = P.unpack[4 * i], at = P.unpack[4 * i + 1], c0 = P.unpack[4 * i + 2], clamp = P.unpack[4 * i + 3];
+    double v = V[c0];
+    if (clamp) v = v > 0.0 ? v : 0.0;
+    (arr == 0 ? L : I)[at] = v;
+  }
+}
+
+__global__ __launch_bounds__(kNT) void budgets_kernel(const PackDev P, int ncell, const double* __restrict__ var, const double* __restrict__ fix,
+                                                      const double* __restrict__ rconst, double dt, double* __restrict__ bg, double* __restrict__ bgs) {
+  const int cell = blockIdx.x, t = threadIdx.x;
+  if (cell >= ncell) return;
+  const double* V = var + (size_t)cell * P.nvar;
+  const double* F = fix + (size_t)cell * P.nfix;
+  const double* K = rconst + (size_t)cell * P.nreact;
+  auto X = [&](int c0) { return c0 < P.nvar ? V[c0] : c0 < P.nvar + P.nfix ? F[c0 - P.nvar] : P.consts[c0 - P.nvar - P.nfix]; };
+  if (bg) {      // bud_x: bg(1,i,kl) = RCONST(i)*reactants, left to right; bg(2,i,kl) += dtg*bg(1,i,kl)
+    double* B = bg + (size_t)cell * 2 * P.nreact;      // (2, nreact) as the Fortran holds it: [i][0] instantaneous, [i][1] cumulative
+    for (int r = t; r < P.nreact; r += kNT) {
+      double p = K[r];
+      for (int q = P.a_ptr[r]; q < P.a_ptr[r + 1]; q++) p = p * X(P.a_fac[q]);
+      B[2 * r] = p;
+      B[2 * r + 1] = B[2 * r + 1] + dt * p;
+    }
+  }
+  if (bgs) {     // bud_s_x: bgs(1,slot,k) = +-RCONST(r)*C(..)*.. +- ..; the listed slot ranges accumulate
+    double* S = bgs + (size_t)cell * 2 * kBudSlots;
+    for (int s = t; s < P.n_slots; s += kNT) {
+      double acc = 0.0;
+      for (int q = P.slot_first[s]; q < P.slot_first[s + 1]; q++) {
+        const int sign = P.terms[3 * q], r = P.terms[3 * q + 1], w0 = P.terms[3 * q + 2], w1 = q + 1 < P.n_terms ? P.terms[3 * (q + 1) + 2] : P.n_words;
+        double p = K[r];
+        for (int w = w0; w < w1; w++) p = p * V[P.term_words[w]];      // (C indices of the budget terms are all variable species; the host checks)
+        acc = q == P.slot_first[s] ? (sign < 0 ? -p : p) : (sign < 0 ? acc - p : acc + p);
+      }
+      S[2 * (P.slot_id[s] - 1)] = acc;
+    }
+    __syncthreads();
+    for (int a = 0; a < P.n_acc; a++)
+      for (int i = P.acc[2 * a] - 1 + t; i < P.acc[2 * a + 1]; i += kNT) S[2 * i + 1] = S[2 * i + 1] + dt * S[2 * i];
+  }
+}
+
+__global__ __launch_bounds__(kNT) void env_from_c_kernel(const PackDev P, int ncell, int nenv, const double* __restrict__ var,
+                                                         const double* __restrict__ fix, double* __restrict__ env) {
+  const int i = blockIdx.x * kNT + threadIdx.x;
+  if (i >= ncell * P.n_envc) return;
+  const int cell = i / P.n_envc, e = i % P.n_envc, slot = P.envc[2 * e], c0 = P.envc[2 * e + 1];
+  env[(size_t)cell * nenv + slot] = c0 < P.nvar ? var[(size_t)cell * P.nvar + c0] : fix[(size_t)cell * P.nfix + (c0 - P.nvar)];
+}
+
+}  // namespace
+
+hipError_t launch_pack(const PackDev& P, int ncell, const double* s1, const double* s3, double* sl1, double* sion1, const double* scal,
+                       double* var, double* fix, hipStream_t stream) {
+  if (ncell <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ncell), dim3(kNT), 0, stream, P, ncell, s1, s3, sl1, sion1, scal, var, fix);
+  return hipGetLastError();
+}
+hipError_t launch_unpack(const PackDev& P, int ncell, const double* var, double* s1, double* s3, double* sl1, double* sion1, hipStream_t stream) {
+  if (ncell <= 0) return hipSuccess;
+  hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)ncell), dim3(kNT), 0, stream, P, ncell, var, s1, s3, sl1, sion1);
+  return hipGetLastError();
+}
+hipError_t launch_budgets(const PackDev& P, int ncell, const double* var, const double* fix, const double* rconst, double dt, double* bg,
+                          double* bgs, hipStream_t stream) {
+  if (ncell <= 0) return hipSuccess;
+  hipLaunchKernelGGL(budgets_kernel, dim3((unsigned)ncell), dim3(kNT), 0, stream, P, ncell, var, fix, rconst, dt, bg, bgs);
+  return hipGetLastError();
+}
+hipError_t launch_env_from_c(const PackDev& P, int ncell, int nenv, const double* var, const double* fix, double* env, hipStream_t stream) {
+  if (ncell <= 0 || P.n_envc == 0) return hipSuccess;
+  const int n = ncell * P.n_envc;
+  hipLaunchKernelGGL(env_from_c_kernel, dim3((unsigned)((n + kNT - 1) / kNT)), dim3(kNT), 0, stream, P, ncell, nenv, var, fix, env);
+  return hipGetLastError();
+}
+
+}  // namespace mistra

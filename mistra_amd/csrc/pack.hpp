@@ -1,0 +1,45 @@
+// Hand-over tables of the reference's per-layer drivers (mistra_amd/mech/<mech>.pack, written by tools/extract_pack.py) and the
+// device kernels that do what gas_drive / aer_drive / tot_drive do around Update_RCONST_x + INTEGRATE_x (gas.f:60-217 | aer.f:59-246 |
+// tot.f:59-982 with aer_mk.dat / aer_km.dat; budgets bud_x.f / bud_s_x.f): SURVEY.md §8 f2.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mistra {
+
+struct PackTable {
+  int nvar = 0, nfix = 0, j2 = 0, j6 = 0, nkc = 0, preclamp = 0;
+  std::vector<int32_t> pack, fix, unpack;                 // [n][4], [n][3], [n][4]  (see tools/extract_pack.py: write_binary)
+  std::vector<int32_t> slot_id, slot_first, terms, term_words, acc, envc;
+  int n_pack() const { return (int)pack.size() / 4; }
+  int n_fix() const { return (int)fix.size() / 3; }
+  int n_unpack() const { return (int)unpack.size() / 4; }
+  int n_slots() const { return (int)slot_id.size(); }
+  int n_envc() const { return (int)envc.size() / 2; }
+  bool load(const std::string& path, std::string* err);
+};
+
+constexpr int kBudSlots = 122;      // common /budgs/ bgs(2,122,n)   (bud_s_g.f:63)
+
+struct PackDev {                    // device copy of one mechanism's tables + the run-time species maps of module gas_common
+  const int32_t *pack, *fix, *unpack, *slot_id, *slot_first, *terms, *term_words, *acc, *envc;
+  int n_pack, n_fix, n_unpack, n_slots, n_terms, n_words, n_acc, n_envc;
+  int nvar, nfix, nreact, j2, j6, nkc, preclamp;
+  // gas_m2k_x(1:2, 1:j1) as the Fortran holds it (C index, s1 index; 1-based), gas_k2m_x(1:j1) (C index of s1(j)); likewise rad_* for s3
+  const int32_t *gas_m2k, *gas_k2m, *rad_m2k, *rad_k2m;
+  int j1, j5;
+  const int32_t *a_ptr, *a_fac;     // Fun_x's rate products A(i) = RCT(i) * prod X[a_fac] (mechanism table): bg(1,i,kl) of bud_x
+  const double* consts;             // X = [VAR | FIX | consts]
+};
+
+hipError_t launch_pack(const PackDev& P, int ncell, const double* s1, const double* s3, double* sl1, double* sion1, const double* scal,
+                       double* var, double* fix, hipStream_t stream);
+hipError_t launch_unpack(const PackDev& P, int ncell, const double* var, double* s1, double* s3, double* sl1, double* sion1, hipStream_t stream);
+hipError_t launch_budgets(const PackDev& P, int ncell, const double* var, const double* fix, const double* rconst, double dt, double* bg,
+                          double* bgs, hipStream_t stream);
+hipError_t launch_env_from_c(const PackDev& P, int ncell, int nenv, const double* var, const double* fix, double* env, hipStream_t stream);
+
+}  // namespace mistra

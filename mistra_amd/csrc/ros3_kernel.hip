@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "kernel_args.hpp"
 #include "ros3_kernel.hpp"
@@ -206,28 +207,21 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev P, int wave, int la
 #undef MISTRA_VM_OPERANDS
 }
 
-// ---- tail chain of the triangular solves (schedule.hpp: TailSolve), run by ONE wave: lane l holds rows h+l and
-//      h+64+l of the solution in registers, the pivot value travels by v_readlane, matrix entries are gathered from
-//      LDS through per-column index tables streamed through the look-ahead ring (one 16-byte slot = 4 columns).
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  const uint64_t u = __builtin_bit_cast(uint64_t, v);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
-  return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
-}
-
-// ---- forward chain over the dense tail block (schedule.hpp: DenseTail), inside the tail chain's wave: lane l holds entry l of
-//      the block's 64 rows, lane row r (16 lanes) = 16x16 block row r.  Per block column J:
-//        1. the 16 unknowns of block J, in lane row J: x(i) -= L(i,j) x(j), j ascending — the pivot value reaches the other lanes of
-//           its lane row inside the multiply-add itself (DPP row_newbcast on v_fmac_f64: measured 10 cycles per dependent step
-//           with one wait state, 14 with the two the ISA manual asks for; the v_readlane -> SGPR -> VALU round trip of the generic
-//           chain costs ~57);
+// ---- tail chain of the triangular solves (schedule.hpp: TailSolve), run by ONE wave: lane l holds rows h+l and h+64+l of the
+//      solution in registers (x[0], x[1]); lane row r (16 lanes) of register q = 16x16 block row 4q + r of the tail triangle.
+//      Matrix entries are gathered from LDS through per-column index tables streamed through the look-ahead ring (one 16-byte
+//      slot = 4 columns, a 16-column block = 4 slots; the backward tables follow the forward ones through the same ring, so the
+//      stream is primed once per solve).  Per block column J (forward; backward runs the blocks and the columns the other way):
+//        1. the block's own 16 unknowns, in their lane row: x(i) -= L(i,j) x(j), j ascending — the pivot value reaches the other
+//           lanes of its lane row inside the multiply-add itself (DPP row_newbcast on v_fmac_f64: measured 10 cycles per dependent
+//           step with one wait state, 14 with the two the ISA manual asks for; the v_readlane -> SGPR -> VALU round trip that all
+//           columns but the dense block's forward ones took until round 3 costs ~57);
 //        2. the 16 finished values go to all four lane rows (gfx950 v_permlane16_swap / v_permlane32_swap);
-//        3. the lane rows below take their 16 terms, j ascending, again by DPP.
-//      Every row still receives its terms in ascending column order with the operands and the fused multiply-add of the generic
-//      chain: the results are bit-identical.  A row of the block is contiguous in Ghimj (CSR, columns ascending) and only its
-//      first column may be missing (the host checks the row table for that), so the 16 operands of a block column are 16
-//      consecutive cells from one per-lane base address: no index tables, no address arithmetic per column.
+//        3. the rows below take their 16 terms, j ascending, again by DPP: the lane rows below in the same register, and every
+//           lane row of the other register.
+//      Every row still receives its terms in ascending (backward: descending) column order with the operands and the fused
+//      multiply-add of the column-by-column chain the emulator states (tests/emu/schedule_emu.cpp): the results are bit-identical.
+//      Operands that are not in the pattern (and every diagonal) point at the 0.0 cell.
 template <int ROW>
 __device__ __forceinline__ double lane_row_to_all(double v) {
   const uint64_t u = __builtin_bit_cast(uint64_t, v);
@@ -241,15 +235,17 @@ __device__ __forceinline__ double lane_row_to_all(double v) {
   const auto h32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
   return __builtin_bit_cast(double, (uint64_t)l32[(ROW >> 1) & 1] | ((uint64_t)h32[(ROW >> 1) & 1] << 32));
 }
-// One block column J.  The two phases are ONE asm statement each: between separate statements the compiler adds wait
-// states of its own, and masking the operands of step 1 by lane (v_cmp + 2 v_cndmask per value) cost more issue slots
-// than the steps themselves.  Here the lanes that take step j are selected through EXEC, a scalar move per step that also
-// serves as one of the two wait states the DPP read needs (tools/ubench/dpp.hip): the rows i >= j of the block — row j
-// itself stays enabled because a DPP read of a disabled lane is no read at all; its operand is the diagonal cell, which
-// dense_fwd_chain has set to zero (the diagonal of U is dead once its reciprocal is published), so the step leaves it alone.
+// The phases are ONE asm statement each: between separate statements the compiler adds wait states of its own, and masking the
+// operands of step 1 by lane (v_cmp + 2 v_cndmask per value) cost more issue slots than the steps themselves.  The lanes that
+// take step j are selected through EXEC, a scalar move per step that also serves as one of the two wait states the DPP read
+// needs (tools/ubench/dpp.hip): forward the rows i >= j of the block, backward the rows i <= j — row j itself stays enabled
+// because a DPP read of a disabled lane is no read at all; its operand is the diagonal, i.e. the 0.0 cell, so the step leaves it alone.
+#define MISTRA_TAIL_COPS                                                                                                          \
+  [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]),     \
+      [c8] "v"(c[8]), [c9] "v"(c[9]), [c10] "v"(c[10]), [c11] "v"(c[11]), [c12] "v"(c[12]), [c13] "v"(c[13]), [c14] "v"(c[14]), [c15] "v"(c[15])
 #define MISTRA_DIAG_STEP(J, EXECHALF, MASK) \
   "s_mov_b32 " EXECHALF ", " MASK "\n\ts_nop 0\n\tv_fmac_f64_dpp %[x], -%[x], %[c" #J "] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
-#define MISTRA_DIAG_PHASE(EXECHALF, OTHERHALF, SH)                                                                             \
+#define MISTRA_DIAG_FWD(EXECHALF, OTHERHALF, SH)                                                                                \
   asm volatile("s_mov_b32 " OTHERHALF ", 0\n\t"                                                                                 \
                MISTRA_DIAG_STEP(0, EXECHALF, "0xffff" SH) MISTRA_DIAG_STEP(1, EXECHALF, "0xfffe" SH) MISTRA_DIAG_STEP(2, EXECHALF, "0xfffc" SH)   \
                MISTRA_DIAG_STEP(3, EXECHALF, "0xfff8" SH) MISTRA_DIAG_STEP(4, EXECHALF, "0xfff0" SH) MISTRA_DIAG_STEP(5, EXECHALF, "0xffe0" SH)   \
@@ -257,62 +253,198 @@ __device__ __forceinline__ double lane_row_to_all(double v) {
                MISTRA_DIAG_STEP(9, EXECHALF, "0xfe00" SH) MISTRA_DIAG_STEP(10, EXECHALF, "0xfc00" SH) MISTRA_DIAG_STEP(11, EXECHALF, "0xf800" SH) \
                MISTRA_DIAG_STEP(12, EXECHALF, "0xf000" SH) MISTRA_DIAG_STEP(13, EXECHALF, "0xe000" SH) MISTRA_DIAG_STEP(14, EXECHALF, "0xc000" SH) \
                "s_mov_b64 exec, -1"                                                                                             \
-               : [x] "+v"(x)                                                                                                    \
-               : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), \
-                 [c8] "v"(c[8]), [c9] "v"(c[9]), [c10] "v"(c[10]), [c11] "v"(c[11]), [c12] "v"(c[12]), [c13] "v"(c[13]), [c14] "v"(c[14]))
+               : [x] "+v"(x) : MISTRA_TAIL_COPS)
+// (backward: SHL = "" for the lane row in the low 16 bits of its EXEC half; for the high one the masks are written out shifted)
+#define MISTRA_DIAG_BWD(EXECHALF, OTHERHALF, M15, M14, M13, M12, M11, M10, M9, M8, M7, M6, M5, M4, M3, M2, M1)                   \
+  asm volatile("s_mov_b32 " OTHERHALF ", 0\n\t"                                                                                 \
+               MISTRA_DIAG_STEP(15, EXECHALF, M15) MISTRA_DIAG_STEP(14, EXECHALF, M14) MISTRA_DIAG_STEP(13, EXECHALF, M13)       \
+               MISTRA_DIAG_STEP(12, EXECHALF, M12) MISTRA_DIAG_STEP(11, EXECHALF, M11) MISTRA_DIAG_STEP(10, EXECHALF, M10)       \
+               MISTRA_DIAG_STEP(9, EXECHALF, M9) MISTRA_DIAG_STEP(8, EXECHALF, M8) MISTRA_DIAG_STEP(7, EXECHALF, M7)             \
+               MISTRA_DIAG_STEP(6, EXECHALF, M6) MISTRA_DIAG_STEP(5, EXECHALF, M5) MISTRA_DIAG_STEP(4, EXECHALF, M4)             \
+               MISTRA_DIAG_STEP(3, EXECHALF, M3) MISTRA_DIAG_STEP(2, EXECHALF, M2) MISTRA_DIAG_STEP(1, EXECHALF, M1)             \
+               "s_mov_b64 exec, -1"                                                                                             \
+               : [x] "+v"(x) : MISTRA_TAIL_COPS)
+#define MISTRA_DIAG_BWD_LO(EXECHALF, OTHERHALF)                                                                                 \
+  MISTRA_DIAG_BWD(EXECHALF, OTHERHALF, "0xffff", "0x7fff", "0x3fff", "0x1fff", "0xfff", "0x7ff", "0x3ff", "0x1ff", "0xff", "0x7f", "0x3f", "0x1f", "0xf", "0x7", "0x3")
+#define MISTRA_DIAG_BWD_HI(EXECHALF, OTHERHALF)                                                                                 \
+  MISTRA_DIAG_BWD(EXECHALF, OTHERHALF, "0xffff0000", "0x7fff0000", "0x3fff0000", "0x1fff0000", "0xfff0000", "0x7ff0000", "0x3ff0000", "0x1ff0000", "0xff0000", "0x7f0000", "0x3f0000", "0x1f0000", "0xf0000", "0x70000", "0x30000")
 #define MISTRA_UPD_STEP(J, ROWMASK) "v_fmac_f64_dpp %[x], -%[xb], %[c" #J "] row_newbcast:" #J " row_mask:" ROWMASK " bank_mask:0xf\n\t"
-#define MISTRA_UPDATE_PHASE(ROWMASK)                                                                                           \
+#define MISTRA_UPDATE_FWD(ROWMASK)                                                                                             \
   asm volatile("s_nop 1\n\t"                                                                                                   \
                MISTRA_UPD_STEP(0, ROWMASK) MISTRA_UPD_STEP(1, ROWMASK) MISTRA_UPD_STEP(2, ROWMASK) MISTRA_UPD_STEP(3, ROWMASK)   \
                MISTRA_UPD_STEP(4, ROWMASK) MISTRA_UPD_STEP(5, ROWMASK) MISTRA_UPD_STEP(6, ROWMASK) MISTRA_UPD_STEP(7, ROWMASK)   \
                MISTRA_UPD_STEP(8, ROWMASK) MISTRA_UPD_STEP(9, ROWMASK) MISTRA_UPD_STEP(10, ROWMASK) MISTRA_UPD_STEP(11, ROWMASK) \
                MISTRA_UPD_STEP(12, ROWMASK) MISTRA_UPD_STEP(13, ROWMASK) MISTRA_UPD_STEP(14, ROWMASK)                            \
                "v_fmac_f64_dpp %[x], -%[xb], %[c15] row_newbcast:15 row_mask:" ROWMASK " bank_mask:0xf"                         \
-               : [x] "+v"(x)                                                                                                    \
-               : [xb] "v"(xb), [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]),    \
-                 [c7] "v"(c[7]), [c8] "v"(c[8]), [c9] "v"(c[9]), [c10] "v"(c[10]), [c11] "v"(c[11]), [c12] "v"(c[12]), [c13] "v"(c[13]),          \
-                 [c14] "v"(c[14]), [c15] "v"(c[15]))
-template <int J>
-__device__ __forceinline__ void dense_fwd_block(double& x, const uint32_t base, const uint32_t col0, const int lane) {
-  double c[16];      // this lane's row, columns 16J .. 16J+15: L(i,j) left of the diagonal, 0 on it; to the right U (those lanes sit the step out)
-#pragma unroll
-  for (int j = 0; j < 16; j++) c[j] = lds_ld((J == 0 && j == 0) ? col0 : base + 8u * (uint32_t)(16 * J + j));
-  // 1. lane row J, inside its 16x16 block
-  if constexpr (J == 0) MISTRA_DIAG_PHASE("exec_lo", "exec_hi", "");
-  else if constexpr (J == 1) MISTRA_DIAG_PHASE("exec_lo", "exec_hi", "0000");
-  else if constexpr (J == 2) MISTRA_DIAG_PHASE("exec_hi", "exec_lo", "");
-  else MISTRA_DIAG_PHASE("exec_hi", "exec_lo", "0000");
-  if constexpr (J < 3) {
-    const double xb = lane_row_to_all<J>(x);      // 2.
-    if constexpr (J == 0) MISTRA_UPDATE_PHASE("0xe");      // 3. the lane rows below
-    else if constexpr (J == 1) MISTRA_UPDATE_PHASE("0xc");
-    else MISTRA_UPDATE_PHASE("0x8");
+               : [x] "+v"(x) : [xb] "v"(xb), MISTRA_TAIL_COPS)
+#define MISTRA_UPDATE_BWD(ROWMASK)                                                                                             \
+  asm volatile("s_nop 1\n\t"                                                                                                   \
+               MISTRA_UPD_STEP(15, ROWMASK) MISTRA_UPD_STEP(14, ROWMASK) MISTRA_UPD_STEP(13, ROWMASK) MISTRA_UPD_STEP(12, ROWMASK) \
+               MISTRA_UPD_STEP(11, ROWMASK) MISTRA_UPD_STEP(10, ROWMASK) MISTRA_UPD_STEP(9, ROWMASK) MISTRA_UPD_STEP(8, ROWMASK)   \
+               MISTRA_UPD_STEP(7, ROWMASK) MISTRA_UPD_STEP(6, ROWMASK) MISTRA_UPD_STEP(5, ROWMASK) MISTRA_UPD_STEP(4, ROWMASK)     \
+               MISTRA_UPD_STEP(3, ROWMASK) MISTRA_UPD_STEP(2, ROWMASK) MISTRA_UPD_STEP(1, ROWMASK)                                 \
+               "v_fmac_f64_dpp %[x], -%[xb], %[c0] row_newbcast:0 row_mask:" ROWMASK " bank_mask:0xf"                           \
+               : [x] "+v"(x) : [xb] "v"(xb), MISTRA_TAIL_COPS)
+
+// step 1 of a block column for the lane row ROW of x
+template <int ROW, bool BACKWARD>
+__device__ __forceinline__ void tail_diag(double& x, const double (&c)[16]) {
+  if constexpr (!BACKWARD) {
+    if constexpr (ROW == 0) MISTRA_DIAG_FWD("exec_lo", "exec_hi", "");
+    else if constexpr (ROW == 1) MISTRA_DIAG_FWD("exec_lo", "exec_hi", "0000");
+    else if constexpr (ROW == 2) MISTRA_DIAG_FWD("exec_hi", "exec_lo", "");
+    else MISTRA_DIAG_FWD("exec_hi", "exec_lo", "0000");
+  } else {
+    if constexpr (ROW == 0) MISTRA_DIAG_BWD_LO("exec_lo", "exec_hi");
+    else if constexpr (ROW == 1) MISTRA_DIAG_BWD_HI("exec_lo", "exec_hi");
+    else if constexpr (ROW == 2) MISTRA_DIAG_BWD_LO("exec_hi", "exec_lo");
+    else MISTRA_DIAG_BWD_HI("exec_hi", "exec_lo");
   }
 }
+// step 3: the lane rows selected by MASK (a 4-bit row mask) take the block column's 16 terms from the broadcast values xb
+template <int MASK, bool BACKWARD>
+__device__ __forceinline__ void tail_update(double& x, const double xb, const double (&c)[16]) {
+  static_assert(MASK >= 1 && MASK <= 15, "row mask");
+#define MISTRA_UPD_CASE(M, S) else if constexpr (MASK == M) { if constexpr (BACKWARD) MISTRA_UPDATE_BWD(S); else MISTRA_UPDATE_FWD(S); }
+  if constexpr (MASK == 15) { if constexpr (BACKWARD) MISTRA_UPDATE_BWD("0xf"); else MISTRA_UPDATE_FWD("0xf"); }
+  MISTRA_UPD_CASE(14, "0xe") MISTRA_UPD_CASE(12, "0xc") MISTRA_UPD_CASE(8, "0x8") MISTRA_UPD_CASE(1, "0x1") MISTRA_UPD_CASE(3, "0x3") MISTRA_UPD_CASE(7, "0x7")
+  else static_assert(MASK == 15, "row mask not instantiated");
+#undef MISTRA_UPD_CASE
+}
 #undef MISTRA_DIAG_STEP
-#undef MISTRA_DIAG_PHASE
+#undef MISTRA_DIAG_FWD
+#undef MISTRA_DIAG_BWD
+#undef MISTRA_DIAG_BWD_LO
+#undef MISTRA_DIAG_BWD_HI
 #undef MISTRA_UPD_STEP
-#undef MISTRA_UPDATE_PHASE
-__device__ __forceinline__ void dense_fwd_chain(double& x, const uint32_t info_addr, const uint32_t zero_addr, const int lane) {
-  const u32x4 info = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(info_addr + 16u * (uint32_t)lane);
-  const uint32_t absent0 = info.y & 1u;                              // (only column 0 of a row may be missing: schedule.cpp, build_dense_tail)
-  const uint32_t base = 8u * (info.x - absent0);                     // cell of column c >= 1: base + 8 c
-  const uint32_t col0 = absent0 ? zero_addr : 8u * info.x;
-  lds_st(base + 8u * (uint32_t)lane, 0.0);                          // the row's diagonal cell (see dense_fwd_block); the reads below are this wave's own, in order
-  dense_fwd_block<0>(x, base, col0, lane);
-  dense_fwd_block<1>(x, base, col0, lane);
-  dense_fwd_block<2>(x, base, col0, lane);
-  dense_fwd_block<3>(x, base, col0, lane);
+#undef MISTRA_UPDATE_FWD
+#undef MISTRA_UPDATE_BWD
+#undef MISTRA_TAIL_COPS
+
+// One block column, in two halves so that the operand gathers of block b + 1 are in flight while block b computes (a lone wave
+// would otherwise sit out the table wait and an LDS round trip in front of every block: measured, the chain then took as long
+// as the column-by-column one).  w[0..3]: the block's four table slots (16 columns in chain order: ascending forward,
+// descending backward); a word holds the Ghimj cell of (row h + lane, column) in its low half and of (row h + 64 + lane,
+// column) in its high half.
+template <bool BACKWARD>
+__device__ __forceinline__ uint32_t tail_word(const u32x4 (&w)[4], int j) {      // table word of the block's column j
+  const int i = BACKWARD ? 15 - j : j;
+  const u32x4& s = w[i / 4];
+  return (i % 4) == 0 ? s.x : (i % 4) == 1 ? s.y : (i % 4) == 2 ? s.z : s.w;
+}
+// operands of the block's own register (diagonal block, lane rows below / above): gathered one block ahead
+template <int R, int J, bool BACKWARD>
+__device__ __forceinline__ void tail_gather(double (&c)[16], const u32x4 (&w)[4]) {
+  constexpr int REG = J / 4;
+#pragma unroll
+  for (int j = 0; j < 16; j++) c[j] = lds_ld(8u * (REG == 0 ? (tail_word<BACKWARD>(w, j) & 0xFFFFu) : (tail_word<BACKWARD>(w, j) >> 16)));
+}
+// NEXT: takes the next block's table slots and issues the gathers of its operands (into c and w, free by then) — placed between
+// the block's last use of c and the other register's update, whose 16 dependent steps cover the gathers' LDS round trip.
+template <int R, int J, bool BACKWARD, bool LAST, class NEXT>
+__device__ __forceinline__ void tail_block(double (&xr)[R], double (&c)[16], const u32x4 (&w)[4], NEXT&& next) {
+  constexpr int REG = J / 4, ROW = J % 4;
+  constexpr int OTHER = BACKWARD ? 0 : R - 1;                    // the other register's rows lie wholly below (forward) / above (backward) the block
+  constexpr bool HAS_OTHER = !LAST && R == 2 && REG != OTHER;
+  double d[16];      // ... their operands: gathered here, used three phases further down
+  if constexpr (HAS_OTHER) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) d[j] = lds_ld(8u * (OTHER == 0 ? (tail_word<BACKWARD>(w, j) & 0xFFFFu) : (tail_word<BACKWARD>(w, j) >> 16)));
+  }
+  double x = xr[REG];
+  tail_diag<ROW, BACKWARD>(x, c);                                  // 1.
+  if constexpr (!LAST) {
+    const double xb = lane_row_to_all<ROW>(x);                     // 2.
+    constexpr int same = BACKWARD ? (1 << ROW) - 1 : (0xF << (ROW + 1)) & 0xF;      // 3. lane rows above / below in the same register
+    if constexpr (same != 0) tail_update<same, BACKWARD>(x, xb, c);
+    xr[REG] = x;
+    if constexpr (HAS_OTHER) {
+      double y = xr[OTHER];
+      asm volatile("" : "+v"(y), "+v"(d[0]), "+v"(d[15]));      // (d and y are in registers before the next block's table words overwrite w)
+      next();
+      tail_update<15, BACKWARD>(y, xb, d);
+      xr[OTHER] = y;
+    } else {
+      next();
+    }
+  } else {
+    xr[REG] = x;
+    next();
+  }
 }
 
-// FWD_FROM: first 64-row block of the forward chain.  0: the whole forward chain; R: none (the vector has been
-// forward-swept already — stage 1, inside the LU program); 1 of R = 2: only the columns of the dense tail block, whose
-// rows the LU program leaves without exactly those terms (schedule.cpp: lu_entries, dense_h)
-// DENSE_INFO: LDS byte address of the dense tail block's row table (0: no such block).  With it, the last 64 columns of the
-// forward chain — the block's own — are dense_fwd_chain's.
-template <int R, int FWD_FROM, bool LOW, uint32_t DENSE_INFO = 0, uint32_t ZERO_CELL = 0>
+// FWD_BLOCK0: first 16-column block of the forward chain.  0: the whole forward chain; 4R: none (the vector has been
+// forward-swept already — stage 1, inside the LU program); 4 of R = 2 with the dense tail block: only the block's own columns,
+// whose rows the LU program leaves without exactly those terms (schedule.cpp: lu_entries, dense_h)
+template <int R, int FWD_BLOCK0, bool LOW>
 __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t xb, uint32_t rb, int lane) {
-  constexpr int FWD_END = DENSE_INFO ? R - 1 : R;      // 64-row blocks of the forward chain that go through the generic loop
+  constexpr int NB = 4 * R;                      // 16-column blocks of the tail triangle
+  constexpr int NF = NB - FWD_BLOCK0;            // ... of them in the forward chain
+  constexpr int NS = NF + NB;                    // blocks of the whole solve, forward then backward
+  static_assert(FWD_BLOCK0 >= 0 && FWD_BLOCK0 <= NB && NS <= 16, "first forward block");
+  double x[R], rd[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    x[r] = lds_ld(xb + 8 * (r * 64 + lane));
+    rd[r] = lds_ld(rb + 8 * (r * 64 + lane));          // R(k) = 1/U(k,k), published by the LU program
+  }
+  const gptr<u32x4> tf = G_(reinterpret_cast<const u32x4*>(T.fwd)) + lane + FWD_BLOCK0 * 4 * 64;
+  const gptr<u32x4> tb = G_(reinterpret_cast<const u32x4*>(T.bwd)) + lane;
+  auto group = [&](int g) -> gptr<u32x4> { return g < 4 * NF ? tf + g * 64 : tb + (g - 4 * NF) * 64; };      // (past the last group: the tables' slack rows)
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
+  vm_ring_load<LOW, 0>(group(0)); vm_ring_load<LOW, 1>(group(1)); vm_ring_load<LOW, 2>(group(2)); vm_ring_load<LOW, 3>(group(3));
+  vm_ring_load<LOW, 4>(group(4)); vm_ring_load<LOW, 5>(group(5)); vm_ring_load<LOW, 6>(group(6)); vm_ring_load<LOW, 7>(group(7));
+  // block S of the stream (S < NF: forward block FWD_BLOCK0 + S; else backward block NB - 1 - (S - NF)): its four slots (blocks
+  // alternate between the ring's halves, refilled with block S + 2's) and the gathers of its operands
+  double c[16];
+  u32x4 w[4];
+#define MISTRA_TAIL_GATHER(S)                                                                                             \
+  if constexpr ((S) < NS) {                                                                                              \
+    constexpr int K0 = ((S) & 1) * 4;                                                                                    \
+    w[0] = vm_ring_take<LOW, K0, 7>(); w[1] = vm_ring_take<LOW, K0 + 1, 6>();                                            \
+    w[2] = vm_ring_take<LOW, K0 + 2, 5>(); w[3] = vm_ring_take<LOW, K0 + 3, 4>();                                        \
+    vm_ring_load<LOW, K0>(group(4 * (S) + 8)); vm_ring_load<LOW, K0 + 1>(group(4 * (S) + 9));                           \
+    vm_ring_load<LOW, K0 + 2>(group(4 * (S) + 10)); vm_ring_load<LOW, K0 + 3>(group(4 * (S) + 11));                      \
+    if constexpr ((S) < NF) tail_gather<R, (FWD_BLOCK0 + (S)) % NB, false>(c, w);                                        \
+    else tail_gather<R, (NB - 1 - ((S) - NF) + NB) % NB, true>(c, w);                                                    \
+  }
+  // ... and its arithmetic; between the forward and the backward half: x = R .* x (the backward half runs on the row-scaled
+  // triangle U' = D^-1 U that the factorisation leaves in the tail block — schedule.cpp: lu_entries; dense_lu — so there is
+  // no quotient on the serial chain)
+#define MISTRA_TAIL_STEP(S)                                                                                               \
+  if constexpr ((S) < NS) {                                                                                              \
+    if constexpr ((S) == NF) {                                                                                           \
+      _Pragma("unroll") for (int r = 0; r < R; r++) x[r] = x[r] * rd[r];                                                 \
+    }                                                                                                                    \
+    auto next = [&]() { MISTRA_TAIL_GATHER((S) + 1) };                                                                   \
+    if constexpr ((S) < NF) tail_block<R, (FWD_BLOCK0 + (S)) % NB, false, FWD_BLOCK0 + (S) == NB - 1>(x, c, w, next);    \
+    else tail_block<R, (NB - 1 - ((S) - NF) + NB) % NB, true, (S) == NS - 1>(x, c, w, next);                             \
+  }
+  MISTRA_TAIL_GATHER(0)
+  MISTRA_TAIL_STEP(0) MISTRA_TAIL_STEP(1) MISTRA_TAIL_STEP(2) MISTRA_TAIL_STEP(3) MISTRA_TAIL_STEP(4) MISTRA_TAIL_STEP(5) MISTRA_TAIL_STEP(6) MISTRA_TAIL_STEP(7)
+  MISTRA_TAIL_STEP(8) MISTRA_TAIL_STEP(9) MISTRA_TAIL_STEP(10) MISTRA_TAIL_STEP(11) MISTRA_TAIL_STEP(12) MISTRA_TAIL_STEP(13) MISTRA_TAIL_STEP(14) MISTRA_TAIL_STEP(15)
+#undef MISTRA_TAIL_STEP
+#undef MISTRA_TAIL_GATHER
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // the look-ahead loads past the stream's end have landed
+#pragma unroll
+  for (int r = 0; r < R; r++) lds_st(xb + 8 * (r * 64 + lane), x[r]);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+  return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
+
+// FWD_FROM: first 64-row block of the forward chain.  0: the whole forward chain; R: none (the vector has been forward-swept
+// already — stage 1, inside the LU program).
+// The column-by-column form of the chain, kept for the kernels held to 128 registers (aer, gas): the pivot value travels by
+// v_readlane (~57 cycles per column); the block form above needs 16 operands per lane in registers at once, more than those
+// kernels' functions have below their look-ahead ring.
+template <int R, int FWD_FROM, bool LOW>
+__device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, uint32_t xb, uint32_t rb, int lane) {
+  constexpr int FWD_END = R;
   constexpr bool FORWARD = FWD_FROM < FWD_END;
   constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
   double x[R], rd[R];
@@ -363,10 +495,6 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
         tp += kRingSlots * 64;
       }
     }
-  }
-  if constexpr (DENSE_INFO != 0 && FWD_FROM < R) {
-    if constexpr (FORWARD) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");      // the generic loop's look-ahead loads have landed
-    dense_fwd_chain(x[R - 1], DENSE_INFO, ZERO_CELL, lane);
   }
   // ---- backward, on the row-scaled triangle U' = D^-1 U that the LU program's last phase leaves in the tail block
   //      (schedule.cpp: lu_entries): x = R .* x, then for every tail column q descending  x(i) -= U'(i,q) * x(q)  for the
@@ -682,33 +810,60 @@ __device__ __attribute__((noinline)) void dense_lu(int lane) {
     T1[r] = lds_ld(dense_slot(info, 16u * J0 + 16u + lcol, ZERO));
   }
   // ---- Schur steps: pivots jm .. h-1, four per MFMA, ascending: D -= W * U' with W the still unscaled L slots of the
-  //      block's rows and U' the row-scaled U slots of the pivots' rows (schedule.hpp: DenseTail)
-  const u32x4 lrow_info = lds_ldu4(INFO + 16u * (64u + 16u * I + lcol));      // A operand: row 16I + (lane&15), k = lane>>4
+  //      block's rows and U' the row-scaled U slots of the pivots' rows (schedule.hpp: DenseTail).  The operands' cells come from
+  //      the host-made table in LDS, and everything is fetched in three batches (cells, values, then the MFMAs): taken step by
+  //      step, every step waited out three dependent LDS round trips and ~60 instructions of row-table arithmetic (round 2:
+  //      7 500 cycles for these 28 MFMAs).
+  constexpr uint32_t SCH = 8u * (uint32_t)LdsLayout<MT, NT>::SCHUR;
+  typedef __attribute__((address_space(3))) uint16_t lds_u16;
+  const uint32_t wtab = SCH + 2u * ((uint32_t)I * KB * 64u + (uint32_t)lane);                                            // + 128 k
+  const uint32_t utab = SCH + 2u * (4u * KB * 64u + (uint32_t)(wave & 1) * KB * 128u + (uint32_t)lane);                   // + 256 k (+ 128: second tile)
   uint32_t wslot[KB];
+  double wl[KB];
+  static_assert(KB % 2 == 0, "two batches of Schur steps");
 #pragma unroll
-  for (int k = 0; k < KB; k++) {
-    const u32x4 urow_info = lds_ldu4(INFO + 16u * (128u + 4u * k + lrow));     // B operand: k = lane>>4, column 16J + (lane&15)
-    wslot[k] = dense_slot(lrow_info, 4u * k + lrow, ZERO);
-    const double wl = lds_ld(wslot[k]);
-    const double u0 = lds_ld(dense_slot(urow_info, 16u * J0 + lcol, ZERO)), u1 = lds_ld(dense_slot(urow_info, 16u * J0 + 16u + lcol, ZERO));
-    T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-wl, u0, T0, 0, 0, 0);
-    T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-wl, u1, T1, 0, 0, 0);
+  for (int half = 0; half < 2; half++) {      // two batches of KB/2 steps: one batch of all KB needed more registers than dense_lu can have without saving callee-saved ones
+    constexpr int HB = KB / 2;
+    uint32_t us0[HB], us1[HB];
+#pragma unroll
+    for (int kk = 0; kk < HB; kk++) {
+      const int k = half * HB + kk;
+      wslot[k] = 8u * (uint32_t)*(const lds_u16*)(uintptr_t)(wtab + 128u * k);
+      us0[kk] = 8u * (uint32_t)*(const lds_u16*)(uintptr_t)(utab + 256u * k);
+      us1[kk] = 8u * (uint32_t)*(const lds_u16*)(uintptr_t)(utab + 256u * k + 128u);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // (the compiler's scheduler would otherwise weave the batches back into one chain per step)
+    double u0[HB], u1[HB];
+#pragma unroll
+    for (int kk = 0; kk < HB; kk++) {
+      wl[half * HB + kk] = lds_ld(wslot[half * HB + kk]);
+      u0[kk] = lds_ld(us0[kk]);
+      u1[kk] = lds_ld(us1[kk]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < HB; kk++) {
+      T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-wl[half * HB + kk], u0[kk], T0, 0, 0, 0);
+      T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-wl[half * HB + kk], u1[kk], T1, 0, 0, 0);
+    }
   }
+  // R(j) of the steps' pivots for the lane's own multipliers (below); the reads run beside the MFMAs
+  double rj[KB / 2];
+#pragma unroll
+  for (int k2 = 0; k2 < KB / 2; k2++) rj[k2] = lds_ld(RDIAG + 8u * (JM + 4u * (2u * k2 + (uint32_t)(wave & 1)) + lrow));
   MISTRA_STAMP(t1)
   lds_barrier();      // both waves of a block row have read the unscaled slots
   {                   // L = W * R(j) for the solves; the two waves of a block row share the work (steps k even / k odd)
     static_assert(KB % 2 == 0, "the two waves of a block row take every other Schur step");
-    double v[KB / 2];
-    uint32_t at[KB / 2];
-    const uint32_t odd = (uint32_t)(wave & 1), pick = odd ? 0xFFFFFFFFu : 0u;      // (bit selects: an array element picked by a run-time condition would put the array in scratch memory)
+    if (wave & 1) {   // (wave-uniform branch: compile-time register indices on both sides)
 #pragma unroll
-    for (int k2 = 0; k2 < KB / 2; k2++) {
-      at[k2] = (wslot[2 * k2 + 1] & pick) | (wslot[2 * k2] & ~pick);
-      v[k2] = lds_ld(at[k2]) * lds_ld(RDIAG + 8u * (JM + 4u * (2u * k2 + odd) + lrow));
+      for (int k = 1; k < KB; k += 2)
+        if (wslot[k] != ZERO) lds_st(wslot[k], wl[k] * rj[k / 2]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < KB; k += 2)
+        if (wslot[k] != ZERO) lds_st(wslot[k], wl[k] * rj[k / 2]);
     }
-#pragma unroll
-    for (int k2 = 0; k2 < KB / 2; k2++)
-      if (at[k2] != ZERO) lds_st(at[k2], v[k2]);
   }
   MISTRA_STAMP(t2)
   MISTRA_STAMP_ADD(0, t1 - t0) MISTRA_STAMP_ADD(1, t2 - t1) MISTRA_STAMP_ADD(9, 1)
@@ -817,7 +972,9 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   if (t < NFIX) X[NVAR + t] = G_(a.fix)[(size_t)cell * NFIX + t];
   if (t < NCONST) X[NVAR + NFIX + t] = G_(a.consts)[t];
   if constexpr (MT::DENSE_ND > 0) {      // the dense tail block's row table stays in LDS for the whole call
-    if (t < 192) *(lds_u32x4*)(uintptr_t)(8u * (uint32_t)L::DINFO + 16u * (uint32_t)t) = G_(reinterpret_cast<const u32x4*>(a.dense.row_info))[t];
+    if (t < 64) *(lds_u32x4*)(uintptr_t)(8u * (uint32_t)L::DINFO + 16u * (uint32_t)t) = G_(reinterpret_cast<const u32x4*>(a.dense.row_info))[t];
+    for (int i = t; i < L::SCHUR_WORDS; i += NT)      // the Schur steps' operand cells (uint16 pairs)
+      *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)(8u * (uint32_t)L::SCHUR + 4u * (uint32_t)i) = G_(reinterpret_cast<const uint32_t*>(a.dense.schur_cells))[i];
   }
   if (t == 0) {   // the VM's constant cells: 0.0 (padding update slots), 1.0 (neutral factor), -1.0 (partial-sum combine)
     M[NNZ + NVAR] = 0.0;
@@ -982,7 +1139,18 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
 
   // ---- KppSolve_x (gas.f:6206) on a register vector.  swept = true: XS already holds the forward-swept vector (the LU
   //      program carried the stage-1 right-hand side through the elimination), only the backward half is left.
-  constexpr uint32_t kDenseInfo = MT::DENSE_ND == 64 ? 8u * (uint32_t)L::DINFO : 0u, kZeroCell = 8u * (uint32_t)(NNZ + NVAR);
+  // the tail chain (one wave).  SWEPT: the forward half is done already (stage 1: inside the LU program), up to the dense block's own
+  // columns where the mechanism has one
+  auto tail = [&](auto swept_tag) {
+    constexpr bool SWEPT = decltype(swept_tag)::value;
+    constexpr uint32_t xs_tail = 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), r_tail = 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS);
+    if constexpr (MT::RING_LOW) {
+      static_assert(MT::DENSE_ND == 0, "the column form has no dense-block variant");
+      tail_solve_columns<MT::TAIL_REGS, SWEPT ? MT::TAIL_REGS : 0, true>(a.tail, xs_tail, r_tail, lane);
+    } else {
+      tail_solve<MT::TAIL_REGS, !SWEPT ? 0 : MT::DENSE_ND ? 4 * (MT::TAIL_REGS - 1) : 4 * MT::TAIL_REGS, false>(a.tail, xs_tail, r_tail, lane);
+    }
+  };
   auto solve = [&](double (&k)[SPT], bool swept) {
     for (int i = t; i < a.n_temps; i += NT) M[NNZ + 2 * NVAR + 4 + i] = 0.0;         // partial-sum cells of the head sweeps
     if (!swept) {
@@ -996,11 +1164,11 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       vm_run<NT, MT::VM_SLOTS>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
       lap(8);
       if (wave == 0)                                                                         // tail chain, one wave
-        tail_solve<MT::TAIL_REGS, 0, MT::RING_LOW, kDenseInfo, kZeroCell>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
+        tail(std::false_type{});
     } else {
       lap(6);
       if (wave == 0)      // with the dense tail block the forward chain still has the block's own columns to do
-        tail_solve<MT::TAIL_REGS, MT::DENSE_ND ? MT::TAIL_REGS - 1 : MT::TAIL_REGS, MT::RING_LOW, kDenseInfo, kZeroCell>(a.tail, 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS), lane);
+        tail(std::true_type{});
     }
     lds_barrier();
     lap(9);

@@ -53,8 +53,10 @@ struct LdsLayout {
   static constexpr int AB_TRASH = max_i(MT::NREACT, MT::NB);                           // spare cells, one per lane: products no reaction owns land here
   static constexpr int RED = AB + round_up2(AB_TRASH + 64);                            // (one shared cell: every such store of a wave hit the same address, and LDS serialises those)                             // per-wave partial sums
   static constexpr int FLAGS = RED + 32;
-  static constexpr int DINFO = FLAGS + 2;                                               // dense tail block: row table, 192 x 16 bytes (schedule.hpp: DenseTail)
-  static constexpr int TOTAL = DINFO + (MT::DENSE_ND > 0 ? 192 * 2 : 0);
+  static constexpr int DINFO = FLAGS + 2;                                               // dense tail block: row table of the block's 64 rows, 16 bytes each (schedule.hpp: DenseTail)
+  static constexpr int SCHUR = DINFO + (MT::DENSE_ND > 0 ? 64 * 2 : 0);                 // ... and the Schur steps' operand cells, uint16 x 8 x DENSE_KB x 64
+  static constexpr int SCHUR_WORDS = MT::DENSE_ND > 0 ? 8 * MT::DENSE_KB * 64 / 2 : 0;   // in 32-bit words
+  static constexpr int TOTAL = SCHUR + SCHUR_WORDS / 2;
   // dense_lu's panel buffers live in the A/B product array, which nothing reads between Jac_SP and the next Fun:
   // two buffers of [64][4] panel columns + [64][4] panel rows, two 64-entry broadcast rows of the eliminating wave
   static constexpr int PANEL = AB;

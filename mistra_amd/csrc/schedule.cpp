@@ -633,7 +633,6 @@ DenseTail build_dense_tail(const MechTables& m, const VmLayout& lay, int nd, int
   D.jm = D.h - 4 * kb;
   if (D.jm < 0 || kb < 0) throw std::invalid_argument("more Schur steps than pivots");
   if (D.info_rows() > DenseTail::kInfoRowsMax) throw std::invalid_argument("too many Schur steps for the LDS row table");
-  (void)lay;
   D.row_info.assign((size_t)DenseTail::kInfoRowsMax * 4, 0u);
   auto describe_range = [&](int g, int row, int c0, int c1) {        // slots of `row` with columns in [c0, c1)
     int first = -1, seen = 0;
@@ -660,6 +659,17 @@ DenseTail build_dense_tail(const MechTables& m, const VmLayout& lay, int nd, int
     describe_range(64 + i, D.h + i, D.jm, D.h);
   }
   for (int r = 0; r < 4 * kb; r++) describe_range(128 + r, D.jm + r, D.h, n);
+  // operand cells of the Schur steps in MFMA lane order (schedule.hpp)
+  if (lay.zero() > 0xFFFF) throw std::invalid_argument("Schur cell table needs 16-bit M cells");
+  D.schur_cells.assign((size_t)8 * kb * 64, (uint16_t)lay.zero());
+  auto cell_or_zero = [&](int g, int c) { const int x = D.cell(g, c); return (uint16_t)(x < 0 ? lay.zero() : x); };
+  for (int k = 0; k < kb; k++)
+    for (int lane = 0; lane < 64; lane++) {
+      const int lrow = lane >> 4, lcol = lane & 15;
+      for (int I = 0; I < 4; I++) D.schur_cells[D.schur_w(I, k, lane)] = cell_or_zero(64 + 16 * I + lcol, 4 * k + lrow);
+      for (int half = 0; half < 2; half++)
+        for (int t = 0; t < 2; t++) D.schur_cells[D.schur_u(half, k, t, lane)] = cell_or_zero(128 + 4 * k + lrow, 16 * (2 * half + t) + lcol);
+    }
   return D;
 }
 

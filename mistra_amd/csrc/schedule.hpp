@@ -177,6 +177,15 @@ struct DenseTail {
   //   g = 64 + i    (i < 64)       row h+i, columns [jm, h)     L operands of the Schur steps
   //   g = 128 + r   (r < 4 kb)     row jm+r, columns [h, n)     U operands of the Schur steps
   std::vector<uint32_t> row_info;
+  // The Schur steps' operand cells, resolved on the host (the row-table arithmetic above cost the kernel ~3 000 cycles of address
+  // work per decomposition): uint16 M cells, absent = the 0.0 cell, in the order the MFMA lanes take them (lane l of a wave:
+  // lrow = l>>4, lcol = l&15; wave w: block row I = w>>1, block columns 2(w&1), 2(w&1)+1):
+  //   W part  [I (4)][k (kb)][lane]          cell of (row h + 16I + lcol, column jm + 4k + lrow)          A operand of step k
+  //   U part  [w&1 (2)][k (kb)][t (2)][lane]  cell of (row jm + 4k + lrow, column h + 16(2(w&1) + t) + lcol)   B operand, tile t
+  // The kernel keeps the table in LDS for the whole call (14 336 bytes for kb = 14).
+  std::vector<uint16_t> schur_cells;
+  size_t schur_w(int I, int k, int lane) const { return ((size_t)I * kb + k) * 64 + lane; }
+  size_t schur_u(int half, int k, int t, int lane) const { return (size_t)4 * kb * 64 + (((size_t)half * kb + k) * 2 + t) * 64 + lane; }
   static constexpr int kInfoRowsMax = 192;
   int info_rows() const { return 128 + 4 * kb; }
   int cell(int g, int c) const {                // (host mirror of the kernel's arithmetic) M cell, -1 if absent

@@ -100,6 +100,10 @@ static void write_rec(int m, int nvar, int nfix, int nreact, double tin, double 
   nrec[m]++;
 }
 
+/* C = VAR | FIX as the last INTEGRATE_x call of a mechanism received it (oracle/capture_drive_wrap.f90 asks for it) */
+static double last_c_in[3][424];
+void capture_last_c_in(int mech, double *out) { memcpy(out, last_c_in[mech], sizeof(double) * (size_t)(mech == 0 ? 105 : mech == 1 ? 262 : 424)); }
+
 #define DEF_WRAP(sfx, M, NVAR, NFIX, NREACT)                                                        \
   void __wrap_integrate_##sfx##_(double *tin, double *tout) {                                      \
     if (!inited) init();                                                                            \
@@ -107,6 +111,7 @@ static void write_rec(int m, int nvar, int nfix, int nreact, double tin, double 
     if (reset_dummies) { gdata_##sfx##_.c[3] = 0.0; if (M > 0) gdata_##sfx##_.c[4] = 0.0; }          \
     double t0 = *tin, t1 = *tout;                                                                   \
     static double c_in[NVAR + NFIX];                                                                \
+    memcpy(last_c_in[M], gdata_##sfx##_.c, sizeof c_in);                                            \
     if (keep) memcpy(c_in, gdata_##sfx##_.c, sizeof c_in);                                          \
     __real_integrate_##sfx##_(tin, tout);                                                           \
     nstep_tot[M] += statistics_.nstp;                                                               \

@@ -9,7 +9,7 @@ for V in "$@"; do
   if [ "$V" = env ]; then      # the schedule compiler's A/B switches (MISTRA_DIAG_*), read from the environment -> libdiag_env.so
     hipcc --offload-arch=gfx950 $FLAGS -DMISTRA_DIAG_ENV -c mistra_amd/csrc/capi.cpp -o /tmp/capi_env.o &&
     hipcc --offload-arch=gfx950 $FLAGS -DMISTRA_DIAG_ENV -c mistra_amd/csrc/schedule.cpp -o /tmp/schedule_env.o &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/diaglib/libdiag_env.so mistra_amd/build/ros3_kernel.o /tmp/capi_env.o /tmp/schedule_env.o mistra_amd/build/mech_tables.o mistra_amd/build/rates.o -ldl
+    hipcc --offload-arch=gfx950 -shared -fPIC -o tools/diaglib/libdiag_env.so mistra_amd/build/ros3_kernel.o /tmp/capi_env.o /tmp/schedule_env.o mistra_amd/build/mech_tables.o mistra_amd/build/rates.o mistra_amd/build/pack.o -ldl
     continue
   fi
   case $V in
@@ -19,5 +19,5 @@ for V in "$@"; do
     stampslate) DEF="-DMISTRA_DIAG_STAMPS -DMISTRA_DIAG_LATE_LOADS";;
   esac
   hipcc --offload-arch=gfx950 $FLAGS $DEF -c mistra_amd/csrc/ros3_kernel.hip -o /tmp/ros3_diag_$V.o &&
-  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/diaglib/libdiag_$V.so /tmp/ros3_diag_$V.o mistra_amd/build/capi.o mistra_amd/build/schedule.o mistra_amd/build/mech_tables.o mistra_amd/build/rates.o -ldl
+  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/diaglib/libdiag_$V.so /tmp/ros3_diag_$V.o mistra_amd/build/capi.o mistra_amd/build/schedule.o mistra_amd/build/mech_tables.o mistra_amd/build/rates.o mistra_amd/build/pack.o -ldl
 done
