@@ -69,6 +69,14 @@ def lib():
         L.mistra_chem_update_rconst_device.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mistra_chem_integrate_common.argtypes = [C.c_int, C.c_void_p, _dp, _dp]
         L.mistra_chem_singular_rows.argtypes = [C.c_int, C.c_int, _ip]
+        vp = C.c_void_p
+        L.mistra_chem_set_species_maps.argtypes = [C.c_int, C.c_int, _ip, _ip, C.c_int, _ip, _ip]
+        L.mistra_chem_drive_dims.argtypes = [C.c_int, _ip, _ip, _ip, _ip]
+        L.mistra_chem_pack_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.mistra_chem_unpack_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+        L.mistra_chem_budgets_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp, vp]
+        L.mistra_chem_rates_env_from_c_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp]
+        L.mistra_chem_drive_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp]
         L.mistra_chem_last_error.restype = C.c_char_p
         L.mistra_chem_describe.restype = C.c_char_p
         L.mistra_chem_describe.argtypes = [C.c_int]
@@ -239,3 +247,61 @@ def integrate_into(mech, var, fix, rconst, out, ierr, stats, tin=0.0, tout=10.0,
     first step size per cell instead of the reference's 1e-3 (include/mistra_chem.h: mistra_chem_integrate_device_hstart)."""
     mid, name = _mech_id(mech)
     return _integrate_torch(mid, name, var, fix, rconst, tin, tout, out, ierr, stats, texit_hexit, hstart)
+
+
+# ---- the hand-over halves of x_drive on the device (include/mistra_chem.h; SURVEY.md §8 f2).  torch CUDA tensors, float64, contiguous,
+#      cell-major; everything runs on torch's current stream.
+def set_species_maps(mech, gas_m2k, gas_k2m, rad_m2k, rad_k2m):
+    """The model's species index maps for one mechanism (module gas_common: gas_m2k_x(1:2,j), gas_k2m_x(j), rad_*; 1-based)."""
+    mid, _ = _mech_id(mech)
+    if _inited_device is None:
+        init(0)
+    a = [np.ascontiguousarray(x, np.int32) for x in (gas_m2k, gas_k2m, rad_m2k, rad_k2m)]
+    _check(lib().mistra_chem_set_species_maps(mid, len(a[1]), a[0].ctypes.data_as(_ip), a[1].ctypes.data_as(_ip), len(a[3]),
+                                              a[2].ctypes.data_as(_ip), a[3].ctypes.data_as(_ip)))
+
+
+def drive_dims(mech):
+    """(j2, j6, nkc, nbgs): dimensions of sl1(j2,nkc,n), sion1(j6,nkc,n) and of bgs(2,nbgs,n)"""
+    mid, _ = _mech_id(mech)
+    v = [C.c_int32() for _ in range(4)]
+    _check(lib().mistra_chem_drive_dims(mid, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+def _stream(t):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def pack(mech, s1, s3, sl1, sion1, scal, var, fix):
+    """x_drive up to Update_RCONST_x: var, fix (in/out: entries the driver does not set keep their content) from the layer arrays; sl1 / sion1
+    are clamped in place where the driver does (aer, tot)."""
+    mid, _ = _mech_id(mech)
+    _check(lib().mistra_chem_pack_device(mid, var.shape[0], _p(s1), _p(s3), _p(sl1), _p(sion1), _p(scal), _p(var), _p(fix), _stream(var)))
+
+
+def unpack(mech, var, s1, s3, sl1, sion1):
+    mid, _ = _mech_id(mech)
+    _check(lib().mistra_chem_unpack_device(mid, var.shape[0], _p(var), _p(s1), _p(s3), _p(sl1), _p(sion1), _stream(var)))
+
+
+def budgets(mech, var, fix, rconst, dt, bg=None, bgs=None):
+    mid, _ = _mech_id(mech)
+    _check(lib().mistra_chem_budgets_device(mid, var.shape[0], _p(var), _p(fix), _p(rconst), float(dt), _p(bg), _p(bgs), _stream(var)))
+
+
+def rates_env_from_c(mech, var, fix, env):
+    mid, _ = _mech_id(mech)
+    _check(lib().mistra_chem_rates_env_from_c_device(mid, var.shape[0], _p(var), _p(fix), _p(env), _stream(var)))
+
+
+def drive(mech, s1, s3, sl1, sion1, scal, env, var, fix, tin, dt, ierr, stats, texit_hexit=None, bg=None, bgs=None):
+    """One x_drive per layer for a batch of layers, device-resident: pack -> rates -> INTEGRATE_x(tin, tin + dt) -> budgets -> hand-over."""
+    mid, _ = _mech_id(mech)
+    _check(lib().mistra_chem_drive_device(mid, var.shape[0], _p(s1), _p(s3), _p(sl1), _p(sion1), _p(scal), _p(env), _p(var), _p(fix), float(tin),
+                                          float(dt), _p(ierr), _p(stats), _p(texit_hexit), _p(bg), _p(bgs), _stream(var)))

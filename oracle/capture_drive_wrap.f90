@@ -5,7 +5,8 @@
 ! in Fortran because the layer's data sits in module gas_common (s1, s3 and the species index maps, allocatable) besides the
 ! COMMON blocks.  Around the real driver it records, for the calls selected by MISTRA_CAPTURE_DRIVE_SKIP_x / _EVERY_x / _MAX_x:
 !   before:  the driver's arguments, s1(:,k), s3(:,k), sl1(:,:,k), sion1(:,:,k), the index maps gas_m2k_x / gas_k2m_x / rad_m2k_x / rad_k2m_x
-!   inside:  C = VAR | FIX as x_drive handed it to INTEGRATE_x (oracle/capture_wrap.c keeps the last one: capture_last_c_in)
+!   inside:  C = VAR | FIX as x_drive handed it to INTEGRATE_x (oracle/capture_wrap.c keeps the last one: capture_last_c_in) and the inputs of
+!            its Update_RCONST_x call as MISTRA_RATES_ENV_x packs them (oracle/capture_rates_wrap.c: capture_last_env)
 !   after:   RCONST and C of COMMON /GDATA_x/, s1(:,k), s3(:,k), sl1(:,:,k), sion1(:,:,k), bgs(1:2,:,k) of /budgs/ and, where k is one of
 !            the budget levels il(:), bg(1:2,:,kl) of /budg/
 ! into MISTRA_CAPTURE_DRIVE_FILE (stream of records, see write_record).  No reference source is modified.
@@ -80,7 +81,7 @@ end subroutine capture_drive_budgets
 
 ! record: int32 {magic 'DRIV', mech, k, j1, j5, nvar, nfix, nreact, nargs}, args(nargs) [scalars in call order, then xph_rat(47)],
 !         maps as int32: gas_m2k(2,j1), gas_k2m(j1), rad_m2k(2,j5), rad_k2m(j5),
-!         layer before, bgs/bg before, c_in(nspec), [real driver], rconst(nreact), c_out(nspec), layer after, bgs/bg after
+!         layer before, bgs/bg before, [real driver], c_in(nspec), rconst(nreact), c_out(nspec), env(nenv), layer after, bgs/bg after
 subroutine wrap_gas_drive(tkpp, dt_ch, k, yhal, yiod, yhet1, yhet2, air, h2o, xph_rat) bind(C, name="__wrap_gas_drive_")
   use capture_drive_state
   use gas_common, only: j1, j5, gas_m2k_g, gas_k2m_g, rad_m2k_g, rad_k2m_g
@@ -88,7 +89,7 @@ subroutine wrap_gas_drive(tkpp, dt_ch, k, yhal, yiod, yhet1, yhet2, air, h2o, xp
   double precision :: tkpp, dt_ch, yhal, yiod, yhet1, yhet2, air, h2o, xph_rat(47)
   integer :: k
   integer, parameter :: NVAR = 102, NFIX = 3, NREACT = 331
-  double precision :: C(NVAR + NFIX), RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX, cin(NVAR + NFIX)
+  double precision :: C(NVAR + NFIX), RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX, cin(NVAR + NFIX), env(74)
   common /GDATA_g/ C, RCONST, TIME, DT, ATOL, RTOL, STEPMIN, STEPMAX
   interface
      subroutine real_gas_drive(tkpp, dt_ch, k, yhal, yiod, yhet1, yhet2, air, h2o, xph_rat) bind(C, name="__real_gas_drive_")
@@ -99,6 +100,10 @@ subroutine wrap_gas_drive(tkpp, dt_ch, k, yhal, yiod, yhet1, yhet2, air, h2o, xp
        integer, value :: mech
        double precision :: out(*)
      end subroutine capture_last_c_in
+     subroutine capture_last_env(mech, out) bind(C, name="capture_last_env")
+       integer, value :: mech
+       double precision :: out(*)
+     end subroutine capture_last_env
   end interface
   logical :: keep
   keep = want(1)
@@ -112,7 +117,8 @@ subroutine wrap_gas_drive(tkpp, dt_ch, k, yhal, yiod, yhet1, yhet2, air, h2o, xp
   call real_gas_drive(tkpp, dt_ch, k, yhal, yiod, yhet1, yhet2, air, h2o, xph_rat)
   if (keep) then
      call capture_last_c_in(0, cin)
-     write (unit_out) cin, RCONST, C
+     call capture_last_env(0, env)
+     write (unit_out) cin, RCONST, C, env
      call capture_drive_layer(k, j1, j5)
      call capture_drive_budgets(k, NREACT)
      nrec(1) = nrec(1) + 1
@@ -126,7 +132,7 @@ subroutine wrap_aer_drive(tkpp, dt_ch, k, xcvv1, xcvv2, yhal, yiod, yliq1, yliq2
   double precision :: tkpp, dt_ch, xcvv1, xcvv2, yhal, yiod, yliq1, yliq2, yhet1, yhet2, air, h2o, xph_rat(47)
   integer :: k
   integer, parameter :: NVAR = 257, NFIX = 5, NREACT = 979
-  double precision :: C(NVAR + NFIX), RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX, cin(NVAR + NFIX)
+  double precision :: C(NVAR + NFIX), RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX, cin(NVAR + NFIX), env(330)
   common /GDATA_a/ C, RCONST, TIME, DT, ATOL, RTOL, STEPMIN, STEPMAX
   interface
      subroutine real_aer_drive(tkpp, dt_ch, k, xcvv1, xcvv2, yhal, yiod, yliq1, yliq2, yhet1, yhet2, air, h2o, xph_rat) bind(C, name="__real_aer_drive_")
@@ -137,6 +143,10 @@ subroutine wrap_aer_drive(tkpp, dt_ch, k, xcvv1, xcvv2, yhal, yiod, yliq1, yliq2
        integer, value :: mech
        double precision :: out(*)
      end subroutine capture_last_c_in
+     subroutine capture_last_env(mech, out) bind(C, name="capture_last_env")
+       integer, value :: mech
+       double precision :: out(*)
+     end subroutine capture_last_env
   end interface
   logical :: keep
   keep = want(2)
@@ -150,7 +160,8 @@ subroutine wrap_aer_drive(tkpp, dt_ch, k, xcvv1, xcvv2, yhal, yiod, yliq1, yliq2
   call real_aer_drive(tkpp, dt_ch, k, xcvv1, xcvv2, yhal, yiod, yliq1, yliq2, yhet1, yhet2, air, h2o, xph_rat)
   if (keep) then
      call capture_last_c_in(1, cin)
-     write (unit_out) cin, RCONST, C
+     call capture_last_env(1, env)
+     write (unit_out) cin, RCONST, C, env
      call capture_drive_layer(k, j1, j5)
      call capture_drive_budgets(k, NREACT)
      nrec(2) = nrec(2) + 1
@@ -165,7 +176,7 @@ subroutine wrap_tot_drive(tkpp, dt_ch, k, xcvv1, xcvv2, xcvv3, xcvv4, yhal, yiod
   double precision :: tkpp, dt_ch, xcvv1, xcvv2, xcvv3, xcvv4, yhal, yiod, yliq1, yliq2, yliq3, yliq4, yhet1, yhet2, air, h2o, xph_rat(47)
   integer :: k
   integer, parameter :: NVAR = 417, NFIX = 7, NREACT = 1627
-  double precision :: C(NVAR + NFIX), RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX, cin(NVAR + NFIX)
+  double precision :: C(NVAR + NFIX), RCONST(NREACT), TIME, DT, ATOL(NVAR), RTOL(NVAR), STEPMIN, STEPMAX, cin(NVAR + NFIX), env(544)
   common /GDATA_t/ C, RCONST, TIME, DT, ATOL, RTOL, STEPMIN, STEPMAX
   interface
      subroutine real_tot_drive(tkpp, dt_ch, k, xcvv1, xcvv2, xcvv3, xcvv4, yhal, yiod, yliq1, yliq2, yliq3, yliq4, yhet1, yhet2, air, h2o, xph_rat) &
@@ -177,6 +188,10 @@ subroutine wrap_tot_drive(tkpp, dt_ch, k, xcvv1, xcvv2, xcvv3, xcvv4, yhal, yiod
        integer, value :: mech
        double precision :: out(*)
      end subroutine capture_last_c_in
+     subroutine capture_last_env(mech, out) bind(C, name="capture_last_env")
+       integer, value :: mech
+       double precision :: out(*)
+     end subroutine capture_last_env
   end interface
   logical :: keep
   keep = want(3)
@@ -190,7 +205,8 @@ subroutine wrap_tot_drive(tkpp, dt_ch, k, xcvv1, xcvv2, xcvv3, xcvv4, yhal, yiod
   call real_tot_drive(tkpp, dt_ch, k, xcvv1, xcvv2, xcvv3, xcvv4, yhal, yiod, yliq1, yliq2, yliq3, yliq4, yhet1, yhet2, air, h2o, xph_rat)
   if (keep) then
      call capture_last_c_in(2, cin)
-     write (unit_out) cin, RCONST, C
+     call capture_last_env(2, env)
+     write (unit_out) cin, RCONST, C, env
      call capture_drive_layer(k, j1, j5)
      call capture_drive_budgets(k, NREACT)
      nrec(3) = nrec(3) + 1

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <string.h>
 
 #define DECL(sfx, NVAR, NFIX, NREACT)                                                               \
   extern struct { double c[NVAR + NFIX]; double rconst[NREACT]; double time, dt;                   \
@@ -55,12 +56,16 @@ static int want(int m) {
   return ((n - skip[m]) % every[m]) == 0;
 }
 
+/* the packed inputs of the last Update_RCONST_x call of a mechanism (oracle/capture_drive_wrap.f90 records them with the driver call) */
+static double last_env[3][544];
+void capture_last_env(int mech, double *out) { memcpy(out, last_env[mech], sizeof(double) * (size_t)(mech == 0 ? 74 : mech == 1 ? 330 : 544)); }
+
 #define DEF_WRAP(sfx, M, NVAR, NFIX, NREACT, NENV)                                                 \
   void __wrap_update_rconst_##sfx##_(void) {                                                       \
     if (!inited) init();                                                                            \
-    static double env[NENV];                                                                        \
+    double *env = last_env[M];                                                                      \
     const int keep = want(M);                                                                       \
-    if (keep) mistra_rates_env_##sfx(env);                                                          \
+    mistra_rates_env_##sfx(env);                                                                    \
     __real_update_rconst_##sfx##_();                                                                \
     if (keep) {                                                                                     \
       int32_t h[6] = {0x52415445, M, NENV, NVAR + NFIX, NREACT, (int32_t)(ncall[M] - 1)};          \

@@ -62,6 +62,7 @@ def read_records(path):
         layer("in")
         budgets("in")
         r["c_in"], r["rconst"], r["c_out"] = rd.f64(nvar + nfix), rd.f64(nreact), rd.f64(nvar + nfix)
+        r["env"] = rd.f64({"gas": 74, "aer": 330, "tot": 544}[r["mech"]])      # Update_RCONST_x's inputs as MISTRA_RATES_ENV_x packed them
         layer("out")
         budgets("out")
         recs.append(r)

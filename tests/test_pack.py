@@ -1,0 +1,64 @@
+"""Host logic of the drivers' hand-over halves, CPU: the tables tools/extract_pack.py cuts out of gas_drive / aer_drive /
+tot_drive (with aer_mk.dat / aer_km.dat) and of the budget routines, evaluated by the numpy restatement oracle/pack_py.py, reproduce what
+the RUNNING REFERENCE MODEL did in captured driver calls (tests/golden/drive_<mech>.npz, oracle/capture_drive_wrap.f90) — bit for bit:
+C as handed to INTEGRATE_x, the clamped sl1 / sion1, s1 / s3 / sl1 / sion1 after the hand-over, bg and bgs."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MECHS, REPO
+
+NVAR = {"gas": 102, "aer": 257, "tot": 417}
+NARG = {"gas": 8, "aer": 12, "tot": 16}
+
+
+def scalars(mech, args):
+    """(dt, air, h2o, cvv[4]) from the driver's argument list (gas.f:60-61 | aer.f:59-61 | tot.f:59-61)"""
+    if mech == "gas":      # tkpp, dt_ch, yhal, yiod, yhet1, yhet2, air, h2o
+        return args[1], args[6], args[7], [0.0, 0.0, 0.0, 0.0]
+    if mech == "aer":      # tkpp, dt_ch, xcvv1, xcvv2, yhal, yiod, yliq1, yliq2, yhet1, yhet2, air, h2o
+        return args[1], args[10], args[11], [args[2], args[3], 0.0, 0.0]
+    return args[1], args[14], args[15], list(args[2:6])
+
+
+@pytest.mark.parametrize("mech", MECHS)
+def test_tables_reproduce_captured_driver_calls(mech):
+    from mistra_amd.mechtab import load as load_mech
+    from oracle import pack_py
+    tab, t = pack_py.load(mech), load_mech(mech)
+    g = np.load(os.path.join(REPO, "tests", "golden", "drive_%s.npz" % mech))
+    n = g["c_in"].shape[0]
+    assert n >= 16 and tab["nvar"] == NVAR[mech]
+    nlev = 0
+    for i in range(n):
+        dt, air, h2o, cvv = scalars(mech, g["args"][i])
+        # ---- pack: entries the driver does not set (KPP's dummy products) keep what COMMON held: take them from the capture itself
+        C, L, I = pack_py.pack(tab, g["c_in"][i], g["s1_in"][i], g["s3_in"][i], g["sl1_in"][i], g["sion1_in"][i], air, h2o, cvv, g["gas_m2k"], g["rad_m2k"])
+        assert np.array_equal(C, g["c_in"][i]), "C handed to INTEGRATE_%s differs (call %d)" % (mech[0], i)
+        # (that the pack really writes: a poisoned start must give the same C on every entry the tables name)
+        Cp, _, _ = pack_py.pack(tab, np.full_like(C, -7.0), g["s1_in"][i], g["s3_in"][i], g["sl1_in"][i], g["sion1_in"][i], air, h2o, cvv, g["gas_m2k"], g["rad_m2k"])
+        written = Cp != -7.0
+        assert written.sum() >= len(tab["pack"]) + len(tab["fix"]) and np.array_equal(Cp[written], g["c_in"][i][written])
+        # ---- hand-over
+        s1, s3, L2, I2 = pack_py.unpack(tab, g["c_out"][i], g["s1_in"][i], g["s3_in"][i], L, I, g["gas_k2m"], g["rad_k2m"])
+        for got, key in ((s1, "s1_out"), (s3, "s3_out"), (L2, "sl1_out"), (I2, "sion1_out")):
+            assert np.array_equal(got, g[key][i]), "%s differs (call %d)" % (key, i)
+        # ---- budgets
+        bg, bgs = pack_py.budgets(tab, t, g["c_out"][i], g["rconst"][i], dt, g["bg_in"][i], g["bgs_in"][i])
+        assert np.array_equal(bgs.ravel(), g["bgs_out"][i]), "bgs differs (call %d)" % i
+        if g["level"][i] > 0:
+            nlev += 1
+            assert np.array_equal(bg.ravel(), g["bg_out"][i]), "bg differs (call %d)" % i
+    assert nlev >= 1
+
+
+def test_tables_in_the_repo_are_what_the_extractor_writes(tmp_path):
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("no reference tree here")
+    import subprocess
+    import sys
+    for mech in MECHS:
+        before = open(os.path.join(REPO, "mistra_amd", "mech", mech + ".pack"), "rb").read()
+        subprocess.run([sys.executable, os.path.join(REPO, "tools", "extract_pack.py"), mech], check=True, stdout=subprocess.DEVNULL)
+        assert open(os.path.join(REPO, "mistra_amd", "mech", mech + ".pack"), "rb").read() == before

@@ -87,16 +87,25 @@ def extract(mech):
 
     before, after = driver_body(mech)
     pack, fix, unpack = [], [], []
+    j2_model, _, _ = model_dims()
+    j3_model = int(re.search(r"integer,\s*parameter\s*::\s*j3\s*=\s*(\d+)", open(os.path.join(REF, "global_params.f90"), errors="replace").read()).group(1))
+    IDX = r"(\d+|j2-j3\+\d+)"      # first index of sl1: a literal, or j2-j3+N (the radicals' liquid-phase counterparts behind the j1_fake gases)
+
+    def index(txt):
+        return int(txt) if txt.isdigit() else j2_model - j3_model + int(txt.split("+")[1])
+
     preclamp = any(re.search(r"sl1\(:,:,k\)\s*=\s*max\(0\.d0,\s*sl1\(:,:,k\)\)", l) for _, l in before)
     assert preclamp == any(re.search(r"sion1\(:,:,k\)\s*=\s*max\(0\.d0,\s*sion1\(:,:,k\)\)", l) for _, l in before)
     gas_maps = any("gas_m2k_" in l for _, l in before) and any("gas_k2m_" in l for _, l in after)
     assert gas_maps
     pending_if = None
     for where, l in before:
-        m = re.match(r"\s+C\((ind_\w+)\)\s*=\s*(max\(0\.d0,\s*)?(sl1|sion1)\((\d+),(\d+),k\)\)?\s*$", l)
+        m = re.match(r"\s+C\((ind_\w+)\)\s*=\s*(max\(0\.d0,\s*)?(sl1|sion1)\(" + IDX + r",(\d+),k\)\)?\s*$", l.replace(" ", "").replace("C(", " C(", 1))
         if m:
-            pack.append([cidx(m.group(1)), m.group(3), int(m.group(4)), int(m.group(5)), bool(m.group(2))])
+            pack.append([cidx(m.group(1)), m.group(3), index(m.group(4)), int(m.group(5)), bool(m.group(2))])
             continue
+        if re.search(r"\b(sl1|sion1)\(", l) and not re.search(r"(sl1|sion1)\(:,:,k\)|common|double precision", l):
+            raise ValueError("%s: unrecognised statement with sl1 / sion1: %r" % (where, l))
         m = re.match(r"\s+FIX\((indf_\w+)\)\s*=\s*(.+?)\s*$", l)
         if m:
             name, rhs = m.group(1), m.group(2).replace(" ", "")
@@ -119,9 +128,11 @@ def extract(mech):
         if m:
             pending_if = int(m.group(1))
     for where, l in after:
-        m = re.match(r"\s+(sl1|sion1)\((\d+),(\d+),k\)\s*=\s*(max\(0\.d0,\s*)?C\((ind_\w+)\)\)?\s*$", l)
+        m = re.match(r"\s+(sl1|sion1)\(" + IDX + r",(\d+),k\)\s*=\s*(max\(0\.d0,\s*)?C\((ind_\w+)\)\)?\s*$", " " + l.replace(" ", ""))
         if m:
-            unpack.append([m.group(1), int(m.group(2)), int(m.group(3)), cidx(m.group(5)), bool(m.group(4))])
+            unpack.append([m.group(1), index(m.group(2)), int(m.group(3)), cidx(m.group(5)), bool(m.group(4))])
+        elif re.search(r"\b(sl1|sion1)\(", l):
+            raise ValueError("%s: unrecognised statement with sl1 / sion1: %r" % (where, l))
     # every C index is written at most once by the explicit assignments, every array element at most once by the hand-over
     assert len({p[0] for p in pack}) == len(pack), "a C entry is packed twice"
     assert len({(u[0], u[1], u[2]) for u in unpack}) == len(unpack)
