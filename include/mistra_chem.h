@@ -66,6 +66,13 @@ int mistra_chem_integrate(int mech, int ncell, const double* var_in, const doubl
 int mistra_chem_integrate_ex(int mech, int ncell, const double* var_in, const double* fix, const double* rconst,
                              double tin, double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h);
 
+/* The same from the rate evaluator's inputs instead of the rate constants (mistra_chem_update_rconst below: env [ncell]
+ * [mistra_chem_rates_env_size(mech)], what MISTRA_RATES_ENV_x of shim/mistra_kpp_rates.f90 packs per layer): Update_RCONST_x
+ * (gas.f:172) and INTEGRATE_x (gas.f:173) of x_drive in one call, RCONST made on the device — 74 / 330 / 544 doubles per layer go
+ * up instead of 331 / 979 / 1627. */
+int mistra_chem_integrate_env_ex(int mech, int ncell, const double* var_in, const double* fix, const double* env, double tin,
+                                 double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h);
+
 /* Same call on device-resident buffers (hipMalloc'ed or torch tensors), asynchronous on `hip_stream` (a hipStream_t of
  * that device; NULL = its default stream).  The call runs on the device the buffers live on, which must be one the
  * library was initialised on.  d_ierr (ncell) and d_stats (ncell*8) are required;

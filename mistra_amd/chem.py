@@ -55,6 +55,7 @@ def lib():
         L.mistra_chem_init.argtypes = [C.c_int]
         L.mistra_chem_init_devices.argtypes = [C.c_int, _ip]
         L.mistra_chem_integrate_ex.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip, _dp]
+        L.mistra_chem_integrate_env_ex.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip, _dp]
         L.mistra_chem_integrate_common_status.argtypes = [C.c_int, C.c_void_p, _dp, _dp, _ip, _dp, _dp, _ip]
         L.mistra_chem_finalize.restype = None
         L.mistra_chem_dims.argtypes = [C.c_int, _ip, _ip, _ip, _ip]
@@ -153,7 +154,7 @@ def integrate(mech, var, fix, rconst, tin=0.0, tout=10.0, device=None):
     return IntegrateResult(out, ierr, stats)
 
 
-def integrate_ex(mech, var, fix, rconst, tin=0.0, tout=10.0):
+def integrate_ex(mech, var, fix, rconst, tin=0.0, tout=10.0, env=None):
     """mistra_chem_integrate_ex on host buffers: what `integrate` returns plus t_h [ncell, 3] — per cell the exit time (-> TIN,
     gas.f:769), the last accepted step (-> STEPMIN, gas.f:770) and H when the integrator returned.  This is the call the batched
     Fortran surface makes (shim/mistra_kpp_shim.f90: INTEGRATE_BATCH_x); with several devices initialised (init_devices) the
@@ -165,12 +166,16 @@ def integrate_ex(mech, var, fix, rconst, tin=0.0, tout=10.0):
     v = np.ascontiguousarray(var, np.float64).reshape(-1, nvar)
     ncell = v.shape[0]
     f = np.ascontiguousarray(fix, np.float64).reshape(ncell, nfix)
-    r = np.ascontiguousarray(rconst, np.float64).reshape(ncell, nreact)
+    if env is not None:      # mistra_chem_integrate_env_ex: the rate evaluator's inputs instead of the rate constants
+        r = np.ascontiguousarray(env, np.float64).reshape(ncell, -1)
+        assert r.shape[1] == lib().mistra_chem_rates_env_size(mid)
+    else:
+        r = np.ascontiguousarray(rconst, np.float64).reshape(ncell, nreact)
     out = np.empty_like(v)
     ierr = np.zeros(ncell, np.int32)
     stats = np.zeros((ncell, 8), np.int32)
     th = np.zeros((ncell, 3))
-    _check(lib().mistra_chem_integrate_ex(mid, ncell, v.ctypes.data_as(_dp), f.ctypes.data_as(_dp), r.ctypes.data_as(_dp),
+    _check((lib().mistra_chem_integrate_env_ex if env is not None else lib().mistra_chem_integrate_ex)(mid, ncell, v.ctypes.data_as(_dp), f.ctypes.data_as(_dp), r.ctypes.data_as(_dp),
                                          float(tin), float(tout), out.ctypes.data_as(_dp), ierr.ctypes.data_as(_ip),
                                          stats.ctypes.data_as(_ip), th.ctypes.data_as(_dp)))
     return IntegrateResult(out, ierr, stats), th

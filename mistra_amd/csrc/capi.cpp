@@ -374,8 +374,11 @@ int init_locked(int n, const int* ids) {
 }
 
 // one device's share of a host-buffer call: upload, integrate, download (synchronous on that device)
+// `env` != nullptr: the caller hands over the rate evaluator's inputs instead of the rate constants (rconst is then ignored): RCONST
+// is made on the device and never crosses PCIe
 int integrate_host_on(DeviceState& D, int mech, int ncell, const double* var_in, const double* fix, const double* rconst, double tin,
-                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h, size_t batch_start = 0) {
+                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h, size_t batch_start = 0,
+                      const double* env = nullptr) {
   HIP_TRY(hipSetDevice(D.id));
   MechState& S = D.mech[mech];
   const size_t nv = (size_t)kDims[mech][0], nf = (size_t)kDims[mech][1], nr = (size_t)kDims[mech][2], nc = (size_t)ncell;
@@ -388,7 +391,17 @@ int integrate_host_on(DeviceState& D, int mech, int ncell, const double* var_in,
   if (t_h) HIP_TRY(S.s_th.reserve(nc * 3));
   HIP_TRY(hipMemcpy(S.s_var.p, var_in, nc * nv * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(S.s_fix.p, fix, nc * nf * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(S.s_rct.p, rconst, nc * nr * sizeof(double), hipMemcpyHostToDevice));
+  if (env) {
+    if (!S.rates_ready) return fail(std::string("no device rate table for the ") + kMechName[mech] + " mechanism");
+    const size_t ne = (size_t)S.rates_nenv;
+    HIP_TRY(S.s_env.reserve(nc * ne));
+    HIP_TRY(hipMemcpy(S.s_env.p, env, nc * ne * sizeof(double), hipMemcpyHostToDevice));
+    const RatesDev R{S.rates_consts.p, S.rates_offs.p, S.rates_words.p, S.rates_fslot.p, S.tab.nreact, S.rates_nenv};
+    hipError_t e = launch_update_rconst(R, S.s_env.p, S.s_rct.p, ncell, nullptr);
+    if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
+  } else {
+    HIP_TRY(hipMemcpy(S.s_rct.p, rconst, nc * nr * sizeof(double), hipMemcpyHostToDevice));
+  }
   KernelArgs a = make_args(S, ncell, S.s_var.p, S.s_fix.p, S.s_rct.p, tin, tout, S.s_var.p, S.s_ierr.p, S.s_stats.p, t_h ? S.s_th.p : nullptr);
   if (t_h) a.h_last = S.s_th.p + 2 * nc;
   a.sing_rows = S.s_sing.p;      // stays on the device: fetched by mistra_chem_singular_rows, i.e. only when a cell reports Nsng > 0
@@ -717,18 +730,32 @@ static int lazy_init() {
   return mistra_chem_init(dev ? std::atoi(dev) : 0);
 }
 
+static int integrate_host(int mech, int ncell, const double* var_in, const double* fix, const double* rconst, const double* env, double tin,
+                          double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h);
+
 int mistra_chem_integrate_ex(int mech, int ncell, const double* var_in, const double* fix, const double* rconst, double tin,
                              double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h) {
+  return integrate_host(mech, ncell, var_in, fix, rconst, nullptr, tin, tout, var_out, ierr, stats, t_h);
+}
+
+int mistra_chem_integrate_env_ex(int mech, int ncell, const double* var_in, const double* fix, const double* env, double tin, double tout,
+                                 double* var_out, int32_t* ierr, int32_t* stats, double* t_h) {
+  return integrate_host(mech, ncell, var_in, fix, nullptr, env, tin, tout, var_out, ierr, stats, t_h);
+}
+
+static int integrate_host(int mech, int ncell, const double* var_in, const double* fix, const double* rconst, const double* env, double tin,
+                          double tout, double* var_out, int32_t* ierr, int32_t* stats, double* t_h) {
   if (int rc = lazy_init()) return rc;
   if (int rc = check_call(mech, ncell)) return rc;
   if (ncell == 0) return 0;
-  if (!var_in || !fix || !rconst || !var_out) return fail("null host pointer");
+  if (!var_in || !fix || !var_out || (!rconst && !env)) return fail("null host pointer");
   std::lock_guard<std::mutex> lock(g_mu);
   const size_t nv = (size_t)kDims[mech][0], nf = (size_t)kDims[mech][1], nr = (size_t)kDims[mech][2];
+  const size_t ne = env ? (size_t)g_devs[0].mech[mech].rates_nenv : 0;
   const int ndev = (int)g_devs.size();
   for (auto& d : g_devs) d.mech[mech].sing_count = 0;
   if (ndev == 1 || ncell < 2 * ndev) {
-    int rc = integrate_host_on(g_devs[0], mech, ncell, var_in, fix, rconst, tin, tout, var_out, ierr, stats, t_h);
+    int rc = integrate_host_on(g_devs[0], mech, ncell, var_in, fix, rconst, tin, tout, var_out, ierr, stats, t_h, 0, env);
     (void)hipSetDevice(g_devs[0].id);
     return rc;
   }
@@ -742,8 +769,9 @@ int mistra_chem_integrate_ex(int mech, int ncell, const double* var_in, const do
     const size_t start = (size_t)d * per + (size_t)std::min(d, rem);
     const int count = per + (d < rem ? 1 : 0);
     workers.emplace_back([=, &rcs, &errs]() {
-      rcs[(size_t)d] = integrate_host_on(g_devs[(size_t)d], mech, count, var_in + start * nv, fix + start * nf, rconst + start * nr, tin, tout,
-                                         var_out + start * nv, ierr ? ierr + start : nullptr, stats ? stats + start * 8 : nullptr, t_h ? t_h + start * 3 : nullptr, start);
+      rcs[(size_t)d] = integrate_host_on(g_devs[(size_t)d], mech, count, var_in + start * nv, fix + start * nf, rconst ? rconst + start * nr : nullptr, tin, tout,
+                                         var_out + start * nv, ierr ? ierr + start : nullptr, stats ? stats + start * 8 : nullptr, t_h ? t_h + start * 3 : nullptr, start,
+                                         env ? env + start * ne : nullptr);
       if (rcs[(size_t)d]) errs[(size_t)d] = g_err;      // g_err is thread-local: carry the text to the caller's thread
     });
   }

@@ -30,6 +30,11 @@ static double *gdata_stepmin(int mech) { return mech == 0 ? &gdata_g_.stepmin : 
 
 const char *mistra_chem_last_error(void) { return ""; }
 int mistra_chem_init_devices(int n, const int *ids) { (void)n; (void)ids; return 0; }
+int mistra_chem_integrate_env_ex(int mech, int ncell, const double *v, const double *f, const double *e, double t0, double t1, double *o,
+                                 int32_t *ierr, int32_t *stats, double *t_h) {      /* not used by the two-pass validation (RCONST path) */
+  (void)mech; (void)ncell; (void)v; (void)f; (void)e; (void)t0; (void)t1; (void)o; (void)ierr; (void)stats; (void)t_h;
+  return 1;
+}
 int mistra_chem_singular_rows(int mech, int cell, int32_t *rows8) { (void)mech; (void)cell; (void)rows8; return 0; }   /* never asked: nsng = 0 below */
 
 int mistra_chem_integrate_ex(int mech, int ncell, const double *var_in, const double *fix, const double *rconst, double tin,

@@ -36,6 +36,15 @@ module mistra_chem_c_api
        integer(c_int32_t) :: ierr(*), stats(*)
        integer(c_int) :: rc
      end function mistra_chem_integrate_ex
+     function mistra_chem_integrate_env_ex(mech, ncell, var_in, fix, env, tin, tout, var_out, ierr, stats, t_h) &
+          bind(C, name="mistra_chem_integrate_env_ex") result(rc)
+       import :: c_int, c_double, c_int32_t
+       integer(c_int), value :: mech, ncell
+       real(c_double), value :: tin, tout
+       real(c_double) :: var_in(*), fix(*), env(*), var_out(*), t_h(*)
+       integer(c_int32_t) :: ierr(*), stats(*)
+       integer(c_int) :: rc
+     end function mistra_chem_integrate_env_ex
      function mistra_chem_init_devices(n_devices, device_ids) bind(C, name="mistra_chem_init_devices") result(rc)
        import :: c_int, c_ptr
        integer(c_int), value :: n_devices
@@ -132,18 +141,28 @@ contains
     if (ierr < 0 .or. nsng > 0) call mistra_chem_report(sfx, int(ierr), t_err, h_err, tin_in, int(nsng), mech, 0)
   end subroutine integrate_one
 
-  subroutine integrate_batch(mech, sfx, NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+  ! use_env: RCONST holds the rate evaluator's inputs (MISTRA_RATES_ENV_x) instead of rate constants: Update_RCONST_x runs on the GPU too
+  subroutine integrate_batch(mech, sfx, NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT, use_env)
     integer, intent(in) :: mech, NCELL
     character(len=1), intent(in) :: sfx
+    logical, intent(in), optional :: use_env
+    logical :: env
     real(c_double) :: VAR(*), FIX(*), RCONST(*), TEXIT(NCELL), HEXIT(NCELL)
     real(c_double), intent(in) :: TIN, TOUT
     integer(c_int32_t) :: IERR(NCELL), ISTAT(8, NCELL)
     real(c_double), allocatable :: th(:, :)
     integer :: k
     if (NCELL <= 0) return
+    env = .false.
+    if (present(use_env)) env = use_env
     allocate (th(3, NCELL))
-    if (mistra_chem_integrate_ex(int(mech, c_int), int(NCELL, c_int), VAR, FIX, RCONST, TIN, TOUT, VAR, IERR, ISTAT, th) /= 0) &
-         call mistra_chem_fail('INTEGRATE_BATCH_'//sfx)
+    if (env) then
+       if (mistra_chem_integrate_env_ex(int(mech, c_int), int(NCELL, c_int), VAR, FIX, RCONST, TIN, TOUT, VAR, IERR, ISTAT, th) /= 0) &
+            call mistra_chem_fail('INTEGRATE_BATCH_ENV_'//sfx)
+    else
+       if (mistra_chem_integrate_ex(int(mech, c_int), int(NCELL, c_int), VAR, FIX, RCONST, TIN, TOUT, VAR, IERR, ISTAT, th) /= 0) &
+            call mistra_chem_fail('INTEGRATE_BATCH_'//sfx)
+    end if
     do k = 1, NCELL            ! the messages in layer order, as the serial loop would have written them
        TEXIT(k) = th(1, k)
        HEXIT(k) = th(2, k)
@@ -253,3 +272,35 @@ subroutine INTEGRATE_BATCH_t(NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, I
   integer(c_int32_t) :: IERR(*), ISTAT(8, *)
   call integrate_batch(2, 't', NCELL, VAR, FIX, RCONST, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
 end subroutine INTEGRATE_BATCH_t
+
+! ---- the same from the rate evaluator's inputs: Update_RCONST_x + INTEGRATE_x of NCELL layers in one call, RCONST never on the host.
+!   ENV(nenv_x,NCELL): per layer what MISTRA_RATES_ENV_x (mistra_kpp_rates.f90) packs from the COMMON blocks
+subroutine INTEGRATE_BATCH_ENV_g(NCELL, VAR, FIX, ENV, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+  use iso_c_binding
+  use mistra_chem_c_api
+  implicit none
+  integer :: NCELL
+  real(c_double) :: VAR(102, *), FIX(3, *), ENV(74, *), TIN, TOUT, TEXIT(*), HEXIT(*)
+  integer(c_int32_t) :: IERR(*), ISTAT(8, *)
+  call integrate_batch(0, 'g', NCELL, VAR, FIX, ENV, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT, .true.)
+end subroutine INTEGRATE_BATCH_ENV_g
+
+subroutine INTEGRATE_BATCH_ENV_a(NCELL, VAR, FIX, ENV, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+  use iso_c_binding
+  use mistra_chem_c_api
+  implicit none
+  integer :: NCELL
+  real(c_double) :: VAR(257, *), FIX(5, *), ENV(330, *), TIN, TOUT, TEXIT(*), HEXIT(*)
+  integer(c_int32_t) :: IERR(*), ISTAT(8, *)
+  call integrate_batch(1, 'a', NCELL, VAR, FIX, ENV, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT, .true.)
+end subroutine INTEGRATE_BATCH_ENV_a
+
+subroutine INTEGRATE_BATCH_ENV_t(NCELL, VAR, FIX, ENV, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT)
+  use iso_c_binding
+  use mistra_chem_c_api
+  implicit none
+  integer :: NCELL
+  real(c_double) :: VAR(417, *), FIX(7, *), ENV(544, *), TIN, TOUT, TEXIT(*), HEXIT(*)
+  integer(c_int32_t) :: IERR(*), ISTAT(8, *)
+  call integrate_batch(2, 't', NCELL, VAR, FIX, ENV, TIN, TOUT, TEXIT, HEXIT, IERR, ISTAT, .true.)
+end subroutine INTEGRATE_BATCH_ENV_t

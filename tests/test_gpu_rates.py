@@ -79,3 +79,27 @@ def test_rates_feed_the_integrator_on_the_device(chem, mech, oracles):
     rel = np.abs(res.var.cpu().numpy() - want) / (np.abs(want) + floor)
     print("%s: rates -> integrator on the device, %d model layers, max rel diff %.2e, steps %s" % (mech, n, rel.max(), st[:, 2].tolist()))
     assert rel.max() <= 2e-5
+
+
+@pytest.mark.parametrize("mech", ["gas", "aer", "tot"])
+def test_host_buffer_call_from_the_rate_inputs(chem, mech, oracles):
+    """mistra_chem_integrate_env_ex (what INTEGRATE_BATCH_ENV_x of the Fortran shim calls): VAR, FIX and the rate evaluator's inputs
+    go up, RCONST is made on the device.  Same answers as the oracle with the reference's RCONST of those layers; also through the
+    in-library split over device slots."""
+    g = np.load(os.path.join(REPO, "tests", "golden", "rates_model_%s.npz" % mech))
+    n = min(16, g["env"].shape[0])
+    var, fix, env = g["var"][:n], g["fix"][:n], g["env"][:n]
+    want, ierr, st = oracles[mech].integrate_batch(var, fix, g["rconst"][:n], 0.0, 10.0)
+    res, th = chem.integrate_ex(mech, var, fix, None, 0.0, 10.0, env=env)
+    assert np.array_equal(res.ierr, ierr) and np.array_equal(res.stats, st)
+    floor = 1e-12 * np.abs(want).max(axis=1, keepdims=True)
+    assert (np.abs(res.var - want) / (np.abs(want) + floor)).max() <= 2e-5
+    assert np.allclose(th[:, 0], 10.0, rtol=1e-12)
+    chem.finalize()
+    try:
+        chem.init_devices([0, 0])
+        res2, th2 = chem.integrate_ex(mech, var, fix, None, 0.0, 10.0, env=env)
+        assert np.array_equal(res2.var, res.var) and np.array_equal(res2.stats, res.stats) and np.array_equal(th2, th)
+    finally:
+        chem.finalize()
+        chem.init(0)
