@@ -177,6 +177,22 @@ int mistra_chem_drive_device(int mech, int ncell, double* d_s1, double* d_s3, do
                              double* d_env, double* d_var, double* d_fix, double tin, double dt, int32_t* d_ierr, int32_t* d_stats,
                              double* d_texit_hexit, double* d_bg, double* d_bgs, void* hip_stream);
 
+/* ---- liq_parm, first slice: the gas <-> particle mass-transfer coefficients of fast_k_mt_a (mech = aer;
+ * kpp.f90:2683-2947) and fast_k_mt_t (mech = tot; kpp.f90:2421-2676), called by liq_parm every 120 s (kpp.f90:617,637), for nlayer
+ * layers at once.  Per layer, as the COMMON blocks hold them for that k:
+ *   d_ff [nka][nkt]           ff(1:nkt,1:nka,k) of /cb52/: the 2-D particle spectrum (nkt = nka = 70)
+ *   d_cw, d_cm [nkc]          cw(1:nkc,k), cm(1:nkc,k) of /blck12/ (liquid water content per chemical bin; cm is the activity switch)
+ *   d_freep                   freep(k): mean free path (the routine's argument)
+ *   d_alpha, d_vmean [NSPEC]  alpha(:,k), vmean(:,k) of /kpp_2aer/ | /kpp_2tot/ (accommodation coefficients, mean molecular speeds)
+ *   d_xkmt [nkc][NSPEC]       xkmt(:,1:nkc,k) of /kpp_laer/ | /kpp_ltot/: in/out — written for the 50 exchanged species of the active
+ *                             bins (cm > 0 and cw > 0), everything else left as it is, like the reference
+ * and for the call: d_rq [nka][nkt] = rq(1:nkt,1:nka) of /cb50/ (particle radii, um), kw [nka] (host) and ka of /blck06/, ifeed and
+ * nkc_l of module config.  The summation order is the reference's: bit-identical coefficients.  The LWC-weighted sedimentation
+ * velocity vt(kc,k) that the same routine integrates (consumed by SR sedl, microphysics) is outside this path and not computed. */
+int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const double* d_rq, const int32_t* kw, int ka, int ifeed,
+                                 int nkc_l, const double* d_cw, const double* d_cm, const double* d_freep, const double* d_alpha,
+                                 const double* d_vmean, double* d_xkmt, void* hip_stream);
+
 /* Diagnostics for the phase-level parity tests: integrates the cells like mistra_chem_integrate (results discarded) with the
  * kernel variant that writes out, per cell, the intermediate results of the FIRST attempt of the first Rosenbrock step
  * (gas.f:1201-1262): dump[cell][5*NVAR + 2*LU_NONZERO + 2] = Fcn0 (Fun_x) | Ghimj as ros_PrepareMatrix_x builds it | Ghimj

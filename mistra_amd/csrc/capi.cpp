@@ -100,6 +100,19 @@ bool mistra::PackTable::load(const std::string& path, std::string* err) {
   return ok;
 }
 
+bool mistra::KmtTable::load(const std::string& path, std::string* err) {
+  FILE* f = std::fopen(path.c_str(), "r");
+  if (!f) { if (err) *err = "cannot open " + path; return false; }
+  bool ok = std::fscanf(f, "%d %d %d %d", &nx, &nka, &nkt, &nkc) == 4 && nx > 0 && nx <= 64;
+  if (ok) {
+    lex.resize((size_t)nx);
+    for (int i = 0; ok && i < nx; i++) ok = std::fscanf(f, "%d", &lex[(size_t)i]) == 1;
+  }
+  std::fclose(f);
+  if (!ok && err) *err = path + ": not a species list of fast_k_mt";
+  return ok;
+}
+
 namespace {
 
 struct VmBufs {
@@ -156,6 +169,10 @@ struct MechState {
   DevBuf<int32_t> map_gas_m2k, map_gas_k2m, map_rad_m2k, map_rad_k2m;
   int map_j1 = 0, map_j5 = 0;
   DevBuf<double> d_env, d_rct;      // scratch of mistra_chem_drive_device (grow-only)
+  // fast_k_mt_a / fast_k_mt_t (aer, tot): the exchanged species and the size-axis limits of the last call
+  bool kmt_ready = false;
+  KmtTable kmt_tab;
+  DevBuf<int32_t> kmt_lex, kmt_kw;
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
   DevBuf<int32_t> s_ierr, s_stats, s_sing;
@@ -175,6 +192,7 @@ struct MechState {
     pk_pack.release(); pk_fix.release(); pk_unpack.release(); pk_slot_id.release(); pk_slot_first.release(); pk_terms.release(); pk_words.release();
     pk_acc.release(); pk_envc.release(); pk_aptr.release(); pk_afac.release(); map_gas_m2k.release(); map_gas_k2m.release(); map_rad_m2k.release();
     map_rad_k2m.release(); d_env.release(); d_rct.release(); pack_ready = maps_ready = false;
+    kmt_lex.release(); kmt_kw.release(); kmt_ready = false;
     dense_rows.release(); schur_cells.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); rates_fslot.release(); s_env.release(); rates_ready = false;
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release(); s_sing.release();
     sing_count = 0; sing_one = false;
@@ -298,6 +316,15 @@ int setup_mech(DeviceState& D, int mech) {
       HIP_TRY(S.pk_words.upload(T.term_words)); HIP_TRY(S.pk_acc.upload(T.acc)); HIP_TRY(S.pk_envc.upload(T.envc));
       HIP_TRY(S.pk_aptr.upload(S.tab.a_ptr)); HIP_TRY(S.pk_afac.upload(S.tab.a_fac));
       S.pack_ready = true;
+    }
+  }
+  {   // species list of the mass-transfer routines (aer, tot)
+    std::string kerr;
+    if (S.kmt_tab.load(mech_dir() + "/" + kMechName[mech] + ".kmt", &kerr)) {
+      for (int32_t i : S.kmt_tab.lex)
+        if (i < 1 || i > S.tab.nvar + S.tab.nfix) return fail(std::string(kMechName[mech]) + ".kmt does not belong to this mechanism");
+      HIP_TRY(S.kmt_lex.upload(S.kmt_tab.lex));
+      S.kmt_ready = true;
     }
   }
   S.lu_scale_slots = K.lu_scale.nslots;
@@ -682,6 +709,33 @@ int mistra_chem_drive_device(int mech, int ncell, double* d_s1, double* d_s3, do
   if (int rc = mistra_chem_integrate_device(mech, ncell, d_var, d_fix, S.d_rct.p, tin, tin + dt, d_var, d_ierr, d_stats, d_texit_hexit, hip_stream)) return rc;
   if (d_bg || d_bgs) LAUNCH_TRY(launch_budgets(P, ncell, d_var, d_fix, S.d_rct.p, dt, d_bg, d_bgs, st));
   LAUNCH_TRY(launch_unpack(P, ncell, d_var, d_s1, d_s3, d_sl1, d_sion1, st));
+  return 0;
+}
+
+int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const double* d_rq, const int32_t* kw, int ka, int ifeed, int nkc_l,
+                                 const double* d_cw, const double* d_cm, const double* d_freep, const double* d_alpha, const double* d_vmean,
+                                 double* d_xkmt, void* hip_stream) {
+  if (int rc = check_call(mech, 1)) return rc;
+  if (nlayer == 0) return 0;
+  if (!d_ff || !d_rq || !kw || !d_cw || !d_cm || !d_freep || !d_alpha || !d_vmean || !d_xkmt) return fail("null pointer");
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, d_xkmt) != hipSuccess) return fail("d_xkmt is not a device pointer");
+  DeviceState* D = device_slot(attr.device);
+  if (!D) return fail("the buffers live on a device mistra_chem_init(_devices) did not set up");
+  MechState& S = D->mech[mech];
+  if (!S.kmt_ready) return fail(std::string("the ") + kMechName[mech] + " mechanism has no mass-transfer routine (fast_k_mt_a: aer, fast_k_mt_t: tot)");
+  const KmtTable& T = S.kmt_tab;
+  if (ka < 0 || ka > T.nka || nkc_l < 1 || nkc_l > T.nkc) return fail("ka / nkc_l out of range");
+  std::vector<int32_t> kwv(kw, kw + T.nka);
+  for (int32_t v : kwv)
+    if (v < 0 || v > T.nkt) return fail("kw out of range");      // the kernel's loop limits: checked here, on the host
+  HIP_TRY(hipSetDevice(D->id));
+  std::lock_guard<std::mutex> lock(g_mu);
+  HIP_TRY(S.kmt_kw.reserve(kwv.size()));
+  HIP_TRY(hipMemcpyAsync(S.kmt_kw.p, kwv.data(), kwv.size() * sizeof(int32_t), hipMemcpyHostToDevice, static_cast<hipStream_t>(hip_stream)));
+  HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));      // (kwv is a local)
+  const KmtDev K{S.kmt_lex.p, S.kmt_kw.p, T.nx, T.nka, T.nkt, T.nkc, S.tab.nvar + S.tab.nfix, ka, ifeed, nkc_l};
+  LAUNCH_TRY(launch_fast_k_mt(K, nlayer, d_ff, d_rq, d_cw, d_cm, d_freep, d_alpha, d_vmean, d_xkmt, static_cast<hipStream_t>(hip_stream)));
   return 0;
 }
 

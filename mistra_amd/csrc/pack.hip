@@ -117,7 +117,53 @@ __global__ __launch_bounds__(kNT) void env_from_c_kernel(const PackDev P, int nc
   env[(size_t)cell * nenv + slot] = c0 < P.nvar ? var[(size_t)cell * P.nvar + c0] : fix[(size_t)cell * P.nfix + (c0 - P.nvar)];
 }
 
+// fast_k_mt_a / fast_k_mt_t (kpp.f90:2683-2947 | 2421-2676): the mass-transfer coefficient of every exchanged species l into every
+// active chemical bin kc of a layer, integrated over the bin's part of the 2-D particle spectrum ff(jt,ia):
+//     xk1 = sum_ia sum_jt  vmean / (r/freep + 4/(3 alpha)) * r*r * ff(jt,ia) * 1e6       r = rq(jt,ia)*1e-6 [m]
+//     xkmt(lex(l),kc) = 4 pi / (3 cw(kc)) * xk1                                          where cm(kc) > 0 and cw(kc) > 0
+// One thread per (layer, bin, species) walks its sum in the reference's order (ia outer, jt inner; one rounding per operation), so the
+// coefficients are bit-identical; the lanes of a wave are the species of one (layer, bin): they read the same ff / rq element at a time
+// (broadcast).  The sedimentation velocity vt the routine also integrates (for sedl, microphysics) is not part of this path.
+__global__ __launch_bounds__(64) void fast_k_mt_kernel(const KmtDev K, int nlayer, const double* __restrict__ ff, const double* __restrict__ rq,
+                                                       const double* __restrict__ cw, const double* __restrict__ cm, const double* __restrict__ freep,
+                                                       const double* __restrict__ alpha, const double* __restrict__ vmean, double* __restrict__ xkmt) {
+  const int layer = blockIdx.x, kc = blockIdx.y + 1, l = threadIdx.x;      // kc 1-based as in the Fortran
+  if (layer >= nlayer || kc > K.nkc_l || l >= K.nx) return;
+  const double cmk = cm[(size_t)layer * K.nkc + (kc - 1)], cwk = cw[(size_t)layer * K.nkc + (kc - 1)];
+  if (!(cmk > 0.0)) return;                       // (the dry case only integrates vt)
+  const int sp = K.lex[l] - 1;
+  const double al = alpha[(size_t)layer * K.nspec + sp], vm = vmean[(size_t)layer * K.nspec + sp], fp = freep[layer];
+  double x1 = 0.0, xk1 = 0.0;
+  if (al > 0.0) x1 = 4.0 / (3.0 * al);            // 4./(3.*alpha): default-REAL literals, exact
+  int ia0, ia1;                                   // summation limits (1): the aerosol-size axis, 1-based inclusive
+  if (kc == 1 || kc == 3) { ia0 = K.ifeed == 2 ? 2 : 1; ia1 = K.ka; }
+  else { ia0 = K.ka + 1; ia1 = K.nka; }
+  const double* F = ff + (size_t)layer * K.nka * K.nkt;      // ff(jt,ia,k): jt fastest
+  for (int ia = ia0; ia <= ia1; ia++) {
+    int jt0, jt1;                                 // limits (2): the water axis
+    if (kc == 1 || kc == 2) { jt0 = 1; jt1 = K.kw[ia - 1]; }
+    else { jt0 = K.kw[ia - 1] + 1; jt1 = K.nkt; }
+    for (int jt = jt0; jt <= jt1; jt++) {
+      const double rqq = rq[(size_t)(ia - 1) * K.nkt + (jt - 1)] * 1.0e-6;      // rqm = rq * 1.d-6
+      const double x2 = vm / (rqq / fp + x1);
+      xk1 = xk1 + (((x2 * rqq) * rqq) * F[(size_t)(ia - 1) * K.nkt + (jt - 1)]) * 1.0e6;
+    }
+  }
+  if (cwk > 0.0) {
+    constexpr double z4pi3 = 4.0 * 3.1415926535897932 / 3.0;      // z4pi3 = 4._dp * pi / 3._dp (constants.f90:54)
+    xkmt[((size_t)layer * K.nkc + (kc - 1)) * K.nspec + sp] = z4pi3 / cwk * xk1;
+  }
+}
+
 }  // namespace
+
+hipError_t launch_fast_k_mt(const KmtDev& K, int nlayer, const double* ff, const double* rq, const double* cw, const double* cm, const double* freep,
+                            const double* alpha, const double* vmean, double* xkmt, hipStream_t stream) {
+  if (nlayer <= 0) return hipSuccess;
+  if (K.nx > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fast_k_mt_kernel, dim3((unsigned)nlayer, (unsigned)K.nkc_l), dim3(64), 0, stream, K, nlayer, ff, rq, cw, cm, freep, alpha, vmean, xkmt);
+  return hipGetLastError();
+}
 
 hipError_t launch_pack(const PackDev& P, int ncell, const double* s1, const double* s3, double* sl1, double* sion1, const double* scal,
                        double* var, double* fix, hipStream_t stream) {

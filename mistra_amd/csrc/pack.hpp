@@ -43,3 +43,19 @@ hipError_t launch_budgets(const PackDev& P, int ncell, const double* var, const 
 hipError_t launch_env_from_c(const PackDev& P, int ncell, int nenv, const double* var, const double* fix, double* env, hipStream_t stream);
 
 }  // namespace mistra
+
+// ---- mass-transfer coefficients (kpp.f90: fast_k_mt_a 2683-2947, fast_k_mt_t 2421-2676; SURVEY.md §8 f3, first slice)
+namespace mistra {
+struct KmtTable {
+  int nx = 0, nka = 0, nkt = 0, nkc = 0;
+  std::vector<int32_t> lex;        // C index (1-based) of each exchanged species
+  bool load(const std::string& path, std::string* err);
+};
+struct KmtDev {
+  const int32_t* lex;              // [nx], 1-based
+  const int32_t* kw;               // [nka], as COMMON /blck06/ holds it (1-based jt limits)
+  int nx, nka, nkt, nkc, nspec, ka, ifeed, nkc_l;
+};
+hipError_t launch_fast_k_mt(const KmtDev& K, int nlayer, const double* ff, const double* rq, const double* cw, const double* cm, const double* freep,
+                            const double* alpha, const double* vmean, double* xkmt, hipStream_t stream);
+}  // namespace mistra

@@ -53,6 +53,23 @@ def test_tables_reproduce_captured_driver_calls(mech):
     assert nlev >= 1
 
 
+@pytest.mark.parametrize("mech", ["aer", "tot"])
+def test_mass_transfer_coefficients_of_captured_layers(mech):
+    """SURVEY §8 f3, first slice: xkmt of fast_k_mt_a / fast_k_mt_t (kpp.f90:2683-2947 | 2421-2676) restated in numpy from the extracted
+    species list, on layers captured from the running reference model: bit for bit, untouched entries included."""
+    from oracle import kmt_py
+    tab = kmt_py.load(mech)
+    g = np.load(os.path.join(REPO, "tests", "golden", "kmt_%s.npz" % mech))
+    assert g["ff"].shape[0] >= 4
+    rewritten = 0
+    for i in (0, g["ff"].shape[0] // 2, g["ff"].shape[0] - 1):      # (pure-Python loops: a few layers; the last one has a droplet bin active)
+        got = kmt_py.fast_k_mt_layer(tab, g["ff"][i], g["rq"], g["kw"], int(g["ka"]), int(g["ifeed"]), int(g["nkc_l"]), g["cw"][i], g["cm"][i], float(g["freep"][i]),
+                                     g["alpha"][i], g["vmean"][i], g["xkmt_before"][i])
+        assert np.array_equal(got, g["xkmt_after"][i]), "xkmt of layer k=%d differs" % int(g["k"][i])
+        rewritten += int((got != g["xkmt_before"][i]).sum())
+    assert rewritten > 0
+
+
 def test_tables_in_the_repo_are_what_the_extractor_writes(tmp_path):
     if not os.path.isdir("/root/reference/src"):
         pytest.skip("no reference tree here")
