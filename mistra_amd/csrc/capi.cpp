@@ -265,7 +265,10 @@ int setup_mech(DeviceState& D, int mech) {
   try {
     const int max_temps = mech == MISTRA_MECH_GAS ? GasTraits::MAX_TEMPS : mech == MISTRA_MECH_AER ? AerTraits::MAX_TEMPS : TotTraits::MAX_TEMPS;
     const DenseConfig dc = dense_config(S.tab);
-    K = build_kernel_schedule(S.tab, S.nt, ab_base, max_temps, dc.nd, dc.kb);
+    const uint32_t jb_base = 8u * (uint32_t)(mech == MISTRA_MECH_GAS   ? LdsLayout<GasTraits, kGasNT>::JB
+                                             : mech == MISTRA_MECH_AER ? LdsLayout<AerTraits, kAerNT>::JB
+                                                                       : LdsLayout<TotTraits, kTotNT>::JB);
+    K = build_kernel_schedule(S.tab, S.nt, ab_base, max_temps, dc.nd, dc.kb, jb_base);
   } catch (const std::exception& ex) {
     return fail(std::string("schedule compiler: ") + ex.what());
   }

@@ -85,6 +85,15 @@ __device__ __forceinline__ double wave_uniform(double v) {
   return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
 }
 
+// A constant formed in scalar registers where it is used: hoisted out of the step loop, 0.1 became a vector-register pair the
+// register-starved kernels kept in scratch and re-read three times per step.
+__device__ __forceinline__ double scalar_const(double v) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  uint32_t lo = (uint32_t)u, hi = (uint32_t)(u >> 32);
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
+
 __device__ __forceinline__ double fmin_f(double a, double b) { return (a < b || b != b) ? a : b; }   // Fortran MIN
 __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || b != b) ? a : b; }   // Fortran MAX
 
@@ -131,6 +140,50 @@ __device__ __forceinline__ void vm_ring_load(gptr<u32x4> p) {
     else MISTRA_RING_LOAD(244, 245, 246, 247);
   }
 #undef MISTRA_RING_LOAD
+}
+
+// The same load with the table's base in scalar registers and the lane's 32-bit byte offset in ONE vector register: the row a load
+// fetches is base + ROW KiB.  Rows 0..3 go into the instruction's immediate offset (13 bits signed on gfx950), rows 4..8 take the
+// second base, 4 KiB further on.  (With per-lane 64-bit pointers the compiler kept one 64-bit row offset per load in scalar
+// registers — enough of them to reach the callee-saved ones, whose save area cost tail_solve_columns a scratch store and reload
+// per call: aer's last per-step HBM traffic.)
+struct RingBase { uint64_t b0, b1; };      // b1 = b0 + 4096
+__device__ __forceinline__ RingBase ring_base(const void* p) {
+  const uint64_t u = (uint64_t)(uintptr_t)p;
+  uint32_t lo, hi;
+  // (a scalar register written by a vector instruction may not feed a memory instruction's address for 5 wait states, and the
+  // compiler's hazard pass does not look inside the asm statements that issue the loads: the wait is spelled out here)
+  asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 4" : "=s"(lo), "=s"(hi) : "v"((uint32_t)u), "v"((uint32_t)(u >> 32)));
+  const uint64_t b = (uint64_t)lo | ((uint64_t)hi << 32);
+  return RingBase{b, b + 4096};
+}
+__device__ __forceinline__ void ring_advance(RingBase& r, uint32_t bytes) { r.b0 += bytes; r.b1 += bytes; }
+template <bool LOW, int K, int ROW>
+__device__ __forceinline__ void vm_ring_load_s(const RingBase& r, uint32_t voff) {
+  static_assert(ROW >= 0 && ROW <= 7, "row within the two 4-KiB windows");
+#define MISTRA_RING_LOAD_S(R0, R1, R2, R3)                                                                                    \
+  asm volatile("global_load_dwordx4 v[" #R0 ":" #R3 "], %0, %1 offset:%2" : : "v"(voff), "s"(ROW < 4 ? r.b0 : r.b1), "n"((ROW % 4) * 1024) \
+               : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3)
+  if constexpr (LOW) {
+    if constexpr (K == 0) MISTRA_RING_LOAD_S(64, 65, 66, 67);
+    else if constexpr (K == 1) MISTRA_RING_LOAD_S(68, 69, 70, 71);
+    else if constexpr (K == 2) MISTRA_RING_LOAD_S(80, 81, 82, 83);
+    else if constexpr (K == 3) MISTRA_RING_LOAD_S(84, 85, 86, 87);
+    else if constexpr (K == 4) MISTRA_RING_LOAD_S(96, 97, 98, 99);
+    else if constexpr (K == 5) MISTRA_RING_LOAD_S(100, 101, 102, 103);
+    else if constexpr (K == 6) MISTRA_RING_LOAD_S(112, 113, 114, 115);
+    else MISTRA_RING_LOAD_S(116, 117, 118, 119);
+  } else {
+    if constexpr (K == 0) MISTRA_RING_LOAD_S(192, 193, 194, 195);
+    else if constexpr (K == 1) MISTRA_RING_LOAD_S(196, 197, 198, 199);
+    else if constexpr (K == 2) MISTRA_RING_LOAD_S(208, 209, 210, 211);
+    else if constexpr (K == 3) MISTRA_RING_LOAD_S(212, 213, 214, 215);
+    else if constexpr (K == 4) MISTRA_RING_LOAD_S(224, 225, 226, 227);
+    else if constexpr (K == 5) MISTRA_RING_LOAD_S(228, 229, 230, 231);
+    else if constexpr (K == 6) MISTRA_RING_LOAD_S(240, 241, 242, 243);
+    else MISTRA_RING_LOAD_S(244, 245, 246, 247);
+  }
+#undef MISTRA_RING_LOAD_S
 }
 
 template <bool LOW, int K, int PENDING = 7>
@@ -235,39 +288,28 @@ __device__ __forceinline__ double lane_row_to_all(double v) {
   const auto h32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
   return __builtin_bit_cast(double, (uint64_t)l32[(ROW >> 1) & 1] | ((uint64_t)h32[(ROW >> 1) & 1] << 32));
 }
-// The phases are ONE asm statement each: between separate statements the compiler adds wait states of its own, and masking the
-// operands of step 1 by lane (v_cmp + 2 v_cndmask per value) cost more issue slots than the steps themselves.  The lanes that
-// take step j are selected through EXEC, a scalar move per step that also serves as one of the two wait states the DPP read
-// needs (tools/ubench/dpp.hip): forward the rows i >= j of the block, backward the rows i <= j — row j itself stays enabled
-// because a DPP read of a disabled lane is no read at all; its operand is the diagonal, i.e. the 0.0 cell, so the step leaves it alone.
+// The phases are ONE asm statement each: between separate statements the compiler adds wait states of its own.  Step j of the
+// diagonal block needs no lane selection: every operand that is not a strictly-lower (forward) / strictly-upper (backward) entry of
+// the block points at the 0.0 cell, so the lanes i <= j (i >= j) of the lane row add an exact zero, as the column-by-column chain
+// of the emulator does; row_mask confines the writes to the block's lane row.  The DPP read of the value the previous step wrote
+// needs two wait states, the hardware does not interlock it (tools/ubench/dpp.hip: 10 cycles per dependent step with one, wrong
+// with none).
 #define MISTRA_TAIL_COPS                                                                                                          \
   [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]),     \
       [c8] "v"(c[8]), [c9] "v"(c[9]), [c10] "v"(c[10]), [c11] "v"(c[11]), [c12] "v"(c[12]), [c13] "v"(c[13]), [c14] "v"(c[14]), [c15] "v"(c[15])
-#define MISTRA_DIAG_STEP(J, EXECHALF, MASK) \
-  "s_mov_b32 " EXECHALF ", " MASK "\n\ts_nop 0\n\tv_fmac_f64_dpp %[x], -%[x], %[c" #J "] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"
-#define MISTRA_DIAG_FWD(EXECHALF, OTHERHALF, SH)                                                                                \
-  asm volatile("s_mov_b32 " OTHERHALF ", 0\n\t"                                                                                 \
-               MISTRA_DIAG_STEP(0, EXECHALF, "0xffff" SH) MISTRA_DIAG_STEP(1, EXECHALF, "0xfffe" SH) MISTRA_DIAG_STEP(2, EXECHALF, "0xfffc" SH)   \
-               MISTRA_DIAG_STEP(3, EXECHALF, "0xfff8" SH) MISTRA_DIAG_STEP(4, EXECHALF, "0xfff0" SH) MISTRA_DIAG_STEP(5, EXECHALF, "0xffe0" SH)   \
-               MISTRA_DIAG_STEP(6, EXECHALF, "0xffc0" SH) MISTRA_DIAG_STEP(7, EXECHALF, "0xff80" SH) MISTRA_DIAG_STEP(8, EXECHALF, "0xff00" SH)   \
-               MISTRA_DIAG_STEP(9, EXECHALF, "0xfe00" SH) MISTRA_DIAG_STEP(10, EXECHALF, "0xfc00" SH) MISTRA_DIAG_STEP(11, EXECHALF, "0xf800" SH) \
-               MISTRA_DIAG_STEP(12, EXECHALF, "0xf000" SH) MISTRA_DIAG_STEP(13, EXECHALF, "0xe000" SH) MISTRA_DIAG_STEP(14, EXECHALF, "0xc000" SH) \
-               "s_mov_b64 exec, -1"                                                                                             \
+#define MISTRA_DIAG_STEP(J, RM) "s_nop 1\n\tv_fmac_f64_dpp %[x], -%[x], %[c" #J "] row_newbcast:" #J " row_mask:" RM " bank_mask:0xf\n\t"
+#define MISTRA_DIAG_FWD(RM)                                                                                                     \
+  asm volatile(MISTRA_DIAG_STEP(0, RM) MISTRA_DIAG_STEP(1, RM) MISTRA_DIAG_STEP(2, RM) MISTRA_DIAG_STEP(3, RM) MISTRA_DIAG_STEP(4, RM)   \
+               MISTRA_DIAG_STEP(5, RM) MISTRA_DIAG_STEP(6, RM) MISTRA_DIAG_STEP(7, RM) MISTRA_DIAG_STEP(8, RM) MISTRA_DIAG_STEP(9, RM)   \
+               MISTRA_DIAG_STEP(10, RM) MISTRA_DIAG_STEP(11, RM) MISTRA_DIAG_STEP(12, RM) MISTRA_DIAG_STEP(13, RM) MISTRA_DIAG_STEP(14, RM) \
+               "s_nop 0"                                                                                                        \
                : [x] "+v"(x) : MISTRA_TAIL_COPS)
-// (backward: SHL = "" for the lane row in the low 16 bits of its EXEC half; for the high one the masks are written out shifted)
-#define MISTRA_DIAG_BWD(EXECHALF, OTHERHALF, M15, M14, M13, M12, M11, M10, M9, M8, M7, M6, M5, M4, M3, M2, M1)                   \
-  asm volatile("s_mov_b32 " OTHERHALF ", 0\n\t"                                                                                 \
-               MISTRA_DIAG_STEP(15, EXECHALF, M15) MISTRA_DIAG_STEP(14, EXECHALF, M14) MISTRA_DIAG_STEP(13, EXECHALF, M13)       \
-               MISTRA_DIAG_STEP(12, EXECHALF, M12) MISTRA_DIAG_STEP(11, EXECHALF, M11) MISTRA_DIAG_STEP(10, EXECHALF, M10)       \
-               MISTRA_DIAG_STEP(9, EXECHALF, M9) MISTRA_DIAG_STEP(8, EXECHALF, M8) MISTRA_DIAG_STEP(7, EXECHALF, M7)             \
-               MISTRA_DIAG_STEP(6, EXECHALF, M6) MISTRA_DIAG_STEP(5, EXECHALF, M5) MISTRA_DIAG_STEP(4, EXECHALF, M4)             \
-               MISTRA_DIAG_STEP(3, EXECHALF, M3) MISTRA_DIAG_STEP(2, EXECHALF, M2) MISTRA_DIAG_STEP(1, EXECHALF, M1)             \
-               "s_mov_b64 exec, -1"                                                                                             \
+#define MISTRA_DIAG_BWD(RM)                                                                                                     \
+  asm volatile(MISTRA_DIAG_STEP(15, RM) MISTRA_DIAG_STEP(14, RM) MISTRA_DIAG_STEP(13, RM) MISTRA_DIAG_STEP(12, RM) MISTRA_DIAG_STEP(11, RM) \
+               MISTRA_DIAG_STEP(10, RM) MISTRA_DIAG_STEP(9, RM) MISTRA_DIAG_STEP(8, RM) MISTRA_DIAG_STEP(7, RM) MISTRA_DIAG_STEP(6, RM)     \
+               MISTRA_DIAG_STEP(5, RM) MISTRA_DIAG_STEP(4, RM) MISTRA_DIAG_STEP(3, RM) MISTRA_DIAG_STEP(2, RM) MISTRA_DIAG_STEP(1, RM)      \
+               "s_nop 0"                                                                                                        \
                : [x] "+v"(x) : MISTRA_TAIL_COPS)
-#define MISTRA_DIAG_BWD_LO(EXECHALF, OTHERHALF)                                                                                 \
-  MISTRA_DIAG_BWD(EXECHALF, OTHERHALF, "0xffff", "0x7fff", "0x3fff", "0x1fff", "0xfff", "0x7ff", "0x3ff", "0x1ff", "0xff", "0x7f", "0x3f", "0x1f", "0xf", "0x7", "0x3")
-#define MISTRA_DIAG_BWD_HI(EXECHALF, OTHERHALF)                                                                                 \
-  MISTRA_DIAG_BWD(EXECHALF, OTHERHALF, "0xffff0000", "0x7fff0000", "0x3fff0000", "0x1fff0000", "0xfff0000", "0x7ff0000", "0x3ff0000", "0x1ff0000", "0xff0000", "0x7f0000", "0x3f0000", "0x1f0000", "0xf0000", "0x70000", "0x30000")
 #define MISTRA_UPD_STEP(J, ROWMASK) "v_fmac_f64_dpp %[x], -%[xb], %[c" #J "] row_newbcast:" #J " row_mask:" ROWMASK " bank_mask:0xf\n\t"
 #define MISTRA_UPDATE_FWD(ROWMASK)                                                                                             \
   asm volatile("s_nop 1\n\t"                                                                                                   \
@@ -290,15 +332,15 @@ __device__ __forceinline__ double lane_row_to_all(double v) {
 template <int ROW, bool BACKWARD>
 __device__ __forceinline__ void tail_diag(double& x, const double (&c)[16]) {
   if constexpr (!BACKWARD) {
-    if constexpr (ROW == 0) MISTRA_DIAG_FWD("exec_lo", "exec_hi", "");
-    else if constexpr (ROW == 1) MISTRA_DIAG_FWD("exec_lo", "exec_hi", "0000");
-    else if constexpr (ROW == 2) MISTRA_DIAG_FWD("exec_hi", "exec_lo", "");
-    else MISTRA_DIAG_FWD("exec_hi", "exec_lo", "0000");
+    if constexpr (ROW == 0) MISTRA_DIAG_FWD("0x1");
+    else if constexpr (ROW == 1) MISTRA_DIAG_FWD("0x2");
+    else if constexpr (ROW == 2) MISTRA_DIAG_FWD("0x4");
+    else MISTRA_DIAG_FWD("0x8");
   } else {
-    if constexpr (ROW == 0) MISTRA_DIAG_BWD_LO("exec_lo", "exec_hi");
-    else if constexpr (ROW == 1) MISTRA_DIAG_BWD_HI("exec_lo", "exec_hi");
-    else if constexpr (ROW == 2) MISTRA_DIAG_BWD_LO("exec_hi", "exec_lo");
-    else MISTRA_DIAG_BWD_HI("exec_hi", "exec_lo");
+    if constexpr (ROW == 0) MISTRA_DIAG_BWD("0x1");
+    else if constexpr (ROW == 1) MISTRA_DIAG_BWD("0x2");
+    else if constexpr (ROW == 2) MISTRA_DIAG_BWD("0x4");
+    else MISTRA_DIAG_BWD("0x8");
   }
 }
 // step 3: the lane rows selected by MASK (a 4-bit row mask) take the block column's 16 terms from the broadcast values xb
@@ -314,8 +356,6 @@ __device__ __forceinline__ void tail_update(double& x, const double xb, const do
 #undef MISTRA_DIAG_STEP
 #undef MISTRA_DIAG_FWD
 #undef MISTRA_DIAG_BWD
-#undef MISTRA_DIAG_BWD_LO
-#undef MISTRA_DIAG_BWD_HI
 #undef MISTRA_UPD_STEP
 #undef MISTRA_UPDATE_FWD
 #undef MISTRA_UPDATE_BWD
@@ -448,11 +488,9 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
   constexpr bool FORWARD = FWD_FROM < FWD_END;
   constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
   double x[R], rd[R];
+  const uint32_t voff = 16u * (uint32_t)lane;      // the lane's u32x4 within a table row
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    x[r] = lds_ld(xb + 8 * (r * 64 + lane));
-    rd[r] = lds_ld(rb + 8 * (r * 64 + lane));          // R(k) = 1/U(k,k), published by the LU program
-  }
+  for (int r = 0; r < R; r++) x[r] = lds_ld(xb + 8 * (r * 64 + lane));
   // Matrix entries of a 4-column group are read from LDS one group AHEAD of the chain that uses them (two register
   // buffers, alternating): a lone wave would otherwise expose the LDS latency once per group.  Every row slot is read
   // for every group (rows that take no part point at the 0.0 cell); the arithmetic loops keep their exact row ranges.
@@ -465,14 +503,14 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
   double opa[4][R], opb[4][R];
   // ---- forward: for every tail column q ascending:  x(i) -= L(i,q) * x(q)  for the tail rows i > q
   if constexpr (FORWARD) {
-    gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.fwd)) + lane + FWD_FROM * 16 * 64;      // 16 groups of 4 columns per block
+    RingBase tp = ring_base(T.fwd + FWD_FROM * 16 * 64 * 4);      // 16 groups of 4 columns per block, one u32x4 per lane and group
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-    vm_ring_load<LOW, 0>(tp); vm_ring_load<LOW, 1>(tp + 64); vm_ring_load<LOW, 2>(tp + 128); vm_ring_load<LOW, 3>(tp + 192);
-    vm_ring_load<LOW, 4>(tp + 256); vm_ring_load<LOW, 5>(tp + 320); vm_ring_load<LOW, 6>(tp + 384); vm_ring_load<LOW, 7>(tp + 448);
-    tp += kRingSlots * 64;
+    vm_ring_load_s<LOW, 0, 0>(tp, voff); vm_ring_load_s<LOW, 1, 1>(tp, voff); vm_ring_load_s<LOW, 2, 2>(tp, voff); vm_ring_load_s<LOW, 3, 3>(tp, voff);
+    vm_ring_load_s<LOW, 4, 4>(tp, voff); vm_ring_load_s<LOW, 5, 5>(tp, voff); vm_ring_load_s<LOW, 6, 6>(tp, voff); vm_ring_load_s<LOW, 7, 7>(tp, voff);
+    ring_advance(tp, kRingSlots * 1024);
     {
       const u32x4 first = vm_ring_take<LOW, 0>();
-      vm_ring_load<LOW, 0>(tp);
+      vm_ring_load_s<LOW, 0, 0>(tp, voff);
       MISTRA_TAIL_OPERANDS(opa, first)
     }
 #pragma unroll
@@ -481,7 +519,8 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
 #define MISTRA_TAIL_FWD(K, CUR, NXT)                                                    \
         {                                                                               \
           const u32x4 nxt = vm_ring_take<LOW, (K + 1) % kRingSlots>();                       \
-          vm_ring_load<LOW, (K + 1) % kRingSlots>(tp + (K + 1) * 64);                        \
+          if constexpr (K + 1 == kRingSlots) ring_advance(tp, kRingSlots * 1024);            \
+          vm_ring_load_s<LOW, (K + 1) % kRingSlots, (K + 1) % kRingSlots>(tp, voff);         \
           MISTRA_TAIL_OPERANDS(NXT, nxt)                                                \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const double xq = readlane_f64(x[rq], 4 * (gb + K) + c);                    \
@@ -492,24 +531,27 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
         MISTRA_TAIL_FWD(0, opa, opb) MISTRA_TAIL_FWD(1, opb, opa) MISTRA_TAIL_FWD(2, opa, opb) MISTRA_TAIL_FWD(3, opb, opa)
         MISTRA_TAIL_FWD(4, opa, opb) MISTRA_TAIL_FWD(5, opb, opa) MISTRA_TAIL_FWD(6, opa, opb) MISTRA_TAIL_FWD(7, opb, opa)
 #undef MISTRA_TAIL_FWD
-        tp += kRingSlots * 64;
       }
     }
   }
   // ---- backward, on the row-scaled triangle U' = D^-1 U that the LU program's last phase leaves in the tail block
   //      (schedule.cpp: lu_entries): x = R .* x, then for every tail column q descending  x(i) -= U'(i,q) * x(q)  for the
   //      tail rows i < q.  No quotient on the serial chain: per column it is readlane -> multiply -> subtract.
-#pragma unroll
-  for (int r = 0; r < R; r++) x[r] = x[r] * rd[r];
   {
-    gptr<u32x4> tp = G_(reinterpret_cast<const u32x4*>(T.bwd)) + lane;
+    RingBase tp = ring_base(T.bwd);
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-    vm_ring_load<LOW, 0>(tp); vm_ring_load<LOW, 1>(tp + 64); vm_ring_load<LOW, 2>(tp + 128); vm_ring_load<LOW, 3>(tp + 192);
-    vm_ring_load<LOW, 4>(tp + 256); vm_ring_load<LOW, 5>(tp + 320); vm_ring_load<LOW, 6>(tp + 384); vm_ring_load<LOW, 7>(tp + 448);
-    tp += kRingSlots * 64;
+    vm_ring_load_s<LOW, 0, 0>(tp, voff); vm_ring_load_s<LOW, 1, 1>(tp, voff); vm_ring_load_s<LOW, 2, 2>(tp, voff); vm_ring_load_s<LOW, 3, 3>(tp, voff);
+    vm_ring_load_s<LOW, 4, 4>(tp, voff); vm_ring_load_s<LOW, 5, 5>(tp, voff); vm_ring_load_s<LOW, 6, 6>(tp, voff); vm_ring_load_s<LOW, 7, 7>(tp, voff);
+    ring_advance(tp, kRingSlots * 1024);
+    // R(k) = 1/U(k,k), published by the LU program: fetched here, under the table's first round trip (held through the forward
+    // chain it was the register that pushed this function into a callee-saved one, stored to scratch and reloaded on every call)
+#pragma unroll
+    for (int r = 0; r < R; r++) rd[r] = lds_ld(rb + 8 * (r * 64 + lane));
+#pragma unroll
+    for (int r = 0; r < R; r++) x[r] = x[r] * rd[r];
     {
       const u32x4 first = vm_ring_take<LOW, 0>();
-      vm_ring_load<LOW, 0>(tp);
+      vm_ring_load_s<LOW, 0, 0>(tp, voff);
       MISTRA_TAIL_OPERANDS(opa, first)
     }
 #pragma unroll
@@ -518,7 +560,8 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
 #define MISTRA_TAIL_BWD(K, CUR, NXT)                                                    \
         {                                                                               \
           const u32x4 nxt = vm_ring_take<LOW, (K + 1) % kRingSlots>();                       \
-          vm_ring_load<LOW, (K + 1) % kRingSlots>(tp + (K + 1) * 64);                        \
+          if constexpr (K + 1 == kRingSlots) ring_advance(tp, kRingSlots * 1024);            \
+          vm_ring_load_s<LOW, (K + 1) % kRingSlots, (K + 1) % kRingSlots>(tp, voff);         \
           MISTRA_TAIL_OPERANDS(NXT, nxt)                                                \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const double xq = readlane_f64(x[rq], 63 - (4 * (gb + K) + c));             \
@@ -529,7 +572,6 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
         MISTRA_TAIL_BWD(0, opa, opb) MISTRA_TAIL_BWD(1, opb, opa) MISTRA_TAIL_BWD(2, opa, opb) MISTRA_TAIL_BWD(3, opb, opa)
         MISTRA_TAIL_BWD(4, opa, opb) MISTRA_TAIL_BWD(5, opb, opa) MISTRA_TAIL_BWD(6, opa, opb) MISTRA_TAIL_BWD(7, opb, opa)
 #undef MISTRA_TAIL_BWD
-        tp += kRingSlots * 64;
       }
     }
   }
@@ -909,6 +951,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   double* const XS = M + NNZ;
   double* const X = lds + L::X;
   double* const AB = lds + L::AB;
+  double* const JBp = lds + L::JB;      // Jac_SP's B products: inside the Ghimj area where it is large enough, else the A array (ros3_kernel.hpp)
   double* const red = lds + L::RED;
   int* const flags = reinterpret_cast<int*>(lds + L::FLAGS);
 
@@ -946,7 +989,8 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   auto load_pos = [&]() {
     const uint16_t* jp = a.jvs_pos;
     const uint16_t* zp = a.zero_pos;
-    if constexpr (!RESIDENT) asm volatile("" : "+s"(jp), "+s"(zp));      // opaque: not hoisted out of the step loop
+    int t = threadIdx.x;
+    if constexpr (!RESIDENT) asm volatile("" : "+s"(jp), "+s"(zp), "+v"(t));      // opaque: neither the loads nor the per-thread addresses are hoisted out of the step loop
 #pragma unroll
     for (int q = 0; q < (JPT + 1) / 2; q++)
       jpos[q] = (uint32_t)G_(jp)[(2 * q) * NT + t] | ((2 * q + 1 < JPT ? (uint32_t)G_(jp)[(2 * q + 1) * NT + t] : (uint32_t)kPosNone) << 16);
@@ -1052,8 +1096,12 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     lap(15);
     // sums land in this thread's own cells of XS (free here: the solves copy their result out before Fun runs again);
     // a thread without a species parks its (empty) sum in the trash cell
-    gsum_run<NT, MT::RING_LOW>(a.vdot, wave, lane, t < NVAR ? 8u * (uint32_t)(NNZ + t) : 8u * (uint32_t)(NNZ + NVAR + 2),
-                               t < NVAR ? 8u * (uint32_t)NT : 0u);
+    {
+      int tt = t;
+      if constexpr (!RESIDENT) asm volatile("" : "+v"(tt));      // (derived here: kept across the step loop, the stride was one more register stored to scratch per step)
+      gsum_run<NT, MT::RING_LOW>(a.vdot, wave, lane, tt < NVAR ? 8u * (uint32_t)(NNZ + tt) : 8u * (uint32_t)(NNZ + NVAR + 2),
+                                 tt < NVAR ? 8u * (uint32_t)NT : 0u);
+    }
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
       const int s = q * NT + t;
@@ -1088,7 +1136,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
         double p = rct[q] * f0[b];
         p = p * f1[b];
         p = p * f2[b];
-        AB[(uint32_t)(jfac[q * 3 + b] >> 48)] = p;          // unused product slots write a spare cell: no branch
+        JBp[(uint32_t)(jfac[q * 3 + b] >> 48)] = p;         // unused product slots write a spare cell: no branch
       }
     }
     lds_barrier();
@@ -1096,6 +1144,82 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     // sums land in this thread's own cells of the Ghimj area (free here: ros_PrepareMatrix rebuilds it from jac0)
     gsum_run<NT, MT::RING_LOW>(a.jvs, wave, lane, 8u * (uint32_t)t, 8u * (uint32_t)NT);
     lap(14);
+#pragma unroll
+    for (int q = 0; q < JPT; q++) jac0[q] = M[q * NT + t];
+  };
+
+  // ---- the step's first Fun_x and its Jac_SP_x in one go (both read the same V): the A and the B products are formed in ONE phase — the
+  //      B products have an array of their own inside the Ghimj area — and the two gather-sum programs run back to back.  Two
+  //      barrier phases and one table-stream start-up fewer per step than fun() followed by jac(); operation order inside every
+  //      product and sum unchanged.
+  auto fun_jac = [&](const double (&v)[SPT], double (&out)[SPT]) {
+    uint64_t jfac[3 * RPT];
+    {
+      const uint64_t* jf = a.jac_fac;
+      asm volatile("" : "+s"(jf));      // opaque: loads through it are not hoisted out of the step loop (and spilled there)
+#pragma unroll
+      for (int q = 0; q < 3 * RPT; q++) jfac[q] = G_(jf)[q * NT + t];
+    }
+    if constexpr (!RESIDENT) { load_ffac(); load_rct(true); }
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {
+      const int s = q * NT + t;
+      if (s < NVAR) X[s] = v[q];
+    }
+    lds_barrier();   // X is complete; nobody reads the Ghimj area any more (the last solve's sweeps are behind the error norm's barriers)
+    {
+      double f0[RPT], f1[RPT], f2[RPT];
+      uint32_t slot[RPT];
+#pragma unroll
+      for (int q = 0; q < RPT; q++) {
+        uint64_t w = ffac[q];
+        asm volatile("" : "+v"(w));
+        f0[q] = X[w & 0xFFFFu];
+        f1[q] = X[(w >> 16) & 0xFFFFu];
+        f2[q] = X[(w >> 32) & 0xFFFFu];
+        slot[q] = (uint32_t)(w >> 48);
+      }
+#pragma unroll
+      for (int q = 0; q < RPT; q++) {
+        double p = rct[q] * f0[q];
+        p = p * f1[q];
+        p = p * f2[q];
+        AB[slot[q]] = p;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; q++) {
+      double f0[3], f1[3], f2[3];
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const uint64_t w = jfac[q * 3 + b];
+        f0[b] = X[w & 0xFFFFu];
+        f1[b] = X[(w >> 16) & 0xFFFFu];
+        f2[b] = X[(w >> 32) & 0xFFFFu];
+      }
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        double p = rct[q] * f0[b];
+        p = p * f1[b];
+        p = p * f2[b];
+        JBp[(uint32_t)(jfac[q * 3 + b] >> 48)] = p;
+      }
+    }
+    lds_barrier();
+    lap(13);
+    {
+      int tt = t;
+      if constexpr (!RESIDENT) asm volatile("" : "+v"(tt));
+      gsum_run<NT, MT::RING_LOW>(a.vdot, wave, lane, tt < NVAR ? 8u * (uint32_t)(NNZ + tt) : 8u * (uint32_t)(NNZ + NVAR + 2),
+                                 tt < NVAR ? 8u * (uint32_t)NT : 0u);
+    }
+    gsum_run<NT, MT::RING_LOW>(a.jvs, wave, lane, 8u * (uint32_t)t, 8u * (uint32_t)NT);      // (other cells, another source array: no barrier between)
+    lap(14);
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {
+      const int s = q * NT + t;
+      out[q] = s < NVAR ? XS[s] : 0.0;
+    }
 #pragma unroll
     for (int q = 0; q < JPT; q++) jac0[q] = M[q * NT + t];
   };
@@ -1214,13 +1338,32 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   const double Roundoff = 2.220446049250313e-16, Hmin = 0.0, Hmax = wave_uniform(fabs(Tend - Tstart));
   const double FacMin = 0.2, FacMax = 6.0, FacRej = 0.1, FacSafe = 0.9;
   const double Direction = (Tend >= Tstart) ? 1.0 : -1.0;
-  double T = Tstart, Hexit = 0.0;
+  double T = Tstart;
   // Hstart: INTEGRATE_x fixes RPAR(3) = 1e-3 (gas.f:743).  Opt-in departure from the reference: a caller that keeps
   // each cell's last step size from one chemistry timestep to the next passes it in a.hstart; <= 0 means the reference's value.
   const double hstart0 = (a.hstart && G_(a.hstart)[cell] > 0.0) ? G_(a.hstart)[cell] : 1.0e-3;
-  double H = fmin_f(fmin_f(hstart0, fabs(Tend - Tstart)), Hmax);
-  if (fabs(H) <= 10.0 * Roundoff) H = 1.0e-5;
-  H = wave_uniform(H);
+  // The step size H lives across the whole step loop, and the compiler carried a vector-register copy of it (and of Hexit) around
+  // the loop through scratch: 8-16 bytes per lane and step, stored through to HBM — most of aer's memory traffic in rounds 2 and 3.
+  // So it lives in LDS: one cell per wave behind the error norm's partial sums, written by the wave's lane 0 and read back by the
+  // same wave (LDS operations of a wave complete in order: no barrier is involved); every use below fetches it afresh.  Hexit, which
+  // only thread 0 needs when the integrator returns, sits in the last cell of that block.
+  auto Hget = [&]() -> double {
+    int wv = wave;
+    asm volatile("" : "+v"(wv));
+    return wave_uniform(*(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + 16 + wv)));
+  };
+  auto Hset = [&](double v) {
+    int wv = wave;
+    asm volatile("" : "+v"(wv));
+    if (lane == 0) *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + 16 + wv)) = v;
+  };
+  static_assert(NW <= 15, "red[]: partial sums | H per wave | Hexit");
+  if (t == 0) *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + 31)) = 0.0;
+  {
+    double H0 = fmin_f(fmin_f(hstart0, fabs(Tend - Tstart)), Hmax);
+    if (fabs(H0) <= 10.0 * Roundoff) H0 = 1.0e-5;
+    Hset(H0);
+  }
   bool RejectLastH = false, RejectMoreH = false;
   int nfun = 0, njac = 0, nstp = 0, nacc = 0, nrej = 0, ndec = 0, nsol = 0, nsng = 0;
   int ierr = 1;
@@ -1229,18 +1372,26 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
 
   while (fabs(Tend - T) >= Roundoff) {
     if (nstp > 100000) { ierr = -6; break; }
-    if (((T + 0.1 * H) == T) || (H <= Roundoff)) { ierr = -7; break; }
-    Hexit = H;
-    H = wave_uniform(fmin_f(H, fabs(Tend - T)));
+    {
+      const double H = Hget();
+      if (((T + scalar_const(0.1) * H) == T) || (H <= Roundoff)) { ierr = -7; break; }
+      if (t == 0) *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + 31)) = H;
+      Hset(fmin_f(H, fabs(Tend - T)));
+    }
 
     lap(6);
-    fun(y, fcn0);
-    dump_vec(0, fcn0);
-    lap(0);
+    if constexpr (L::MERGE_FUN_JAC) {
+      fun_jac(y, fcn0);
+      dump_vec(0, fcn0);
+    } else {
+      fun(y, fcn0);
+      dump_vec(0, fcn0);
+      lap(0);
+      jac();
+    }
     // ros_FunTimeDerivative_x (gas.f:1375): Fun_x does not depend on T and RCONST is frozen, so
     // dFdT = (1/Delta)*(Fun - Fcn0) is an exact +0.0; the evaluation is skipped, its count and its "+ HG*0.0" are kept.
     nfun += 2;
-    jac();
     njac += 1;
     lap(1);
 
@@ -1253,7 +1404,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
         int nconsecutive = 0;
         bool singular = true;
         while (singular) {
-          const double ghinv = wave_uniform(1.0 / (Direction * H * kRosGamma1));
+          const double ghinv = wave_uniform(1.0 / (Direction * Hget() * kRosGamma1));
           singular = prepare(ghinv, k1);
           dump_matrix(NVAR);      // Ghimj = 1/(H*gamma) - Jac0
           ndec += 1;
@@ -1271,7 +1422,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
             lds_barrier();   // everyone has read flags[0] (and flags[1]) before the retry clears them
             nsng += 1;
             nconsecutive += 1;
-            if (nconsecutive <= 5) H = wave_uniform(H * 0.5);
+            if (nconsecutive <= 5) Hset(Hget() * 0.5);
             else { ierr = -8; break; }
           } else {
             vm_run<NT, MT::VM_SLOTS>(a.lu, wave, lane);
@@ -1298,7 +1449,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
         }
         if (ierr == -8) break;
       }
-      const double dh = wave_uniform(Direction * H);
+      const double dh = wave_uniform(Direction * Hget());
       // stage 1: its right-hand side went through the LU program above, only the backward half of the solve is left
       lap(6);
       solve(k1, true);
@@ -1339,7 +1490,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       lap(6);
       const double Err = error_norm(y, ynew, yerr);
       if constexpr (DUMP) {
-        if (dumping && t == 0) { dump[5 * NVAR + 2 * NNZ] = Err; dump[5 * NVAR + 2 * NNZ + 1] = H; }
+        if (dumping && t == 0) { dump[5 * NVAR + 2 * NNZ] = Err; dump[5 * NVAR + 2 * NNZ + 1] = Hget(); }
         dumping = false;      // the first attempt only
       }
       lap(5);
@@ -1347,6 +1498,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       if constexpr (MT::WAVES_PER_SIMD > 2) root = err_root(Err);      // register-starved kernels: see err_root
       else root = pow(Err, 1.0 / kRosElo);
       const double Fac = fmin_f(FacMax, fmax_f(FacMin, FacSafe / root));
+      const double H = Hget();
       double Hnew = H * Fac;
       nstp += 1;
       if ((Err <= 1.0) || (H <= Hmin)) {
@@ -1358,13 +1510,13 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
         if (RejectLastH) Hnew = fmin_f(Hnew, H);
         RejectLastH = false;
         RejectMoreH = false;
-        H = wave_uniform(Hnew);
+        Hset(Hnew);
         accepted = true;
       } else {
-        if (RejectMoreH) Hnew = H * FacRej;
+        if (RejectMoreH) Hnew = H * scalar_const(FacRej);
         RejectMoreH = RejectLastH;
         RejectLastH = true;
-        H = wave_uniform(Hnew);
+        Hset(Hnew);
         if (nacc >= 1) nrej += 1;
       }
     }
@@ -1388,9 +1540,9 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     }
     if (a.texit_hexit) {
       GM_(a.texit_hexit)[(size_t)cell * 2] = T;
-      GM_(a.texit_hexit)[(size_t)cell * 2 + 1] = Hexit;
+      GM_(a.texit_hexit)[(size_t)cell * 2 + 1] = *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + 31));
     }
-    if (a.h_last) GM_(a.h_last)[cell] = H;
+    if (a.h_last) GM_(a.h_last)[cell] = Hget();
   }
 }
 

@@ -51,6 +51,12 @@ struct LdsLayout {
   static constexpr int X = M + round_up2(MT::NNZ + 2 * MT::NVAR + 4 + MT::MAX_TEMPS);  // V | F | consts
   static constexpr int AB = X + round_up2(MT::NVAR + MT::NFIX + MT::NCONST);           // A or B products
   static constexpr int AB_TRASH = max_i(MT::NREACT, MT::NB);                           // spare cells, one per lane: products no reaction owns land here
+  // Jac_SP's B products may live INSIDE the Ghimj area instead (dead between a step's start and ros_PrepareMatrix), behind the cells
+  // the JVS sums land in: the step's first Fun and its Jac_SP then form their products in ONE phase and sum them back to back
+  // (ros3_kernel.hip: fun_jac).  Where the area is too small for that (gas) B shares the array of A as before.
+  static constexpr int JVS_CELLS = (MT::NJNZ + NT - 1) / NT * NT;
+  static constexpr bool MERGE_FUN_JAC = JVS_CELLS + round_up2(AB_TRASH + 64) <= MT::NNZ;
+  static constexpr int JB = MERGE_FUN_JAC ? M + JVS_CELLS : AB;                             // base of the B products
   static constexpr int RED = AB + round_up2(AB_TRASH + 64);                            // (one shared cell: every such store of a wave hit the same address, and LDS serialises those)                             // per-wave partial sums
   static constexpr int FLAGS = RED + 32;
   static constexpr int DINFO = FLAGS + 2;                                               // dense tail block: row table of the block's 64 rows, 16 bytes each (schedule.hpp: DenseTail)

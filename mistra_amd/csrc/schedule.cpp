@@ -765,7 +765,8 @@ ScaleProgram build_scale_program(const std::vector<std::pair<int, int>>& pairs, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes, int max_temps, int dense_nd, int dense_kb) {
+KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes, int max_temps, int dense_nd, int dense_kb,
+                                     uint32_t jb_base_bytes) {
   if (nt % 64 != 0 || nt <= 0 || nt > 1024) throw std::invalid_argument("nt must be a multiple of 64 in (0,1024]");
   if (VmLayout{m.nnz, m.nvar, max_temps}.size() * 8 > 160 * 1024) throw std::invalid_argument("mechanism too large for the LDS VM");
   if (m.nx() > 0xFFFF || m.nb >= 0xFFFF || m.nreact > 0xFFFF) throw std::invalid_argument("mechanism too large");
@@ -773,6 +774,7 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   S.nt = nt;
   S.nw = nt / 64;
   S.ab_base_bytes = ab_base_bytes;
+  S.jb_base_bytes = jb_base_bytes ? jb_base_bytes : ab_base_bytes;
   const VmLayout lay{m.nnz, m.nvar, max_temps};                         // M = [Ghimj | XS | 0.0 | 1.0 | trash | -1.0 | R | temps]
   const uint32_t zero_cell_bytes = 8u * (uint32_t)lay.zero();
   S.spt = ceil_div(m.nvar, nt);
@@ -841,7 +843,7 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
       for (int p = m.jv_ptr[k]; p < m.jv_ptr[k + 1]; p++) outs[i].emplace_back(m.jv_idx[(size_t)p], m.jv_coef[(size_t)p]);
       S.jvs_pos[(size_t)slot[i]] = (uint16_t)(k | (is_diag[(size_t)k] ? POS_DIAG : 0));
     }
-    S.jvs = build_gsum_program(outs, slot, S.jpt, nt, ab_base_bytes, zero_cell_bytes);
+    S.jvs = build_gsum_program(outs, slot, S.jpt, nt, S.jb_base_bytes, zero_cell_bytes);
     S.zero_pos.assign((size_t)S.zpt * nt, POS_NONE);
     for (size_t i = 0; i < zero.size(); i++) S.zero_pos[i] = (uint16_t)(zero[i] | (is_diag[(size_t)zero[i]] ? POS_DIAG : 0));
   }

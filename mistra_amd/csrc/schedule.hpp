@@ -206,7 +206,7 @@ struct KernelSchedule {
   int jpt = 0;   // structurally non-zero Jacobian entries per thread
   int zpt = 0;   // structurally zero (fill-in) entries per thread
   int n_jnz = 0, n_jzero = 0;
-  uint32_t ab_base_bytes = 0;
+  uint32_t ab_base_bytes = 0, jb_base_bytes = 0;      // LDS byte addresses of the A products and of the B products (ros3_kernel.hpp: LdsLayout::AB, JB)
   // Fun_x products: A(r) = RCT(r)*X[f1]*X[f2]*X[f3], padded with the constant 1.0
   std::vector<uint64_t> fun_fac;                // [rpt*nt]  f1 | f2<<16 | f3<<32 | out<<48   (out = reaction, or the spare cell max(nreact,nb) for a thread without one)
   GsumProgram vdot;                             // src = A (LDS), output (q,t) = species q*nt+t
@@ -244,8 +244,9 @@ GsumProgram build_gsum_program(const std::vector<std::vector<std::pair<int, doub
                                uint32_t zero_cell_bytes);
 // ab_base_bytes: LDS byte address of the A/B product array the gather-sum tables point into (ros3_kernel.hpp: LdsLayout)
 // dense_nd = 64 with dense_kb Schur steps: the mechanism's last 64 rows are factorised as a dense block (DenseTail)
+// jb_base_bytes: ... of Jac_SP's B products (0: they share the A array)
 KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_base_bytes, int max_temps, int dense_nd = 0,
-                                     int dense_kb = 0);
+                                     int dense_kb = 0, uint32_t jb_base_bytes = 0);
 std::string describe(const KernelSchedule& s);
 
 }  // namespace mistra

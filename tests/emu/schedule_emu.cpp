@@ -399,7 +399,7 @@ void emu_jac_prepare(void* h, const double* V, const double* F, const double* RC
         v = v * X[(w >> 32) & 0xFFFF];
         B[(size_t)out] = v;
       }
-  run_gsum(s.jvs, B, s.ab_base_bytes, 8u * (uint32_t)e->lay().zero(), jac0);
+  run_gsum(s.jvs, B, s.jb_base_bytes, 8u * (uint32_t)e->lay().zero(), jac0);
   for (int i = 0; i < e->m.nnz; i++) G[i] = std::nan("");
   for (size_t i = 0; i < s.jvs_pos.size(); i++) {
     uint16_t p = s.jvs_pos[i];
