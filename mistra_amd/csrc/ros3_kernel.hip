@@ -232,12 +232,14 @@ static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots")
 #include "vm_exec_asm.inc"
 
 template <int NT, int SLOTS>
-__device__ __attribute__((noinline)) void vm_run(const VmDev P, int wave, int lane) {
+__device__ __attribute__((noinline)) void vm_run(const VmDev P, uint32_t row0, int lane) {
   static_assert(SLOTS == 4 || SLOTS == 6 || SLOTS == 8, "ring depths vm_exec_asm.inc is generated for");
   const uint64_t recs = reinterpret_cast<uint64_t>(P.recs);      // the same in every lane: move it to SGPRs
   const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs) |
                         ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(recs >> 32)) << 32);
-  uint32_t va = (uint32_t)G_(P.wave_base)[wave] * 2048u + (uint32_t)lane * 16u;     // this lane's first record (planar rows: lo plane, hi plane + 1024), bytes
+  // row0: the wave's first record row (P.wave_base[wave]; the kernel fetched it when it started — read here it was a memory round
+  // trip in front of the first table load, on every call)
+  uint32_t va = row0 * 2048u + (uint32_t)lane * 16u;     // this lane's first record (planar rows: lo plane, hi plane + 1024), bytes
   uint32_t vb = va + 4096u;                                                          // rows +2, +3
   int rounds = __builtin_amdgcn_readfirstlane(P.nrounds);
   double acc, a1A, r1A, u1A, a2A, r2A, u2A, a1B, r1B, u1B, a2B, r2B, u2B, sc;
@@ -588,9 +590,10 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
 //      address carries GS_ROW_FLUSH completes the lane's current output: it is stored to the lane's next output cell in
 //      LDS (out_addr, then every out_stride bytes) — the caller reads its own cells back, no barrier needed.
 template <int NT, bool LOW>
-__device__ __attribute__((noinline)) void gsum_run(const GsDev P, int wave, int lane, uint32_t out_addr, uint32_t out_stride) {
-  const int n = __builtin_amdgcn_readfirstlane((int)G_(P.rows)[wave]);
-  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)G_(P.wave_base)[wave] * 64 + lane) * 2;
+__device__ __attribute__((noinline)) void gsum_run(const GsDev P, uint32_t row0, int rows, int lane, uint32_t out_addr, uint32_t out_stride) {
+  // row0, rows: P.wave_base[wave] and P.rows[wave], fetched by the kernel when it started (see vm_run)
+  const int n = __builtin_amdgcn_readfirstlane(rows);
+  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)row0 * 64 + lane) * 2;
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
   vm_ring_load<LOW, 0>(rp);       vm_ring_load<LOW, 1, 16>(rp);
   vm_ring_load<LOW, 2>(rp + 128); vm_ring_load<LOW, 3, 16>(rp + 128);
@@ -963,6 +966,20 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     return;
   }
 
+  // ---- where this wave's stream starts in each table program (and how long the gather-sum ones are): the same for the whole
+  //      call, kept in scalar registers
+  struct { uint32_t lu_row0, fwd_row0, bwd_row0, vdot_row0, jvs_row0; int vdot_rows, jvs_rows; } hdr;
+  {
+    const auto u = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    hdr.lu_row0 = u(G_(a.lu.wave_base)[wave]);
+    hdr.fwd_row0 = u(G_(a.solve_head_fwd.wave_base)[wave]);
+    hdr.bwd_row0 = u(G_(a.solve_head_bwd.wave_base)[wave]);
+    hdr.vdot_row0 = u(G_(a.vdot.wave_base)[wave]);
+    hdr.jvs_row0 = u(G_(a.jvs.wave_base)[wave]);
+    hdr.vdot_rows = (int)u(G_(a.vdot.rows)[wave]);
+    hdr.jvs_rows = (int)u(G_(a.jvs.rows)[wave]);
+  }
+
   // ---- per-cell inputs: coalesced cell-major reads, once
   double y[SPT], rct[RPT];
 #pragma unroll
@@ -1099,7 +1116,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     {
       int tt = t;
       if constexpr (!RESIDENT) asm volatile("" : "+v"(tt));      // (derived here: kept across the step loop, the stride was one more register stored to scratch per step)
-      gsum_run<NT, MT::RING_LOW>(a.vdot, wave, lane, tt < NVAR ? 8u * (uint32_t)(NNZ + tt) : 8u * (uint32_t)(NNZ + NVAR + 2),
+      gsum_run<NT, MT::RING_LOW>(a.vdot, hdr.vdot_row0, hdr.vdot_rows, lane, tt < NVAR ? 8u * (uint32_t)(NNZ + tt) : 8u * (uint32_t)(NNZ + NVAR + 2),
                                  tt < NVAR ? 8u * (uint32_t)NT : 0u);
     }
 #pragma unroll
@@ -1142,7 +1159,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     lds_barrier();
     lap(13);
     // sums land in this thread's own cells of the Ghimj area (free here: ros_PrepareMatrix rebuilds it from jac0)
-    gsum_run<NT, MT::RING_LOW>(a.jvs, wave, lane, 8u * (uint32_t)t, 8u * (uint32_t)NT);
+    gsum_run<NT, MT::RING_LOW>(a.jvs, hdr.jvs_row0, hdr.jvs_rows, lane, 8u * (uint32_t)t, 8u * (uint32_t)NT);
     lap(14);
 #pragma unroll
     for (int q = 0; q < JPT; q++) jac0[q] = M[q * NT + t];
@@ -1210,10 +1227,10 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     {
       int tt = t;
       if constexpr (!RESIDENT) asm volatile("" : "+v"(tt));
-      gsum_run<NT, MT::RING_LOW>(a.vdot, wave, lane, tt < NVAR ? 8u * (uint32_t)(NNZ + tt) : 8u * (uint32_t)(NNZ + NVAR + 2),
+      gsum_run<NT, MT::RING_LOW>(a.vdot, hdr.vdot_row0, hdr.vdot_rows, lane, tt < NVAR ? 8u * (uint32_t)(NNZ + tt) : 8u * (uint32_t)(NNZ + NVAR + 2),
                                  tt < NVAR ? 8u * (uint32_t)NT : 0u);
     }
-    gsum_run<NT, MT::RING_LOW>(a.jvs, wave, lane, 8u * (uint32_t)t, 8u * (uint32_t)NT);      // (other cells, another source array: no barrier between)
+    gsum_run<NT, MT::RING_LOW>(a.jvs, hdr.jvs_row0, hdr.jvs_rows, lane, 8u * (uint32_t)t, 8u * (uint32_t)NT);      // (other cells, another source array: no barrier between)
     lap(14);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
@@ -1285,7 +1302,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       }
       lds_barrier();
       lap(6);
-      vm_run<NT, MT::VM_SLOTS>(a.solve_head_fwd, wave, lane);                                          // head rows, all waves
+      vm_run<NT, MT::VM_SLOTS>(a.solve_head_fwd, hdr.fwd_row0, lane);                                          // head rows, all waves
       lap(8);
       if (wave == 0)                                                                         // tail chain, one wave
         tail(std::false_type{});
@@ -1296,7 +1313,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     }
     lds_barrier();
     lap(9);
-    vm_run<NT, MT::VM_SLOTS>(a.solve_head_bwd, wave, lane);
+    vm_run<NT, MT::VM_SLOTS>(a.solve_head_bwd, hdr.bwd_row0, lane);
     lap(10);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
@@ -1425,7 +1442,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
             if (nconsecutive <= 5) Hset(Hget() * 0.5);
             else { ierr = -8; break; }
           } else {
-            vm_run<NT, MT::VM_SLOTS>(a.lu, wave, lane);
+            vm_run<NT, MT::VM_SLOTS>(a.lu, hdr.lu_row0, lane);
             if constexpr (MT::SCALE_PASS) {      // else the scaling is the LU program's last round
               lap(3);
               scale_run<NT, MT::RING_LOW>(a.lu_scale, wave, lane);      // L(k,j) *= R(j); tail block: U(i,c) *= R(i)
