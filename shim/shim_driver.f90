@@ -4,8 +4,13 @@
 !          shim_driver <G|A|T> <in.bin> <out.bin>      the same cells as ONE batched call, INTEGRATE_BATCH_x — the call a two-pass
 !                                                      kpp_driver makes per mechanism and 10-s step (INTEGRATION.md); out.bin then
 !                                                      ends with per cell IERR and the 8 statistics, and the call's wall time in ms
+!          shim_driver <Eg|Ea|Et> <in.bin> <out.bin>   in.bin = ncell, then per cell VAR, FIX, ENV (the vector MISTRA_RATES_ENV_x packs,
+!                                                      mistra_kpp_rates.f90): UPDATE_RCONST_BATCH_x, then INTEGRATE_BATCH_ENV_x (rates and
+!                                                      integrator on the device, RCONST never crosses PCIe); out.bin = per cell VAR,
+!                                                      then per cell IERR + 8 statistics, then per cell RCONST of the first call
 ! After the call the one-cell mode also writes ATOL(1), RTOL(1) (INTEGRATE_x resets them, gas.f:745-746).
 program shim_driver
+  use mistra_kpp_rates
   implicit none
   character(len=256) :: a1, fin, fout
   call get_command_argument(1, a1)
@@ -18,6 +23,13 @@ program shim_driver
   case ('G'); call run_batch(0, 102, 3, 331, trim(fin), trim(fout))
   case ('A'); call run_batch(1, 257, 5, 979, trim(fin), trim(fout))
   case ('T'); call run_batch(2, 417, 7, 1627, trim(fin), trim(fout))
+  case ('E')
+     select case (a1(2:2))
+     case ('g'); call run_env(0, 102, 3, 331, nenv_g, trim(fin), trim(fout))
+     case ('a'); call run_env(1, 257, 5, 979, nenv_a, trim(fin), trim(fout))
+     case ('t'); call run_env(2, 417, 7, 1627, nenv_t, trim(fin), trim(fout))
+     case default; stop 'mechanism must be g, a or t'
+     end select
   case default; stop 'mechanism must be g, a or t'
   end select
 contains
@@ -121,4 +133,46 @@ contains
     write (12) 1.d3 * dble(c1 - c0) / dble(rate)
     close (11); close (12)
   end subroutine run_batch
+  subroutine run_env(mech, NVAR, NFIX, NREACT, NENV, fin, fout)
+    integer, intent(in) :: mech, NVAR, NFIX, NREACT, NENV
+    character(len=*), intent(in) :: fin, fout
+    double precision, allocatable :: VAR(:, :), FIX(:, :), ENV(:, :), RCONST(:, :), TEXIT(:), HEXIT(:), rec(:)
+    integer, allocatable :: IERR(:), ISTAT(:, :)
+    double precision :: rn, tin, tout
+    integer :: n, i
+    open (11, file=fin, access='stream', form='unformatted', status='old')
+    open (12, file=fout, access='stream', form='unformatted', status='replace')
+    read (11) rn
+    n = int(rn)
+    allocate (VAR(NVAR, n), FIX(NFIX, n), ENV(NENV, n), RCONST(NREACT, n), TEXIT(n), HEXIT(n), IERR(n), ISTAT(8, n), rec(NVAR + NFIX + NENV))
+    do i = 1, n
+       read (11) rec
+       VAR(:, i) = rec(1:NVAR)
+       FIX(:, i) = rec(NVAR + 1:NVAR + NFIX)
+       ENV(:, i) = rec(NVAR + NFIX + 1:)
+    end do
+    tin = 0.d0
+    tout = 10.d0
+    select case (mech)
+    case (0)
+       call UPDATE_RCONST_BATCH_g(n, ENV, RCONST)
+       call INTEGRATE_BATCH_ENV_g(n, VAR, FIX, ENV, tin, tout, TEXIT, HEXIT, IERR, ISTAT)
+    case (1)
+       call UPDATE_RCONST_BATCH_a(n, ENV, RCONST)
+       call INTEGRATE_BATCH_ENV_a(n, VAR, FIX, ENV, tin, tout, TEXIT, HEXIT, IERR, ISTAT)
+    case (2)
+       call UPDATE_RCONST_BATCH_t(n, ENV, RCONST)
+       call INTEGRATE_BATCH_ENV_t(n, VAR, FIX, ENV, tin, tout, TEXIT, HEXIT, IERR, ISTAT)
+    end select
+    do i = 1, n
+       write (12) VAR(:, i)
+    end do
+    do i = 1, n
+       write (12) dble(IERR(i)), dble(ISTAT(:, i))
+    end do
+    do i = 1, n
+       write (12) RCONST(:, i)
+    end do
+    close (11); close (12)
+  end subroutine run_env
 end program shim_driver

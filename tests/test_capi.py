@@ -76,3 +76,13 @@ def test_lookahead_ring_registers_are_out_of_the_compilers_reach():
     assert len(dev) >= 9, rep
     low = {k: v for k, v in dev.items() if "Lb1E" in k}
     assert low and max(low.values()) < 64, low      # (ring_register_report has raised already if not)
+
+
+@pytest.mark.parametrize("tool", ["gen_vm_asm.py", "gen_rates_shim.py"])
+def test_generated_sources_are_up_to_date(tool):
+    """mistra_amd/csrc/vm_exec_asm.inc and shim/mistra_kpp_rates.f90 are generator output kept in the tree: what is committed is what
+    the generator writes today."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", tool), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
