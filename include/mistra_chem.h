@@ -193,6 +193,23 @@ int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const
                                  int nkc_l, const double* d_cw, const double* d_cm, const double* d_freep, const double* d_alpha,
                                  const double* d_vmean, double* d_xkmt, void* hip_stream);
 
+/* ---- liq_parm, second slice: the Henry constants of henry_a (mech = aer; kpp.f90:1914-2145) | henry_t (tot;
+ * kpp.f90:1676-1907) and the forward / backward rate constants of the aqueous equilibria of equil_co_a (kpp.f90:3162-3363) | equil_co_t
+ * (kpp.f90:2954-3155), which liq_parm calls every time step (kpp.f90:614-616, 634-636), for nlayer layers at once.  Per layer k:
+ *   d_tt                      tt(k): temperature (/cb53/ t)
+ *   d_henry [NSPEC]           henry(:,k) of /kpp_laer/ | /kpp_ltot/: written whole — the inverse dimensionless constant of the species
+ *                             the routine lists, 0 for the others (NSPEC = NVAR + NFIX)
+ *   d_conv2 [nkc]             conv2(1:nkc,k) of /blck13/ (1/(1000 cw); <= 0 = no liquid water in the bin)
+ *   d_xgamma [nkc][j6]        xgamma(1:j6,1:nkc,k) of /kpp_mol/ (activity coefficients)
+ *   d_xkef, d_xkeb [nkc][NSPEC]   xkef(:,1:nkc,k), xkeb(:,1:nkc,k) of /kpp_laer/ | /kpp_ltot/: in/out — a bin with conv2 <= 0 is zeroed, in
+ *                             the others the listed species are written and the rest left as they are, like the reference; equil_co_a sets
+ *                             bins 1..2 only, equil_co_t all four
+ * The tables (mistra_amd/mech/<mech>.liq) are cut out of the reference source by tools/extract_liq.py; products are formed in the
+ * reference's order, exp is the device library's (last-place differences against the host libm). */
+int mistra_chem_henry_device(int mech, int nlayer, const double* d_tt, double* d_henry, void* hip_stream);
+int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const double* d_tt, const double* d_conv2, const double* d_xgamma,
+                                double* d_xkef, double* d_xkeb, void* hip_stream);
+
 /* Diagnostics for the phase-level parity tests: integrates the cells like mistra_chem_integrate (results discarded) with the
  * kernel variant that writes out, per cell, the intermediate results of the FIRST attempt of the first Rosenbrock step
  * (gas.f:1201-1262): dump[cell][5*NVAR + 2*LU_NONZERO + 2] = Fcn0 (Fun_x) | Ghimj as ros_PrepareMatrix_x builds it | Ghimj

@@ -78,6 +78,8 @@ def lib():
         L.mistra_chem_budgets_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp, vp]
         L.mistra_chem_rates_env_from_c_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp]
         L.mistra_chem_fast_k_mt_device.argtypes = [C.c_int, C.c_int, vp, vp, _ip, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+        L.mistra_chem_henry_device.argtypes = [C.c_int, C.c_int, vp, vp, vp]
+        L.mistra_chem_equil_co_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.mistra_chem_drive_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp]
         L.mistra_chem_last_error.restype = C.c_char_p
         L.mistra_chem_describe.restype = C.c_char_p
@@ -319,3 +321,16 @@ def fast_k_mt(mech, ff, rq, kw, ka, ifeed, nkc_l, cw, cm, freep, alpha, vmean, x
     kwa = np.ascontiguousarray(kw, np.int32)
     _check(lib().mistra_chem_fast_k_mt_device(mid, xkmt.shape[0], _p(ff), _p(rq), kwa.ctypes.data_as(_ip), int(ka), int(ifeed), int(nkc_l), _p(cw), _p(cm),
                                               _p(freep), _p(alpha), _p(vmean), _p(xkmt), _stream(xkmt)))
+
+
+def henry(mech, tt, out):
+    """henry_a (aer) / henry_t (tot) for a batch of layers: out [nlayer, NSPEC] <- tt [nlayer] (include/mistra_chem.h)."""
+    mid, _ = _mech_id(mech)
+    _check(lib().mistra_chem_henry_device(mid, out.shape[0], _p(tt), _p(out), _stream(out)))
+
+
+def equil_co(mech, tt, conv2, xgamma, xkef, xkeb):
+    """equil_co_a (aer) / equil_co_t (tot) for a batch of layers: xkef, xkeb [nlayer, nkc, NSPEC] updated in place from tt [nlayer],
+    conv2 [nlayer, nkc], xgamma [nlayer, nkc, j6] (include/mistra_chem.h)."""
+    mid, _ = _mech_id(mech)
+    _check(lib().mistra_chem_equil_co_device(mid, xkef.shape[0], xkef.shape[1], xgamma.shape[2], _p(tt), _p(conv2), _p(xgamma), _p(xkef), _p(xkeb), _stream(xkef)))

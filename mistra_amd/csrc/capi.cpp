@@ -113,6 +113,41 @@ bool mistra::KmtTable::load(const std::string& path, std::string* err) {
   return ok;
 }
 
+bool mistra::LiqTable::load(const std::string& path, std::string* err) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) { if (err) *err = "cannot open " + path; return false; }
+  int32_t h[8];
+  double d[3];
+  bool ok = std::fread(h, sizeof h, 1, f) == 1 && h[0] == 0x5451494C && h[1] == 1 && h[2] > 0 && h[2] <= 4096 && h[3] >= 0 && h[3] <= h[2] &&
+            h[4] >= 0 && h[4] <= h[2] && h[5] >= 1 && h[5] <= 8 && h[6] >= 0 && h[6] <= 1 << 20 && std::fread(d, sizeof d, 1, f) == 1;
+  std::vector<int32_t> hj, hk, ej;
+  std::vector<double> a0, b0;
+  auto rdi = [&](std::vector<int32_t>& v, size_t n) { v.resize(n); return n == 0 || std::fread(v.data(), 4, n, f) == n; };
+  auto rdd = [&](std::vector<double>& v, size_t n) { v.resize(n); return n == 0 || std::fread(v.data(), 8, n, f) == n; };
+  if (ok) {
+    nspec = h[2]; nh = h[3]; ne = h[4]; nkc_eq = h[5]; nfac = h[6];
+    henry_tref = d[0]; henry_fct = d[1]; equil_tref = d[2];
+    ok = rdi(hj, (size_t)nh) && rdi(hk, (size_t)nh) && rdd(a0, (size_t)nh) && rdd(b0, (size_t)nh) && rdi(ej, (size_t)ne) && rdi(foff, (size_t)ne + 1) &&
+         rdi(boff, (size_t)ne + 1) && rdi(fkind, (size_t)nfac) && rdi(farg, (size_t)nfac) && rdd(fa, (size_t)nfac) && rdd(fb, (size_t)nfac);
+  }
+  std::fclose(f);
+  if (ok) {      // dense per-species forms; every index the kernels follow is checked here
+    h_kind.assign((size_t)nspec, -1); h_a0.assign((size_t)nspec, 0.0); h_b0.assign((size_t)nspec, 0.0); e_of.assign((size_t)nspec, -1);
+    for (int i = 0; ok && i < nh; i++) {
+      ok = hj[(size_t)i] >= 1 && hj[(size_t)i] <= nspec && (hk[(size_t)i] == 0 || hk[(size_t)i] == 1);
+      if (ok) { const size_t j = (size_t)hj[(size_t)i] - 1; h_kind[j] = hk[(size_t)i]; h_a0[j] = a0[(size_t)i]; h_b0[j] = b0[(size_t)i]; }
+    }
+    for (int i = 0; ok && i < ne; i++) {
+      ok = ej[(size_t)i] >= 1 && ej[(size_t)i] <= nspec && foff[(size_t)i] >= 0 && foff[(size_t)i] < boff[(size_t)i] && boff[(size_t)i] < foff[(size_t)i + 1] &&
+           foff[(size_t)i + 1] <= nfac;
+      if (ok) e_of[(size_t)ej[(size_t)i] - 1] = i;
+    }
+    for (int i = 0; ok && i < nfac; i++) ok = fkind[(size_t)i] >= 0 && fkind[(size_t)i] <= 3 && (fkind[(size_t)i] != 3 || (farg[(size_t)i] >= 1 && farg[(size_t)i] <= 4096));
+  }
+  if (!ok && err) *err = path + ": not a table of Henry / equilibrium constants";
+  return ok;
+}
+
 namespace {
 
 struct VmBufs {
@@ -173,6 +208,11 @@ struct MechState {
   bool kmt_ready = false;
   KmtTable kmt_tab;
   DevBuf<int32_t> kmt_lex, kmt_kw;
+  // henry_x / equil_co_x (aer, tot)
+  bool liq_ready = false;
+  LiqTable liq_tab;
+  DevBuf<int32_t> lq_hkind, lq_eof, lq_foff, lq_boff, lq_fkind, lq_farg;
+  DevBuf<double> lq_ha0, lq_hb0, lq_fa, lq_fb;
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
   DevBuf<int32_t> s_ierr, s_stats, s_sing;
@@ -193,6 +233,8 @@ struct MechState {
     pk_acc.release(); pk_envc.release(); pk_aptr.release(); pk_afac.release(); map_gas_m2k.release(); map_gas_k2m.release(); map_rad_m2k.release();
     map_rad_k2m.release(); d_env.release(); d_rct.release(); pack_ready = maps_ready = false;
     kmt_lex.release(); kmt_kw.release(); kmt_ready = false;
+    lq_hkind.release(); lq_eof.release(); lq_foff.release(); lq_boff.release(); lq_fkind.release(); lq_farg.release(); lq_ha0.release(); lq_hb0.release();
+    lq_fa.release(); lq_fb.release(); liq_ready = false;
     dense_rows.release(); schur_cells.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); rates_fslot.release(); s_env.release(); rates_ready = false;
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release(); s_sing.release();
     sing_count = 0; sing_one = false;
@@ -328,6 +370,17 @@ int setup_mech(DeviceState& D, int mech) {
         if (i < 1 || i > S.tab.nvar + S.tab.nfix) return fail(std::string(kMechName[mech]) + ".kmt does not belong to this mechanism");
       HIP_TRY(S.kmt_lex.upload(S.kmt_tab.lex));
       S.kmt_ready = true;
+    }
+  }
+  {   // Henry and equilibrium constants (aer, tot)
+    std::string lerr;
+    LiqTable& T = S.liq_tab;
+    if (T.load(mech_dir() + "/" + kMechName[mech] + ".liq", &lerr)) {
+      if (T.nspec != S.tab.nvar + S.tab.nfix) return fail(std::string(kMechName[mech]) + ".liq does not belong to this mechanism");
+      HIP_TRY(S.lq_hkind.upload(T.h_kind)); HIP_TRY(S.lq_eof.upload(T.e_of)); HIP_TRY(S.lq_foff.upload(T.foff)); HIP_TRY(S.lq_boff.upload(T.boff));
+      HIP_TRY(S.lq_fkind.upload(T.fkind)); HIP_TRY(S.lq_farg.upload(T.farg)); HIP_TRY(S.lq_ha0.upload(T.h_a0)); HIP_TRY(S.lq_hb0.upload(T.h_b0));
+      HIP_TRY(S.lq_fa.upload(T.fa)); HIP_TRY(S.lq_fb.upload(T.fb));
+      S.liq_ready = true;
     }
   }
   S.lu_scale_slots = K.lu_scale.nslots;
@@ -739,6 +792,55 @@ int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));      // (kwv is a local)
   const KmtDev K{S.kmt_lex.p, S.kmt_kw.p, T.nx, T.nka, T.nkt, T.nkc, S.tab.nvar + S.tab.nfix, ka, ifeed, nkc_l};
   LAUNCH_TRY(launch_fast_k_mt(K, nlayer, d_ff, d_rq, d_cw, d_cm, d_freep, d_alpha, d_vmean, d_xkmt, static_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
+namespace {
+// the device slot the buffer lives on and its table of Henry / equilibrium constants
+int liq_state(int mech, const void* d_out, DeviceState** D, MechState** S) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, d_out) != hipSuccess) return fail("the output is not a device pointer");
+  *D = device_slot(attr.device);
+  if (!*D) return fail("the buffers live on a device mistra_chem_init(_devices) did not set up");
+  *S = &(*D)->mech[mech];
+  if (!(*S)->liq_ready) return fail(std::string("the ") + kMechName[mech] + " mechanism has no liquid-phase routines (henry_a / equil_co_a: aer, henry_t / equil_co_t: tot)");
+  return 0;
+}
+LiqDev liq_dev(const MechState& S) {
+  const LiqTable& T = S.liq_tab;
+  return LiqDev{S.lq_hkind.p, S.lq_eof.p, S.lq_foff.p, S.lq_boff.p, S.lq_fkind.p, S.lq_farg.p, S.lq_ha0.p, S.lq_hb0.p, S.lq_fa.p, S.lq_fb.p,
+                T.nspec, T.nkc_eq, T.henry_tref, T.henry_fct, T.equil_tref};
+}
+}  // namespace
+
+int mistra_chem_henry_device(int mech, int nlayer, const double* d_tt, double* d_henry, void* hip_stream) {
+  if (int rc = check_call(mech, 1)) return rc;
+  if (nlayer == 0) return 0;
+  if (nlayer < 0) return fail("nlayer < 0");
+  if (!d_tt || !d_henry) return fail("null pointer");
+  DeviceState* D;
+  MechState* S;
+  if (int rc = liq_state(mech, d_henry, &D, &S)) return rc;
+  HIP_TRY(hipSetDevice(D->id));
+  LAUNCH_TRY(launch_henry(liq_dev(*S), nlayer, d_tt, d_henry, static_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
+int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const double* d_tt, const double* d_conv2, const double* d_xgamma,
+                                double* d_xkef, double* d_xkeb, void* hip_stream) {
+  if (int rc = check_call(mech, 1)) return rc;
+  if (nlayer == 0) return 0;
+  if (nlayer < 0) return fail("nlayer < 0");
+  if (!d_tt || !d_conv2 || !d_xgamma || !d_xkef || !d_xkeb) return fail("null pointer");
+  DeviceState* D;
+  MechState* S;
+  if (int rc = liq_state(mech, d_xkef, &D, &S)) return rc;
+  const LiqTable& T = S->liq_tab;
+  if (nkc < T.nkc_eq) return fail("nkc is smaller than the number of bins the routine sets");
+  for (size_t i = 0; i < T.fkind.size(); i++)
+    if (T.fkind[i] == 3 && T.farg[i] > j6) return fail("j6 is smaller than an activity-coefficient index the routine reads");
+  HIP_TRY(hipSetDevice(D->id));
+  LAUNCH_TRY(launch_equil_co(liq_dev(*S), nlayer, nkc, j6, d_tt, d_conv2, d_xgamma, d_xkef, d_xkeb, static_cast<hipStream_t>(hip_stream)));
   return 0;
 }
 

@@ -157,6 +157,78 @@ __global__ __launch_bounds__(64) void fast_k_mt_kernel(const KmtDev K, int nlaye
 
 }  // namespace
 
+// henry_a | henry_t (kpp.f90:1914-2145 | 1676-1907): one thread per (layer, species).  A species the routine does not set is 0
+// ("k_H = infinity"); a number stays a number, a temperature law is a0*exp(b0*Tfact), Tfact = 1/T - 3.3540d-3; every positive value then
+// becomes the inverse dimensionless constant 1/(k_H * FCT), FCT = 0.0820577*T.  One rounding per operation as in the reference; exp is
+// the device library's (last-place differences against the host libm, like the rate laws).
+__global__ __launch_bounds__(256) void henry_kernel(const LiqDev L, int nlayer, const double* __restrict__ tt, double* __restrict__ henry) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (j >= L.nspec || k >= nlayer) return;
+  const double T = tt[k];
+  const int kind = L.h_kind[j];
+  double h = 0.0;
+  if (kind == 0) h = L.h_a0[j];
+  else if (kind == 1) {
+    const double tfact = 1.0 / T - L.henry_tref;
+    h = L.h_a0[j] * exp(L.h_b0[j] * tfact);
+  }
+  if (h > 0.0) {
+    const double fct = L.henry_fct * T;
+    h = 1.0 / (h * fct);
+  }
+  henry[(size_t)k * L.nspec + j] = h;
+}
+
+// equil_co_a | equil_co_t (kpp.f90:3162-3363 | 2954-3155): one thread per (layer, bin, species).  A bin without liquid water
+// (conv2 <= 0) is zeroed for every species; elsewhere the species the routine sets get the left-to-right product of their factors
+// (number | funa(a0,b0) = a0*exp(b0*(1/T - 3.354d-3)) | conv2 | xgamma(i)) and the others keep what they hold.
+__device__ double liq_product(const LiqDev& L, int first, int last, double T, double cv2, const double* __restrict__ xg) {
+  double v = 0.0;
+  for (int f = first; f < last; f++) {
+    const int kind = L.fkind[f];
+    double x;
+    if (kind == 0) x = L.fa[f];
+    else if (kind == 1) x = L.fa[f] * exp(L.fb[f] * (1.0 / T - L.equil_tref));
+    else if (kind == 2) x = cv2;
+    else x = xg[L.farg[f] - 1];
+    v = f == first ? x : v * x;
+  }
+  return v;
+}
+__global__ __launch_bounds__(256) void equil_co_kernel(const LiqDev L, int nlayer, int nkc, int j6, const double* __restrict__ tt,
+                                                        const double* __restrict__ conv2, const double* __restrict__ xgamma,
+                                                        double* __restrict__ xkef, double* __restrict__ xkeb) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, kc = blockIdx.y, k = blockIdx.z;
+  if (j >= L.nspec || kc >= L.nkc_eq || k >= nlayer) return;
+  const double cv2 = conv2[(size_t)k * nkc + kc];
+  const size_t at = ((size_t)k * nkc + kc) * L.nspec + j;
+  if (!(cv2 > 0.0)) {
+    xkef[at] = 0.0;
+    xkeb[at] = 0.0;
+    return;
+  }
+  const int e = L.e_of[j];
+  if (e < 0) return;
+  const double T = tt[k];
+  const double* xg = xgamma + ((size_t)k * nkc + kc) * j6;
+  xkef[at] = liq_product(L, L.foff[e], L.boff[e], T, cv2, xg);
+  xkeb[at] = liq_product(L, L.boff[e], L.foff[e + 1], T, cv2, xg);
+}
+
+hipError_t launch_henry(const LiqDev& L, int nlayer, const double* tt, double* henry, hipStream_t stream) {
+  if (nlayer <= 0) return hipSuccess;
+  hipLaunchKernelGGL(henry_kernel, dim3((unsigned)((L.nspec + 255) / 256), (unsigned)nlayer), dim3(256), 0, stream, L, nlayer, tt, henry);
+  return hipGetLastError();
+}
+hipError_t launch_equil_co(const LiqDev& L, int nlayer, int nkc, int j6, const double* tt, const double* conv2, const double* xgamma, double* xkef,
+                           double* xkeb, hipStream_t stream) {
+  if (nlayer <= 0) return hipSuccess;
+  if (nlayer > 65535) return hipErrorInvalidValue;      // (grid z)
+  hipLaunchKernelGGL(equil_co_kernel, dim3((unsigned)((L.nspec + 255) / 256), (unsigned)L.nkc_eq, (unsigned)nlayer), dim3(256), 0, stream, L, nlayer, nkc,
+                     j6, tt, conv2, xgamma, xkef, xkeb);
+  return hipGetLastError();
+}
+
 hipError_t launch_fast_k_mt(const KmtDev& K, int nlayer, const double* ff, const double* rq, const double* cw, const double* cm, const double* freep,
                             const double* alpha, const double* vmean, double* xkmt, hipStream_t stream) {
   if (nlayer <= 0) return hipSuccess;

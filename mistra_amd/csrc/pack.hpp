@@ -59,3 +59,26 @@ struct KmtDev {
 hipError_t launch_fast_k_mt(const KmtDev& K, int nlayer, const double* ff, const double* rq, const double* cw, const double* cm, const double* freep,
                             const double* alpha, const double* vmean, double* xkmt, hipStream_t stream);
 }  // namespace mistra
+
+// ---- Henry constants and equilibrium rate constants (kpp.f90: henry_a 1914-2145, henry_t 1676-1907, equil_co_a 3162-3363,
+//      equil_co_t 2954-3155).  Tables: mistra_amd/mech/<mech>.liq, written by tools/extract_liq.py.
+namespace mistra {
+struct LiqTable {
+  int nspec = 0, nh = 0, ne = 0, nkc_eq = 0, nfac = 0;
+  double henry_tref = 0, henry_fct = 0, equil_tref = 0;
+  // dense per-species forms the kernels index by species: henry kind (-1 not set, 0 number, 1 temperature law), a0, b0;
+  // equil entry of the species (-1: the routine does not set it)
+  std::vector<int32_t> h_kind, e_of, foff, boff, fkind, farg;
+  std::vector<double> h_a0, h_b0, fa, fb;
+  bool load(const std::string& path, std::string* err);
+};
+struct LiqDev {
+  const int32_t *h_kind, *e_of, *foff, *boff, *fkind, *farg;
+  const double *h_a0, *h_b0, *fa, *fb;
+  int nspec, nkc_eq;
+  double henry_tref, henry_fct, equil_tref;
+};
+hipError_t launch_henry(const LiqDev& L, int nlayer, const double* tt, double* henry, hipStream_t stream);
+hipError_t launch_equil_co(const LiqDev& L, int nlayer, int nkc, int j6, const double* tt, const double* conv2, const double* xgamma, double* xkef,
+                           double* xkeb, hipStream_t stream);
+}  // namespace mistra

@@ -1,0 +1,69 @@
+"""liq_parm, second slice, on the device (-m gpu): the Henry constants of henry_a / henry_t (kpp.f90:1914-2145 | 1676-1907)
+and the equilibrium rate constants of equil_co_a / equil_co_t (kpp.f90:3162-3363 | 2954-3155) from mistra_chem_henry_device /
+mistra_chem_equil_co_device, against layers captured from the RUNNING reference model (tests/golden/liq_<mech>.npz).  Entries that are
+numbers or products of numbers, conv2 and activity coefficients come out bit for bit; where exp is involved the device library's exp
+differs from the host libm's in the last place: 1e-14 relative, stated here."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-14
+
+
+def _rel(a, b):
+    nz = b != 0.0
+    return float((np.abs(a[nz] - b[nz]) / np.abs(b[nz])).max()) if nz.any() else 0.0
+
+
+@pytest.mark.parametrize("mech", ["aer", "tot"])
+def test_henry_and_equilibrium_constants_on_the_device(mech):
+    import json
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from mistra_amd import chem
+    chem.init(0)
+    dev = torch.device("cuda", 0)
+    g = np.load(os.path.join(REPO, "tests", "golden", "liq_%s.npz" % mech))
+    tab = json.load(open(os.path.join(REPO, "mistra_amd", "mech", mech + ".liq.json")))
+    T = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    # ---- henry_x: the whole array is written (a poisoned buffer comes back clean)
+    want = g["henry"]
+    out = torch.full(want.shape, float("nan"), dtype=torch.float64, device=dev)
+    chem.henry(mech, T(g["henry_tt"]), out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got == 0.0, want == 0.0) and np.isfinite(got).all()
+    plain = np.array([j - 1 for j, _, b0 in tab["henry"]["entries"] if b0 is None])
+    assert np.array_equal(got[:, plain], want[:, plain])                                   # number / (number * T): no library function
+    assert _rel(got, want) <= TOL
+    # ---- equil_co_x: in/out arrays, bins with and without liquid water
+    ef, eb = T(g["xkef_before"]), T(g["xkeb_before"])
+    chem.equil_co(mech, T(g["equil_tt"]), T(g["conv2"]), T(g["xgamma"]), ef, eb)
+    torch.cuda.synchronize()
+    gf, gb = ef.cpu().numpy(), eb.cpu().numpy()
+    for got, want in ((gf, g["xkef"]), (gb, g["xkeb"])):
+        assert np.array_equal(got == 0.0, want == 0.0)
+        assert _rel(got, want) <= TOL
+    nkc_eq = tab["equil"]["nkc"]
+    dry = g["conv2"][:, :nkc_eq] <= 0
+    assert dry.any() and (gf[:, :nkc_eq][dry] == 0).all() and (gb[:, :nkc_eq][dry] == 0).all()
+    # what the routine does not set is untouched: species without an entry in wet bins, and (aer) the bins it never visits
+    listed = np.zeros(gf.shape[2], bool)
+    listed[[e[0] - 1 for e in tab["equil"]["entries"]]] = True
+    wet = ~dry
+    for got, before in ((gf, g["xkef_before"]), (gb, g["xkeb_before"])):
+        assert np.array_equal(got[:, :nkc_eq][wet][:, ~listed], before[:, :nkc_eq][wet][:, ~listed])
+        assert np.array_equal(got[:, nkc_eq:], before[:, nkc_eq:])
+    # entries without exp: bit for bit
+    noexp_f = np.array([e[0] - 1 for e in tab["equil"]["entries"] if not any(f[0] == "funa" for f in e[1])])
+    noexp_b = np.array([e[0] - 1 for e in tab["equil"]["entries"] if not any(f[0] == "funa" for f in e[2])])
+    assert np.array_equal(gf[:, :, noexp_f], g["xkef"][:, :, noexp_f]) and np.array_equal(gb[:, :, noexp_b], g["xkeb"][:, :, noexp_b])
+    print("%s: henry of %d layers (max rel %.1e), xkef / xkeb of %d layers (%.1e / %.1e) against the running model" %
+          (mech, got.shape[0], _rel(out.cpu().numpy(), g["henry"]), gf.shape[0], _rel(gf, g["xkef"]), _rel(gb, g["xkeb"])))
+    # gas has no such routines: the calls fail loudly
+    with pytest.raises(chem.MistraChemError):
+        chem.henry("gas", T(g["henry_tt"]), out)

@@ -70,6 +70,28 @@ def test_mass_transfer_coefficients_of_captured_layers(mech):
     assert rewritten > 0
 
 
+@pytest.mark.parametrize("mech", ["aer", "tot"])
+def test_henry_and_equilibrium_constants_of_captured_layers(mech):
+    """SURVEY §8 f3, second slice: henry_a/t (kpp.f90:1914-2145 | 1676-1907) and equil_co_a/t (kpp.f90:3162-3363 | 2954-3155) restated from
+    the tables tools/extract_liq.py cuts out of them, on layers captured from the running reference model (tests/golden/liq_<mech>.npz:
+    16 layers of two calls, bins with and without liquid water): bit for bit, the entries the routines leave alone included."""
+    from oracle import liq_py
+    tab = liq_py.load(mech)
+    g = np.load(os.path.join(REPO, "tests", "golden", "liq_%s.npz" % mech))
+    assert len(g["henry_k"]) >= 8 and len(g["equil_k"]) >= 8
+    for i in range(len(g["henry_k"])):
+        got = liq_py.henry_layer(tab, float(g["henry_tt"][i]))
+        assert np.array_equal(got, g["henry"][i]), "henry of layer k=%d differs" % int(g["henry_k"][i])
+    assert (g["henry"] > 0).sum(axis=1).min() == sum(1 for e in tab["henry"]["entries"] if e[1] > 0.0)      # (four of the 57 listed constants are 0.)
+    wet = dry = 0
+    for i in range(len(g["equil_k"])):
+        ef, eb = liq_py.equil_co_layer(tab, float(g["equil_tt"][i]), g["conv2"][i], g["xgamma"][i], g["xkef_before"][i], g["xkeb_before"][i])
+        assert np.array_equal(ef, g["xkef"][i]) and np.array_equal(eb, g["xkeb"][i]), "xkef / xkeb of layer k=%d differ" % int(g["equil_k"][i])
+        wet += int((g["conv2"][i][:tab["equil"]["nkc"]] > 0).sum())
+        dry += int((g["conv2"][i][:tab["equil"]["nkc"]] <= 0).sum())
+    assert wet >= 8 and dry >= 2      # both branches of the routine are in the capture
+
+
 def test_tables_in_the_repo_are_what_the_extractor_writes(tmp_path):
     if not os.path.isdir("/root/reference/src"):
         pytest.skip("no reference tree here")
@@ -79,3 +101,4 @@ def test_tables_in_the_repo_are_what_the_extractor_writes(tmp_path):
         before = open(os.path.join(REPO, "mistra_amd", "mech", mech + ".pack"), "rb").read()
         subprocess.run([sys.executable, os.path.join(REPO, "tools", "extract_pack.py"), mech], check=True, stdout=subprocess.DEVNULL)
         assert open(os.path.join(REPO, "mistra_amd", "mech", mech + ".pack"), "rb").read() == before
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "extract_liq.py"), "--check"], check=True, stdout=subprocess.DEVNULL)
