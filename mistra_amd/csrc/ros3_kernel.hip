@@ -186,6 +186,35 @@ __device__ __forceinline__ void vm_ring_load_s(const RingBase& r, uint32_t voff)
 #undef MISTRA_RING_LOAD_S
 }
 
+// ... and with the row's base handed over as it stands (a compile-time offset from a table's start: two scalar additions)
+template <bool LOW, int K, int IMM>
+__device__ __forceinline__ void vm_ring_load_at(uint64_t sbase, uint32_t voff) {
+  static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate offset");
+#define MISTRA_RING_LOAD_AT(R0, R1, R2, R3)                                                                                   \
+  asm volatile("global_load_dwordx4 v[" #R0 ":" #R3 "], %0, %1 offset:%2" : : "v"(voff), "s"(sbase), "n"(IMM)                \
+               : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3)
+  if constexpr (LOW) {
+    if constexpr (K == 0) MISTRA_RING_LOAD_AT(64, 65, 66, 67);
+    else if constexpr (K == 1) MISTRA_RING_LOAD_AT(68, 69, 70, 71);
+    else if constexpr (K == 2) MISTRA_RING_LOAD_AT(80, 81, 82, 83);
+    else if constexpr (K == 3) MISTRA_RING_LOAD_AT(84, 85, 86, 87);
+    else if constexpr (K == 4) MISTRA_RING_LOAD_AT(96, 97, 98, 99);
+    else if constexpr (K == 5) MISTRA_RING_LOAD_AT(100, 101, 102, 103);
+    else if constexpr (K == 6) MISTRA_RING_LOAD_AT(112, 113, 114, 115);
+    else MISTRA_RING_LOAD_AT(116, 117, 118, 119);
+  } else {
+    if constexpr (K == 0) MISTRA_RING_LOAD_AT(192, 193, 194, 195);
+    else if constexpr (K == 1) MISTRA_RING_LOAD_AT(196, 197, 198, 199);
+    else if constexpr (K == 2) MISTRA_RING_LOAD_AT(208, 209, 210, 211);
+    else if constexpr (K == 3) MISTRA_RING_LOAD_AT(212, 213, 214, 215);
+    else if constexpr (K == 4) MISTRA_RING_LOAD_AT(224, 225, 226, 227);
+    else if constexpr (K == 5) MISTRA_RING_LOAD_AT(228, 229, 230, 231);
+    else if constexpr (K == 6) MISTRA_RING_LOAD_AT(240, 241, 242, 243);
+    else MISTRA_RING_LOAD_AT(244, 245, 246, 247);
+  }
+#undef MISTRA_RING_LOAD_AT
+}
+
 template <bool LOW, int K, int PENDING = 7>
 __device__ __forceinline__ u32x4 vm_ring_take() {
   uint32_t x, y, z, w;
@@ -214,6 +243,49 @@ __device__ __forceinline__ u32x4 vm_ring_take() {
   }
 #undef MISTRA_RING_TAKE
   return u32x4{x, y, z, w};
+}
+// The table rows of the tail chain hold two 16-bit Ghimj cell numbers per word (low half: the rows of register 0, high half: of
+// register 1).  This takes slot K out of the ring and turns the halves that are wanted straight into LDS byte addresses, one
+// v_lshlrev_b32_sdwa per cell reading the ring register itself: copied out first and decoded by the compiler it was 4 moves, 4 ands and
+// 8 shifts per slot, a fifth of the instructions of a chain that is bound by instruction issue (a lone wave: one instruction per
+// 4-7 cycles whatever it is).  three: a register holding 3 (the shift count; SDWA takes no literal).
+template <bool LOW, int K, int PENDING, bool LO, bool HI>
+__device__ __forceinline__ void vm_ring_take_cells(uint32_t* lo, uint32_t* hi, uint32_t three) {
+  static_assert(LO || HI, "nothing to take");
+#define MISTRA_SDWA(D, R, W) "\n\tv_lshlrev_b32_sdwa %" #D ", %[three], v" #R " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #W
+#define MISTRA_TAKE_CELLS(R0, R1, R2, R3)                                                                                              \
+  if constexpr (LO && HI)                                                                                                              \
+    asm volatile("s_waitcnt vmcnt(%[pend])" MISTRA_SDWA(0, R0, 0) MISTRA_SDWA(1, R1, 0) MISTRA_SDWA(2, R2, 0) MISTRA_SDWA(3, R3, 0)    \
+                 MISTRA_SDWA(4, R0, 1) MISTRA_SDWA(5, R1, 1) MISTRA_SDWA(6, R2, 1) MISTRA_SDWA(7, R3, 1)                              \
+                 : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])      \
+                 : [three] "v"(three), [pend] "n"(PENDING) : "memory");                                                              \
+  else if constexpr (LO)                                                                                                               \
+    asm volatile("s_waitcnt vmcnt(%[pend])" MISTRA_SDWA(0, R0, 0) MISTRA_SDWA(1, R1, 0) MISTRA_SDWA(2, R2, 0) MISTRA_SDWA(3, R3, 0)    \
+                 : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]) : [three] "v"(three), [pend] "n"(PENDING) : "memory");      \
+  else                                                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(%[pend])" MISTRA_SDWA(0, R0, 1) MISTRA_SDWA(1, R1, 1) MISTRA_SDWA(2, R2, 1) MISTRA_SDWA(3, R3, 1)    \
+                 : "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]) : [three] "v"(three), [pend] "n"(PENDING) : "memory");
+  if constexpr (LOW) {
+    if constexpr (K == 0) { MISTRA_TAKE_CELLS(64, 65, 66, 67) }
+    else if constexpr (K == 1) { MISTRA_TAKE_CELLS(68, 69, 70, 71) }
+    else if constexpr (K == 2) { MISTRA_TAKE_CELLS(80, 81, 82, 83) }
+    else if constexpr (K == 3) { MISTRA_TAKE_CELLS(84, 85, 86, 87) }
+    else if constexpr (K == 4) { MISTRA_TAKE_CELLS(96, 97, 98, 99) }
+    else if constexpr (K == 5) { MISTRA_TAKE_CELLS(100, 101, 102, 103) }
+    else if constexpr (K == 6) { MISTRA_TAKE_CELLS(112, 113, 114, 115) }
+    else { MISTRA_TAKE_CELLS(116, 117, 118, 119) }
+  } else {
+    if constexpr (K == 0) { MISTRA_TAKE_CELLS(192, 193, 194, 195) }
+    else if constexpr (K == 1) { MISTRA_TAKE_CELLS(196, 197, 198, 199) }
+    else if constexpr (K == 2) { MISTRA_TAKE_CELLS(208, 209, 210, 211) }
+    else if constexpr (K == 3) { MISTRA_TAKE_CELLS(212, 213, 214, 215) }
+    else if constexpr (K == 4) { MISTRA_TAKE_CELLS(224, 225, 226, 227) }
+    else if constexpr (K == 5) { MISTRA_TAKE_CELLS(228, 229, 230, 231) }
+    else if constexpr (K == 6) { MISTRA_TAKE_CELLS(240, 241, 242, 243) }
+    else { MISTRA_TAKE_CELLS(244, 245, 246, 247) }
+  }
+#undef MISTRA_TAKE_CELLS
+#undef MISTRA_SDWA
 }
 static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots");
 
@@ -367,31 +439,20 @@ __device__ __forceinline__ void tail_update(double& x, const double xb, const do
 // would otherwise sit out the table wait and an LDS round trip in front of every block: measured, the chain then took as long
 // as the column-by-column one).  w[0..3]: the block's four table slots (16 columns in chain order: ascending forward,
 // descending backward); a word holds the Ghimj cell of (row h + lane, column) in its low half and of (row h + 64 + lane,
-// column) in its high half.
-template <bool BACKWARD>
-__device__ __forceinline__ uint32_t tail_word(const u32x4 (&w)[4], int j) {      // table word of the block's column j
-  const int i = BACKWARD ? 15 - j : j;
-  const u32x4& s = w[i / 4];
-  return (i % 4) == 0 ? s.x : (i % 4) == 1 ? s.y : (i % 4) == 2 ? s.z : s.w;
-}
-// operands of the block's own register (diagonal block, lane rows below / above): gathered one block ahead
-template <int R, int J, bool BACKWARD>
-__device__ __forceinline__ void tail_gather(double (&c)[16], const u32x4 (&w)[4]) {
-  constexpr int REG = J / 4;
-#pragma unroll
-  for (int j = 0; j < 16; j++) c[j] = lds_ld(8u * (REG == 0 ? (tail_word<BACKWARD>(w, j) & 0xFFFFu) : (tail_word<BACKWARD>(w, j) >> 16)));
-}
+// column) in its high half.  (vm_ring_take_cells turns them into LDS addresses as they come out of the ring; a[i]: column i of the
+// block in TABLE order, the chain's step j is table column j forward and 15 - j backward.)
 // NEXT: takes the next block's table slots and issues the gathers of its operands (into c and w, free by then) — placed between
 // the block's last use of c and the other register's update, whose 16 dependent steps cover the gathers' LDS round trip.
+// ad: LDS addresses of the other register's operands of this block, in table order (taken from the ring with the block's own).
 template <int R, int J, bool BACKWARD, bool LAST, class NEXT>
-__device__ __forceinline__ void tail_block(double (&xr)[R], double (&c)[16], const u32x4 (&w)[4], NEXT&& next) {
+__device__ __forceinline__ void tail_block(double (&xr)[R], double (&c)[16], const uint32_t (&ad)[16], NEXT&& next) {
   constexpr int REG = J / 4, ROW = J % 4;
   constexpr int OTHER = BACKWARD ? 0 : R - 1;                    // the other register's rows lie wholly below (forward) / above (backward) the block
   constexpr bool HAS_OTHER = !LAST && R == 2 && REG != OTHER;
   double d[16];      // ... their operands: gathered here, used three phases further down
   if constexpr (HAS_OTHER) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) d[j] = lds_ld(8u * (OTHER == 0 ? (tail_word<BACKWARD>(w, j) & 0xFFFFu) : (tail_word<BACKWARD>(w, j) >> 16)));
+    for (int j = 0; j < 16; j++) d[j] = lds_ld(ad[BACKWARD ? 15 - j : j]);
   }
   double x = xr[REG];
   tail_diag<ROW, BACKWARD>(x, c);                                  // 1.
@@ -430,25 +491,41 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
     x[r] = lds_ld(xb + 8 * (r * 64 + lane));
     rd[r] = lds_ld(rb + 8 * (r * 64 + lane));          // R(k) = 1/U(k,k), published by the LU program
   }
-  const gptr<u32x4> tf = G_(reinterpret_cast<const u32x4*>(T.fwd)) + lane + FWD_BLOCK0 * 4 * 64;
-  const gptr<u32x4> tb = G_(reinterpret_cast<const u32x4*>(T.bwd)) + lane;
-  auto group = [&](int g) -> gptr<u32x4> { return g < 4 * NF ? tf + g * 64 : tb + (g - 4 * NF) * 64; };      // (past the last group: the tables' slack rows)
+  // table rows: one u32x4 per lane and group of 4 columns, 1 KiB per row; the forward tables from block FWD_BLOCK0 on, then the
+  // backward ones; past the last block: the tables' slack rows.  Row bases in scalar registers, the lane's offset in one vector register.
+  const uint64_t tf = ring_base(T.fwd + FWD_BLOCK0 * 4 * 64 * 4).b0, tb = ring_base(T.bwd).b0;
+  const uint32_t voff = 16u * (uint32_t)lane;
+  uint32_t three = 3;
+  asm volatile("" : "+v"(three));      // (held in one register for the whole solve)
+#define MISTRA_TAIL_LOADS(S, K0)                                                                                          \
+  {                                                                                                                      \
+    const uint64_t base = (S) < NF ? tf + (uint64_t)(S) * 4096u : tb + (uint64_t)((S) - NF) * 4096u;                     \
+    vm_ring_load_at<LOW, K0, 0>(base, voff); vm_ring_load_at<LOW, K0 + 1, 1024>(base, voff);                             \
+    vm_ring_load_at<LOW, K0 + 2, 2048>(base, voff); vm_ring_load_at<LOW, K0 + 3, 3072>(base, voff);                      \
+  }
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
-  vm_ring_load<LOW, 0>(group(0)); vm_ring_load<LOW, 1>(group(1)); vm_ring_load<LOW, 2>(group(2)); vm_ring_load<LOW, 3>(group(3));
-  vm_ring_load<LOW, 4>(group(4)); vm_ring_load<LOW, 5>(group(5)); vm_ring_load<LOW, 6>(group(6)); vm_ring_load<LOW, 7>(group(7));
+  MISTRA_TAIL_LOADS(0, 0) MISTRA_TAIL_LOADS(1, 4)
   // block S of the stream (S < NF: forward block FWD_BLOCK0 + S; else backward block NB - 1 - (S - NF)): its four slots (blocks
-  // alternate between the ring's halves, refilled with block S + 2's) and the gathers of its operands
+  // alternate between the ring's halves, refilled with block S + 2's) come out of the ring as LDS addresses — of the block's own
+  // register's operands (gathered at once, into c) and, where the other register takes part, of its operands (ad, gathered by tail_block)
   double c[16];
-  u32x4 w[4];
+  uint32_t ad[16];
 #define MISTRA_TAIL_GATHER(S)                                                                                             \
   if constexpr ((S) < NS) {                                                                                              \
     constexpr int K0 = ((S) & 1) * 4;                                                                                    \
-    w[0] = vm_ring_take<LOW, K0, 7>(); w[1] = vm_ring_take<LOW, K0 + 1, 6>();                                            \
-    w[2] = vm_ring_take<LOW, K0 + 2, 5>(); w[3] = vm_ring_take<LOW, K0 + 3, 4>();                                        \
-    vm_ring_load<LOW, K0>(group(4 * (S) + 8)); vm_ring_load<LOW, K0 + 1>(group(4 * (S) + 9));                           \
-    vm_ring_load<LOW, K0 + 2>(group(4 * (S) + 10)); vm_ring_load<LOW, K0 + 3>(group(4 * (S) + 11));                      \
-    if constexpr ((S) < NF) tail_gather<R, (FWD_BLOCK0 + (S)) % NB, false>(c, w);                                        \
-    else tail_gather<R, (NB - 1 - ((S) - NF) + NB) % NB, true>(c, w);                                                    \
+    constexpr bool BW = (S) >= NF;                                                                                       \
+    constexpr int J = BW ? (NB - 1 - ((S) - NF) + NB) % NB : (FWD_BLOCK0 + (S)) % NB;                                    \
+    constexpr int REG = J / 4, OTHER = BW ? 0 : R - 1;                                                                   \
+    constexpr bool LAST = BW ? (S) == NS - 1 : FWD_BLOCK0 + (S) == NB - 1;                                               \
+    constexpr bool HAS_OTHER = !LAST && R == 2 && REG != OTHER;                                                          \
+    constexpr bool LO = REG == 0 || (HAS_OTHER && OTHER == 0), HI = REG == 1 || (HAS_OTHER && OTHER == 1);               \
+    uint32_t ac[16];                                                                                                     \
+    uint32_t* const alo = REG == 0 ? ac : ad;                                                                            \
+    uint32_t* const ahi = REG == 1 ? ac : ad;                                                                            \
+    vm_ring_take_cells<LOW, K0, 7, LO, HI>(alo, ahi, three);         vm_ring_take_cells<LOW, K0 + 1, 6, LO, HI>(alo + 4, ahi + 4, three);   \
+    vm_ring_take_cells<LOW, K0 + 2, 5, LO, HI>(alo + 8, ahi + 8, three); vm_ring_take_cells<LOW, K0 + 3, 4, LO, HI>(alo + 12, ahi + 12, three); \
+    MISTRA_TAIL_LOADS((S) + 2, K0)                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 16; j++) c[j] = lds_ld(ac[BW ? 15 - j : j]);                                   \
   }
   // ... and its arithmetic; between the forward and the backward half: x = R .* x (the backward half runs on the row-scaled
   // triangle U' = D^-1 U that the factorisation leaves in the tail block — schedule.cpp: lu_entries; dense_lu — so there is
@@ -459,14 +536,15 @@ __device__ __attribute__((noinline)) void tail_solve(const TailDev T, uint32_t x
       _Pragma("unroll") for (int r = 0; r < R; r++) x[r] = x[r] * rd[r];                                                 \
     }                                                                                                                    \
     auto next = [&]() { MISTRA_TAIL_GATHER((S) + 1) };                                                                   \
-    if constexpr ((S) < NF) tail_block<R, (FWD_BLOCK0 + (S)) % NB, false, FWD_BLOCK0 + (S) == NB - 1>(x, c, w, next);    \
-    else tail_block<R, (NB - 1 - ((S) - NF) + NB) % NB, true, (S) == NS - 1>(x, c, w, next);                             \
+    if constexpr ((S) < NF) tail_block<R, (FWD_BLOCK0 + (S)) % NB, false, FWD_BLOCK0 + (S) == NB - 1>(x, c, ad, next);   \
+    else tail_block<R, (NB - 1 - ((S) - NF) + NB) % NB, true, (S) == NS - 1>(x, c, ad, next);                            \
   }
   MISTRA_TAIL_GATHER(0)
   MISTRA_TAIL_STEP(0) MISTRA_TAIL_STEP(1) MISTRA_TAIL_STEP(2) MISTRA_TAIL_STEP(3) MISTRA_TAIL_STEP(4) MISTRA_TAIL_STEP(5) MISTRA_TAIL_STEP(6) MISTRA_TAIL_STEP(7)
   MISTRA_TAIL_STEP(8) MISTRA_TAIL_STEP(9) MISTRA_TAIL_STEP(10) MISTRA_TAIL_STEP(11) MISTRA_TAIL_STEP(12) MISTRA_TAIL_STEP(13) MISTRA_TAIL_STEP(14) MISTRA_TAIL_STEP(15)
 #undef MISTRA_TAIL_STEP
 #undef MISTRA_TAIL_GATHER
+#undef MISTRA_TAIL_LOADS
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // the look-ahead loads past the stream's end have landed
 #pragma unroll
   for (int r = 0; r < R; r++) lds_st(xb + 8 * (r * 64 + lane), x[r]);
