@@ -667,45 +667,30 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
 //      (-0.0f)*(0.0 cell), so terms need no flags and the sums are bit-for-bit the flagged ones.  A row whose first
 //      address carries GS_ROW_FLUSH completes the lane's current output: it is stored to the lane's next output cell in
 //      LDS (out_addr, then every out_stride bytes) — the caller reads its own cells back, no barrier needed.
+//      The instruction stream is generated (tools/gen_gsum_asm.py -> gsum_exec_asm.inc: why, and the pipeline, are described there).
+#include "gsum_exec_asm.inc"
 template <int NT, bool LOW>
 __device__ __attribute__((noinline)) void gsum_run(const GsDev P, uint32_t row0, int rows, int lane, uint32_t out_addr, uint32_t out_stride) {
   // row0, rows: P.wave_base[wave] and P.rows[wave], fetched by the kernel when it started (see vm_run)
-  const int n = __builtin_amdgcn_readfirstlane(rows);
-  gptr<u32x4> rp = G_(reinterpret_cast<const u32x4*>(P.recs)) + ((size_t)row0 * 64 + lane) * 2;
-  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // nothing of the caller's may sit between the counted loads
-  vm_ring_load<LOW, 0>(rp);       vm_ring_load<LOW, 1, 16>(rp);
-  vm_ring_load<LOW, 2>(rp + 128); vm_ring_load<LOW, 3, 16>(rp + 128);
-  vm_ring_load<LOW, 4>(rp + 256); vm_ring_load<LOW, 5, 16>(rp + 256);
-  vm_ring_load<LOW, 6>(rp + 384); vm_ring_load<LOW, 7, 16>(rp + 384);
-  rp += 4 * 128;
+  int n = __builtin_amdgcn_readfirstlane(rows);
+  const uint64_t recs = reinterpret_cast<uint64_t>(P.recs) + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)row0) * 2048u;      // the wave's first row: 2 KiB per row
+  const uint64_t b0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs) |
+                      ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(recs >> 32)) << 32);
+  const uint64_t b1 = b0 + 4096u;
+  uint32_t voff = (uint32_t)lane * 32u;      // two uint4 per lane and row: addresses, coefficients
   double acc = -0.0;
-  for (int i = 0; i < n; i += 4) {
-#define MISTRA_GS_ROW(K)                                                             \
-    {                                                                                \
-      const u32x4 ad = vm_ring_take<LOW, 2 * K, 6>();                                \
-      const u32x4 cb = vm_ring_take<LOW, 2 * K + 1, 6>();                            \
-      vm_ring_load<LOW, 2 * K>(rp + K * 128);                                        \
-      vm_ring_load<LOW, 2 * K + 1, 16>(rp + K * 128);                                \
-      const uint32_t a0 = ad.x;                                                      \
-      const bool flush = __builtin_amdgcn_readfirstlane((int)a0) & 1;   /* the mark is the same in every lane */ \
-      const double x0 = lds_ld(a0 & ~7u), x1 = lds_ld(ad.y), x2 = lds_ld(ad.z), x3 = lds_ld(ad.w); \
-      /* scalars first: __builtin_bit_cast on a vector ELEMENT reads element 0 with this compiler */ \
-      const uint32_t cx = cb.x, cy = cb.y, cz = cb.z, cw = cb.w;                     \
-      acc = acc + (double)__uint_as_float(cx) * x0;                                  \
-      acc = acc + (double)__uint_as_float(cy) * x1;                                  \
-      acc = acc + (double)__uint_as_float(cz) * x2;                                  \
-      acc = acc + (double)__uint_as_float(cw) * x3;                                  \
-      if (flush) {                                                                   \
-        lds_st(out_addr, acc);                                                       \
-        out_addr += out_stride;                                                      \
-        acc = -0.0;                                                                  \
-      }                                                                              \
-    }
-    MISTRA_GS_ROW(0) MISTRA_GS_ROW(1) MISTRA_GS_ROW(2) MISTRA_GS_ROW(3)
-#undef MISTRA_GS_ROW
-    rp += 4 * 128;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // drain the look-ahead loads before returning
+  const double mzero = -0.0;
+  double xA0, xA1, xA2, xA3, xB0, xB1, xB2, xB3, cA0, cA1, cA2, cA3, cB0, cB1, cB2, cB3;
+  uint32_t ad, flA, flB;
+#define MISTRA_GSUM_OPERANDS                                                                                                                   \
+  [acc] "+&v"(acc), [ad] "=&v"(ad), [xA0] "=&v"(xA0), [xA1] "=&v"(xA1), [xA2] "=&v"(xA2), [xA3] "=&v"(xA3), [xB0] "=&v"(xB0), [xB1] "=&v"(xB1),    \
+      [xB2] "=&v"(xB2), [xB3] "=&v"(xB3), [cA0] "=&v"(cA0), [cA1] "=&v"(cA1), [cA2] "=&v"(cA2), [cA3] "=&v"(cA3), [cB0] "=&v"(cB0),               \
+      [cB1] "=&v"(cB1), [cB2] "=&v"(cB2), [cB3] "=&v"(cB3), [flA] "=&s"(flA), [flB] "=&s"(flB), [n] "+s"(n), [voff] "+&v"(voff),               \
+      [out] "+&v"(out_addr)                                                                                                                    \
+      : [b0] "s"(b0), [b1] "s"(b1), [stride] "v"(out_stride), [mzero] "v"(mzero)
+  if constexpr (LOW) asm volatile(MISTRA_GSUM_ASM_LOW : MISTRA_GSUM_OPERANDS : "memory", "scc", MISTRA_GSUM_CLOBBER_LOW);
+  else asm volatile(MISTRA_GSUM_ASM_HIGH : MISTRA_GSUM_OPERANDS : "memory", "scc", MISTRA_GSUM_CLOBBER_HIGH);
+#undef MISTRA_GSUM_OPERANDS
 }
 
 // ---- the factorisation's last act (schedule.hpp: ScaleProgram): M[tgt] *= M[aux] for two cells per 16-byte slot,

@@ -78,9 +78,9 @@ def test_lookahead_ring_registers_are_out_of_the_compilers_reach():
     assert low and max(low.values()) < 64, low      # (ring_register_report has raised already if not)
 
 
-@pytest.mark.parametrize("tool", ["gen_vm_asm.py", "gen_rates_shim.py"])
+@pytest.mark.parametrize("tool", ["gen_vm_asm.py", "gen_gsum_asm.py", "gen_rates_shim.py"])
 def test_generated_sources_are_up_to_date(tool):
-    """mistra_amd/csrc/vm_exec_asm.inc and shim/mistra_kpp_rates.f90 are generator output kept in the tree: what is committed is what
+    """mistra_amd/csrc/vm_exec_asm.inc, gsum_exec_asm.inc and shim/mistra_kpp_rates.f90 are generator output kept in the tree: what is committed is what
     the generator writes today."""
     import subprocess
     import sys
