@@ -569,14 +569,24 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
   constexpr uint32_t mb = 0;      // M starts at LDS address 0 (checked at kernel entry); xb, rb: LDS addresses of the tail of XS and R
   double x[R], rd[R];
   const uint32_t voff = 16u * (uint32_t)lane;      // the lane's u32x4 within a table row
+  static_assert(R == 1 || R == 2, "one or two 64-row registers");
+  uint32_t three = 3;
+  asm volatile("" : "+v"(three));
 #pragma unroll
   for (int r = 0; r < R; r++) x[r] = lds_ld(xb + 8 * (r * 64 + lane));
   // Matrix entries of a 4-column group are read from LDS one group AHEAD of the chain that uses them (two register
   // buffers, alternating): a lone wave would otherwise expose the LDS latency once per group.  Every row slot is read
   // for every group (rows that take no part point at the 0.0 cell); the arithmetic loops keep their exact row ranges.
-#define MISTRA_TAIL_OPERANDS(BUF, TAB)                                                  \
-  _Pragma("unroll") for (int c = 0; c < 4; c++)                                         \
-    _Pragma("unroll") for (int r = 0; r < R; r++) BUF[c][r] = lds_ld(mb + 8 * ((TAB[c] >> (16 * r)) & 0xFFFFu));
+  // (the group's table words come out of the ring as LDS addresses, vm_ring_take_cells: low halves = register 0's rows, high = register 1's)
+#define MISTRA_TAIL_OPERANDS(BUF, K, PENDING)                                           \
+  {                                                                                     \
+    uint32_t alo[4], ahi[4];                                                            \
+    vm_ring_take_cells<LOW, K, PENDING, true, R == 2>(alo, ahi, three);                 \
+    _Pragma("unroll") for (int c = 0; c < 4; c++) {                                     \
+      BUF[c][0] = lds_ld(mb + alo[c]);                                                  \
+      if constexpr (R == 2) BUF[c][1] = lds_ld(mb + ahi[c]);                            \
+    }                                                                                   \
+  }
   // The compiler would otherwise park the off-chain row updates (and their operands) until the row is next read, sixty
   // columns later: pin every group's results to the end of its group.
 #define MISTRA_TAIL_PIN _Pragma("unroll") for (int r = 0; r < R; r++) asm volatile("" : "+v"(x[r]));
@@ -588,20 +598,16 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
     vm_ring_load_s<LOW, 0, 0>(tp, voff); vm_ring_load_s<LOW, 1, 1>(tp, voff); vm_ring_load_s<LOW, 2, 2>(tp, voff); vm_ring_load_s<LOW, 3, 3>(tp, voff);
     vm_ring_load_s<LOW, 4, 4>(tp, voff); vm_ring_load_s<LOW, 5, 5>(tp, voff); vm_ring_load_s<LOW, 6, 6>(tp, voff); vm_ring_load_s<LOW, 7, 7>(tp, voff);
     ring_advance(tp, kRingSlots * 1024);
-    {
-      const u32x4 first = vm_ring_take<LOW, 0>();
-      vm_ring_load_s<LOW, 0, 0>(tp, voff);
-      MISTRA_TAIL_OPERANDS(opa, first)
-    }
+    MISTRA_TAIL_OPERANDS(opa, 0, 7)
+    vm_ring_load_s<LOW, 0, 0>(tp, voff);
 #pragma unroll
     for (int rq = FWD_FROM; rq < FWD_END; rq++) {
       for (int gb = 0; gb < 16; gb += kRingSlots) {
 #define MISTRA_TAIL_FWD(K, CUR, NXT)                                                    \
         {                                                                               \
-          const u32x4 nxt = vm_ring_take<LOW, (K + 1) % kRingSlots>();                       \
+          MISTRA_TAIL_OPERANDS(NXT, (K + 1) % kRingSlots, 7)                                 \
           if constexpr (K + 1 == kRingSlots) ring_advance(tp, kRingSlots * 1024);            \
           vm_ring_load_s<LOW, (K + 1) % kRingSlots, (K + 1) % kRingSlots>(tp, voff);         \
-          MISTRA_TAIL_OPERANDS(NXT, nxt)                                                \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const double xq = readlane_f64(x[rq], 4 * (gb + K) + c);                    \
             _Pragma("unroll") for (int r = rq; r < R; r++) x[r] = __builtin_fma(-CUR[c][r], xq, x[r]); \
@@ -629,20 +635,16 @@ __device__ __attribute__((noinline)) void tail_solve_columns(const TailDev T, ui
     for (int r = 0; r < R; r++) rd[r] = lds_ld(rb + 8 * (r * 64 + lane));
 #pragma unroll
     for (int r = 0; r < R; r++) x[r] = x[r] * rd[r];
-    {
-      const u32x4 first = vm_ring_take<LOW, 0>();
-      vm_ring_load_s<LOW, 0, 0>(tp, voff);
-      MISTRA_TAIL_OPERANDS(opa, first)
-    }
+    MISTRA_TAIL_OPERANDS(opa, 0, 7)
+    vm_ring_load_s<LOW, 0, 0>(tp, voff);
 #pragma unroll
     for (int rq = R - 1; rq >= 0; rq--) {
       for (int gb = 0; gb < 16; gb += kRingSlots) {
 #define MISTRA_TAIL_BWD(K, CUR, NXT)                                                    \
         {                                                                               \
-          const u32x4 nxt = vm_ring_take<LOW, (K + 1) % kRingSlots>();                       \
+          MISTRA_TAIL_OPERANDS(NXT, (K + 1) % kRingSlots, 7)                                 \
           if constexpr (K + 1 == kRingSlots) ring_advance(tp, kRingSlots * 1024);            \
           vm_ring_load_s<LOW, (K + 1) % kRingSlots, (K + 1) % kRingSlots>(tp, voff);         \
-          MISTRA_TAIL_OPERANDS(NXT, nxt)                                                \
           _Pragma("unroll") for (int c = 0; c < 4; c++) {                               \
             const double xq = readlane_f64(x[rq], 63 - (4 * (gb + K) + c));             \
             _Pragma("unroll") for (int r = 0; r <= rq; r++) x[r] = __builtin_fma(-CUR[c][r], xq, x[r]); \
