@@ -804,9 +804,10 @@ __device__ __forceinline__ void dense_store_panel(const int P, const int wave, c
 // During step 2 of the NEXT panel two otherwise idle waves store the finished L(i,j), U'(j,c) = U(j,c)*R(j), U(j,j), R(j)
 // to their Ghimj slots, for the solves (dense_store_panel)
 // The two panel buffers alternate, so that step 1 of the next panel can start while slower waves are still in step 3.
-// P is a run-time value (the sixteen panels are ONE loop body: unrolled, the block's factorisation was 39 KB of
-// straight-line code executed once per decomposition, and instruction fetch, not arithmetic, set its pace); the tile
-// registers a panel needs are picked with selects on wave-uniform conditions.
+// The sixteen panels run as a loop of two copies of eight (MISTRA_DENSE_UNROLL below; fully unrolled, the block's factorisation
+// was 39 KB of straight-line code executed once per decomposition, and instruction fetch, not arithmetic, set its pace); the tile
+// registers a panel needs are picked with selects on wave-uniform conditions, which the compiler resolves where P's low bits are
+// compile-time constants of the copy.
 template <class MT, int NT>
 __device__ __forceinline__ void dense_panel(f64x4& T0, f64x4& T1, const int P, const int wave, const int lane
 #ifdef MISTRA_DIAG_STAMPS
@@ -978,6 +979,9 @@ __device__ __attribute__((noinline)) void dense_lu(int lane) {
   MISTRA_STAMP(t2)
   MISTRA_STAMP_ADD(0, t1 - t0) MISTRA_STAMP_ADD(1, t2 - t1) MISTRA_STAMP_ADD(9, 1)
   // ---- the block's own factorisation
+#ifndef MISTRA_DENSE_UNROLL      // panels per copy of the loop body: with 8 the choices among tile registers (panel within its block column, odd / even
+#define MISTRA_DENSE_UNROLL 8      // block column) are made at compile time — 22 selects fewer per panel and wave; measured on one box: 1: 24 990, 2: 24 860, 4: 24 770,
+#endif                            // 8: 25 210 timesteps/s (16 = the whole loop unrolled was slower in round 2: instruction fetch)
 #ifndef MISTRA_DIAG_DENSE_PANELS      // timing diagnostics only (tools/diag_dense.sh): a library built with fewer panels computes garbage
 #define MISTRA_DIAG_DENSE_PANELS 16
 #endif
@@ -989,7 +993,7 @@ __device__ __attribute__((noinline)) void dense_lu(int lane) {
   MISTRA_STAMP(tp1)
   MISTRA_STAMP_ADD(2, acc[0]) MISTRA_STAMP_ADD(3, acc[1]) MISTRA_STAMP_ADD(4, acc[2]) MISTRA_STAMP_ADD(5, acc[3]) MISTRA_STAMP_ADD(8, acc[4]) MISTRA_STAMP_ADD(12, tp1 - tp0)
 #else
-#pragma unroll 1
+#pragma unroll MISTRA_DENSE_UNROLL
   for (int P = 0; P < MISTRA_DIAG_DENSE_PANELS; P++) dense_panel<MT, NT>(T0, T1, P, wave, lane);
 #endif
   if (dense_is_storer(wave)) dense_store_panel<MT, NT>(15, wave, lane);      // (behind the last panel's second barrier)
