@@ -5,6 +5,7 @@
 namespace mistra {
 
 constexpr int kProfSlots = 16;   // phase counters of the profiling kernel variant
+constexpr int kVmSweepUpdPerRec = 3;   // updates per record of the sweep programs (schedule.hpp: VM_SWEEP_UPD_PER_REC; ros3_kernel.hip: vm_run)
 
 struct VmDev {                 // LDS VM program in device memory (see schedule.hpp)
   const uint32_t* wave_base;   // [NW]         first record row of each wave's stream

@@ -303,9 +303,11 @@ static_assert(kRingSlots == 8, "the ring helpers above are written for 8 slots")
 // The IEEE reciprocal is the sequence hipcc emits for 1.0/x (v_div_scale, v_rcp, two Newton steps, v_div_fmas, v_div_fixup).
 #include "vm_exec_asm.inc"
 
-template <int NT, int SLOTS>
+// UPR: updates per record — 2: (a, r, u) triples, the LU program; 3: (a, u) pairs, the triangular sweeps (schedule.hpp)
+template <int NT, int SLOTS, int UPR = 2>
 __device__ __attribute__((noinline)) void vm_run(const VmDev P, uint32_t row0, int lane) {
   static_assert(SLOTS == 4 || SLOTS == 6 || SLOTS == 8, "ring depths vm_exec_asm.inc is generated for");
+  static_assert(UPR == 2 || (UPR == 3 && SLOTS == 4), "executor variants vm_exec_asm.inc is generated for");
   const uint64_t recs = reinterpret_cast<uint64_t>(P.recs);      // the same in every lane: move it to SGPRs
   const uint64_t base = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs) |
                         ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(recs >> 32)) << 32);
@@ -322,7 +324,9 @@ __device__ __attribute__((noinline)) void vm_run(const VmDev P, uint32_t row0, i
       [r1B] "=&v"(r1B), [u1B] "=&v"(u1B), [a2B] "=&v"(a2B), [r2B] "=&v"(r2B), [u2B] "=&v"(u2B), [sc] "=&v"(sc), [tg] "=&v"(tg), [ax] "=&v"(ax),          \
       [t] "=&v"(t), [flA] "=&s"(flA), [flB] "=&s"(flB), [tmp] "=&s"(tmp), [sv] "=&s"(sv), [sm] "=&s"(sm), [rounds] "+s"(rounds), [va] "+v"(va),         \
       [vb] "+v"(vb)
-  if constexpr (SLOTS == 8) {
+  if constexpr (UPR == 3) {
+    asm volatile(MISTRA_VM_ASM_N4_SWEEP : MISTRA_VM_OPERANDS : [base] "s"(base) : "memory", "vcc", "scc", MISTRA_VM_CLOBBER_N4);
+  } else if constexpr (SLOTS == 8) {
     uint32_t vc = va + 8192u, vd = va + 12288u;                                      // rows +4, +5 and +6, +7
     asm volatile(MISTRA_VM_ASM_N8 : MISTRA_VM_OPERANDS, [vc] "+v"(vc), [vd] "+v"(vd) : [base] "s"(base) : "memory", "vcc", "scc", MISTRA_VM_CLOBBER_N8);
   } else if constexpr (SLOTS == 6) {
@@ -1371,7 +1375,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       }
       lds_barrier();
       lap(6);
-      vm_run<NT, MT::VM_SLOTS>(a.solve_head_fwd, hdr.fwd_row0, lane);                                          // head rows, all waves
+      vm_run<NT, 4, kVmSweepUpdPerRec>(a.solve_head_fwd, hdr.fwd_row0, lane);                                          // head rows, all waves
       lap(8);
       if (wave == 0)                                                                         // tail chain, one wave
         tail(std::false_type{});
@@ -1382,7 +1386,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     }
     lds_barrier();
     lap(9);
-    vm_run<NT, MT::VM_SLOTS>(a.solve_head_bwd, hdr.bwd_row0, lane);
+    vm_run<NT, 4, kVmSweepUpdPerRec>(a.solve_head_bwd, hdr.bwd_row0, lane);
     lap(10);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {

@@ -67,13 +67,13 @@ int lds_pass_cycles(const int* cell64) {
 // thrown at the banks at random and 1 when they are spread.  Records of one pass sit in (nearly) the same rows of
 // their lanes, i.e. are issued together; an item goes to the half-wave in which its operand cells meet the fewest
 // distinct cells of their bank classes already placed there.
-std::vector<int> deal(const std::vector<Item>& items, const std::vector<VmEntry>& entries, int nt) {
+std::vector<int> deal(const std::vector<Item>& items, const std::vector<VmEntry>& entries, int nt, int upr) {
   const int n = (int)items.size();
   std::vector<int> lane((size_t)n);
   static const bool plain_deal = diag_env("MISTRA_DIAG_PLAIN_DEAL") != nullptr;   // A/B diagnostic: positions as sorted
   const int waves_used = std::max(1, std::min(nt / 64, (n + 63) / 64));
   const int lanes = waves_used * 64, groups = lanes / 32;
-  auto nrec = [](const Item& it) { return std::max(1, (it.count + VM_UPD_PER_REC - 1) / VM_UPD_PER_REC); };
+  auto nrec = [upr](const Item& it) { return std::max(1, (it.count + upr - 1) / upr); };
   struct Slot { std::vector<uint16_t> cells; int cnt[32]; };
   for (int p0 = 0; p0 < n; p0 += lanes) {                 // one pass
     const int pn = std::min(lanes, n - p0), pass = p0 / lanes;
@@ -85,13 +85,16 @@ std::vector<int> deal(const std::vector<Item>& items, const std::vector<VmEntry>
     auto operands = [&](const Item& it, int r, int* cell /*7*/) {
       const VmEntry& E = entries[(size_t)it.entry];
       cell[0] = E.tgt;
-      for (int u = 0; u < VM_UPD_PER_REC; u++) {
-        const int i = r * VM_UPD_PER_REC + u;
+      const int per = upr == 2 ? 3 : 2;      // operand cells per update: (a, r, u), or (a, u) in records of three updates
+      for (int u = 0; u < upr; u++) {
+        const int i = r * upr + u;
         if (i < it.count) {
           const VmUpd& up = E.upd[(size_t)(it.first + i)];
-          cell[1 + 3 * u] = up.a; cell[2 + 3 * u] = up.r; cell[3 + 3 * u] = up.u;
+          cell[1 + per * u] = up.a;
+          if (upr == 2) { cell[2 + 3 * u] = up.r; cell[3 + 3 * u] = up.u; }
+          else cell[2 + 2 * u] = up.u;
         } else {
-          cell[1 + 3 * u] = cell[2 + 3 * u] = cell[3 + 3 * u] = -1;      // the 0.0 cell in every lane: broadcast
+          for (int o = 0; o < per; o++) cell[1 + per * u + o] = -1;      // the 0.0 cell in every lane: broadcast
         }
       }
     };
@@ -151,13 +154,15 @@ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
-VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget) {
+VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget, int upr) {
+  if (upr != 2 && upr != 3) throw std::invalid_argument("records hold two (a, r, u) or three (a, u) updates");
   if (nt % 64 != 0 || nt <= 0) throw std::invalid_argument("nt must be a positive multiple of 64");
   const int msize = lay.size(), zero_slot = lay.zero();
   VmProgram P;
   P.nt = nt;
   P.nw = nt / 64;
   P.zero_slot = zero_slot;
+  P.upd_per_rec = upr;
 
   std::vector<int> fin((size_t)msize, 0);   // round at whose end M[x] holds its final value (0 = input)
   std::map<int, std::vector<Item>> rounds;
@@ -214,13 +219,13 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
       static const int smooth = diag_env("MISTRA_DIAG_SMOOTH") ? std::atoi(diag_env("MISTRA_DIAG_SMOOTH")) : 1;
       int last_burst = -1;
       for (size_t k = 0; k + 1 < chunks.size(); k++)
-        if (chunks[k].count >= 2 * VM_UPD_PER_REC) last_burst = (int)k;
+        if (chunks[k].count >= 2 * upr) last_burst = (int)k;
       if (smooth && E.keep_order && last_burst >= 1) {
         int total = 0;
         for (int k = 0; k <= last_burst; k++) total += chunks[(size_t)k].count;
         const int r0 = chunks[0].round, r1 = chunks[(size_t)last_burst].round;
         int per = (total + (r1 - r0)) / (r1 - r0 + 1);               // updates per round over [r0, r1]
-        per = std::max(2 * VM_UPD_PER_REC, (per + VM_UPD_PER_REC - 1) / VM_UPD_PER_REC * VM_UPD_PER_REC);
+        per = std::max(2 * upr, (per + upr - 1) / upr * upr);
         std::vector<Chunk> out;
         int next_first = 0, k = 0, avail = 0;                        // avail: updates ready but not yet paid out
         for (int r = r0; r <= r1; r++) {
@@ -243,7 +248,7 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
       if (!merged.empty()) {
         Chunk& cur = merged.back();
         bool cur_is_final = merged.size() == 1;
-        int limit = cur_is_final ? VM_UPD_PER_REC : merge_budget;
+        int limit = cur_is_final ? upr : std::max(merge_budget, upr);
         if (cur.count + chunks[(size_t)k].count <= limit) {
           cur.first = chunks[(size_t)k].first;
           cur.count += chunks[(size_t)k].count;
@@ -280,9 +285,9 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
   int ridx = 0;
   for (auto& kv : rounds) {
     std::vector<Item>& items = kv.second;
-    auto nrec = [](const Item& it) { return std::max(1, (it.count + VM_UPD_PER_REC - 1) / VM_UPD_PER_REC); };
+    auto nrec = [upr](const Item& it) { return std::max(1, (it.count + upr - 1) / upr); };
     std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return nrec(a) > nrec(b); });
-    std::vector<int> lane = deal(items, entries, nt);
+    std::vector<int> lane = deal(items, entries, nt, upr);
     // The record that publishes a pivot's reciprocal carries an IEEE division (~150 cycles of dependent work) on top of its
     // row; every other wave then waits for it at the barrier.  Where the waves of a round do not all have the same number
     // of rows, that record goes to a wave with fewer: it swaps lanes with an equally long item there (no lane's row count
@@ -329,15 +334,16 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
         }
         w.push_back(vm_off(E.tgt, 0));
         w.push_back(vm_off(aux, f1 | (r > 0 ? VM_D1_CONT : 0u)));
-        for (int u = 0; u < VM_UPD_PER_REC; u++) {
-          int i = r * VM_UPD_PER_REC + u;
+        for (int u = 0; u < upr; u++) {
+          int i = r * upr + u;
           if (i < it.count) {
             const VmUpd& up = E.upd[(size_t)(it.first + i)];
             w.push_back(vm_off(up.a, 0));
-            w.push_back(vm_off(up.r, 0));
+            if (upr == 2) w.push_back(vm_off(up.r, 0));
+            else if (up.r != lay.one()) throw std::logic_error("a record of three updates has no middle operand: it must be the 1.0 cell");
             w.push_back(vm_off(up.u, 0));
           } else {
-            w.push_back(zoff); w.push_back(zoff); w.push_back(zoff);
+            for (int o = 0; o < (upr == 2 ? 3 : 2); o++) w.push_back(zoff);
           }
         }
       }
@@ -881,8 +887,9 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
     int bwd_temps = 0;
     std::vector<VmEntry> bwd = solve_head_bwd_entries(m, lay, S.tail.h, bwd_split, S.n_temps, &bwd_temps);
     S.n_temps += bwd_temps;
-    S.solve_head_fwd = build_vm_program(std::move(fwd), lay, nt);
-    S.solve_head_bwd = build_vm_program(std::move(bwd), lay, nt);
+    // the sweeps' updates are (L(i,j), 1.0, X(j)): the middle operand is dropped and a record holds three of them
+    S.solve_head_fwd = build_vm_program(std::move(fwd), lay, nt, 2, VM_SWEEP_UPD_PER_REC);
+    S.solve_head_bwd = build_vm_program(std::move(bwd), lay, nt, 2, VM_SWEEP_UPD_PER_REC);
   }
   return S;
 }

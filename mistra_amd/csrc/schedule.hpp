@@ -55,6 +55,7 @@
 #include <utility>
 #include <vector>
 
+#include "kernel_args.hpp"
 #include "mech_tables.hpp"
 
 namespace mistra {
@@ -73,7 +74,8 @@ constexpr int VM_ROW_EOR_BIT = 24, VM_ROW_NULL_BIT = 25, VM_ROW_AUX_BIT = 26;
 constexpr uint32_t VM_AUX_MASK = 0x00FFFFF8u;   // byte address part of d1
 constexpr int VM_REC_WORDS = 8;
 inline size_t vm_rec_index(size_t row, int lane, int k) { return row * 512 + (k < 4 ? 0 : 256) + (size_t)lane * 4 + (size_t)(k & 3); }
-constexpr int VM_UPD_PER_REC = 2;
+constexpr int VM_UPD_PER_REC = 2;          // updates (a, r, u) per record of the LU program
+constexpr int VM_SWEEP_UPD_PER_REC = kVmSweepUpdPerRec;    // updates (a, u) per record of the triangular sweeps, whose middle operand is always the 1.0 cell
 constexpr int VM_LOOKAHEAD_ROWS = 16;    // >= 2x the kernel's table look-ahead depth (ros3_kernel.hip)
 
 // VM memory map for a mechanism with nnz LU slots and nvar species
@@ -108,6 +110,7 @@ struct VmEntry {
 
 struct VmProgram {
   int nt = 0, nw = 0, nrounds = 0, zero_slot = 0;
+  int upd_per_rec = VM_UPD_PER_REC;             // 2: d2..d7 = (a1,r1,u1),(a2,r2,u2);  3: d2..d7 = (a1,u1),(a2,u2),(a3,u3), acc -= M[a]*M[u]
   std::vector<uint32_t> wave_base;              // [nw]  first record row of each wave's linear stream
   std::vector<uint16_t> blk_n;                  // [nrounds*nw] record rows of (round, wave), null rows included (census / emulator)
   std::vector<uint32_t> recs;                   // per row 512 words, PLANAR: words 0-3 of all 64 lanes, then words 4-7 of all
@@ -224,7 +227,7 @@ struct KernelSchedule {
   DenseTail dense;                              // nd = 0: the mechanism runs without the dense tail block
 };
 
-VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 2);
+VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 2, int upd_per_rec = VM_UPD_PER_REC);
 // with_rhs: also forward-sweep the vector held in XS while factorising (rows of an appended right-hand-side column)
 // scale_pairs: where to put the (tgt, aux) pairs of the final scaling; nullptr = keep them as a last phase of VM entries
 // dense_h >= 0: rows/columns [dense_h, n) are the dense tail block (DenseTail): the program leaves out the updates of

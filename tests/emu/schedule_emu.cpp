@@ -72,11 +72,19 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
           const int tgt = (int)(rec[0] >> 3), aux = (int)((rec[1] & VM_AUX_MASK) >> 3);
           double acc = (rec[1] & VM_D1_CONT) ? carry : rd(rec[0]);
           if ((rec[1] & VM_D1_CONT) && ridx == 0) return -7;   // a continuation cannot open a round
-          for (int u = 0; u < VM_UPD_PER_REC; u++) {
-            const double av = rd(rec[2 + 3 * u]), rv = rd(rec[3 + 3 * u]), uv = rd(rec[4 + 3 * u]);
-            const double mlt = av * rv;
-            const double p = mlt * uv;
-            acc = acc - p;
+          if (P.upd_per_rec == 2) {
+            for (int u = 0; u < 2; u++) {
+              const double av = rd(rec[2 + 3 * u]), rv = rd(rec[3 + 3 * u]), uv = rd(rec[4 + 3 * u]);
+              const double mlt = av * rv;
+              const double p = mlt * uv;
+              acc = acc - p;
+            }
+          } else {      // records of the sweeps: three updates of two operands
+            for (int u = 0; u < 3; u++) {
+              const double av = rd(rec[2 + 2 * u]), uv = rd(rec[3 + 2 * u]);
+              const double p = av * uv;
+              acc = acc - p;
+            }
           }
           if (rec[1] & VM_D1_RCP) {
             if (!(rec[1] & VM_ROW_AUX)) return -6;   // row mark missing

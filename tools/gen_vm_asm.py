@@ -46,7 +46,7 @@ v_div_fmas_f64 %[a1{P}], %[a1{P}], %[r1{P}], %[a2{P}]
 v_div_fixup_f64 %[a1{P}], %[a1{P}], %[acc], 1.0"""      # the sequence hipcc emits for 1.0/x (IEEE)
 
 
-def variant(n):
+def variant(n, upr=2):
     blk = BLOCKS[n]
     L = []
     emit = L.append
@@ -65,14 +65,24 @@ def variant(n):
             emit("ds_read_b64 %%[%s%s], %s" % (nm, q, d(t, k)))
 
     def muls(p):
-        emit("v_mul_f64 %%[a1%s], %%[a1%s], %%[r1%s]" % (p, p, p))
-        emit("v_mul_f64 %%[a1%s], %%[a1%s], %%[u1%s]" % (p, p, p))
-        emit("v_mul_f64 %%[a2%s], %%[a2%s], %%[r2%s]" % (p, p, p))
-        emit("v_mul_f64 %%[a2%s], %%[a2%s], %%[u2%s]" % (p, p, p))
+        if upr == 2:         # d2..d7 = (a1, r1, u1), (a2, r2, u2): two updates  (M[a]*M[r])*M[u]
+            emit("v_mul_f64 %%[a1%s], %%[a1%s], %%[r1%s]" % (p, p, p))
+            emit("v_mul_f64 %%[a1%s], %%[a1%s], %%[u1%s]" % (p, p, p))
+            emit("v_mul_f64 %%[a2%s], %%[a2%s], %%[r2%s]" % (p, p, p))
+            emit("v_mul_f64 %%[a2%s], %%[a2%s], %%[u2%s]" % (p, p, p))
+        else:                # d2..d7 = (a1, u1), (a2, u2), (a3, u3) in the registers named a1 r1 | u1 a2 | r2 u2: three updates M[a]*M[u]
+            emit("v_mul_f64 %%[a1%s], %%[a1%s], %%[r1%s]" % (p, p, p))
+            emit("v_mul_f64 %%[u1%s], %%[u1%s], %%[a2%s]" % (p, p, p))
+            emit("v_mul_f64 %%[r2%s], %%[r2%s], %%[u2%s]" % (p, p, p))
 
     def adds(p):
-        emit("v_add_f64 %%[acc], %%[acc], -%%[a1%s]" % p)
-        emit("v_add_f64 %%[acc], %%[acc], -%%[a2%s]" % p)
+        if upr == 2:
+            emit("v_add_f64 %%[acc], %%[acc], -%%[a1%s]" % p)
+            emit("v_add_f64 %%[acc], %%[acc], -%%[a2%s]" % p)
+        else:
+            emit("v_add_f64 %%[acc], %%[acc], -%%[a1%s]" % p)
+            emit("v_add_f64 %%[acc], %%[acc], -%%[u1%s]" % p)
+            emit("v_add_f64 %%[acc], %%[acc], -%%[r2%s]" % p)
 
     def aux_head(s):         # aux operand: scale by M[aux] (aux = d1 & VM_AUX_MASK), or publish the reciprocal there (VM_D1_RCP lanes)
         emit("v_and_b32 %%[ax], 0xfffff8, %s" % d(s, 1))
@@ -185,15 +195,17 @@ def variant(n):
 
 def render():
     out = ["// GENERATED by tools/gen_vm_asm.py — do not edit.  Instruction stream of the LDS VM executor (ros3_kernel.hip: vm_run).", ""]
-    for n in (4, 6, 8):
-        lines, clob = variant(n)
-        out.append("#define MISTRA_VM_ASM_N%d \\" % n)
+    for n, upr in ((4, 2), (6, 2), (8, 2), (4, 3)):
+        lines, clob = variant(n, upr)
+        tag = "N%d" % n if upr == 2 else "N%d_SWEEP" % n      # _SWEEP: records of three two-operand updates (schedule.hpp: VM_SWEEP_UPD_PER_REC)
+        out.append("#define MISTRA_VM_ASM_%s \\" % tag)
         for i, ln in enumerate(lines):
             sep = "\\n" if ln.endswith(":") else "\\n\\t"
             last = i == len(lines) - 1
             out.append('  "%s%s"%s' % (ln, "" if last else sep, "" if last else " \\"))
         out.append("")
-        out.append("#define MISTRA_VM_CLOBBER_N%d %s" % (n, clob))
+        if upr == 2:
+            out.append("#define MISTRA_VM_CLOBBER_N%d %s" % (n, clob))
         out.append("")
     return "\n".join(out)
 
