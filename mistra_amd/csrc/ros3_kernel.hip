@@ -1341,10 +1341,12 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       put((q & 1) ? (pw >> 16) : (pw & 0xFFFFu), -jac0[q]);
     }
 #pragma unroll
-    for (int q = 0; q < ZPT; q++) {
-      uint32_t pw = zpos[q / 2];
+    for (int q = 0; q < ZPT; q++) {      // fill-in slots: -0.0.  A diagonal among them (a species whose rate does not depend on itself) sits in
+      uint32_t pw = zpos[q / 2];          // slot 0 of its thread (schedule.cpp sorts them there): the other slots have nothing to select
       asm volatile("" : "+v"(pw));
-      put((q & 1) ? (pw >> 16) : (pw & 0xFFFFu), -0.0);
+      const uint32_t p = (q & 1) ? (pw >> 16) : (pw & 0xFFFFu);
+      if (q == 0) put(p, -0.0);
+      else M[p == kPosNone ? (uint32_t)(NNZ + NVAR + 2) : (p & 0x7FFFu)] = -0.0;
     }
     if (zero_diag) flags[0] = 1;
     lds_barrier();

@@ -851,7 +851,13 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
     }
     S.jvs = build_gsum_program(outs, slot, S.jpt, nt, S.jb_base_bytes, zero_cell_bytes);
     S.zero_pos.assign((size_t)S.zpt * nt, POS_NONE);
-    for (size_t i = 0; i < zero.size(); i++) S.zero_pos[i] = (uint16_t)(zero[i] | (is_diag[(size_t)zero[i]] ? POS_DIAG : 0));
+    // diagonals among the fill-in slots (species whose rate of change does not depend on themselves) first: they land in every
+    // thread's slot 0, the only one the kernel treats as a possible diagonal (ros3_kernel.hip: prepare)
+    std::stable_sort(zero.begin(), zero.end(), [&](int x, int y) { return is_diag[(size_t)x] > is_diag[(size_t)y]; });
+    for (size_t i = 0; i < zero.size(); i++) {
+      if (is_diag[(size_t)zero[i]] && i >= (size_t)nt) throw std::logic_error("more fill-in diagonals than threads");
+      S.zero_pos[i] = (uint16_t)(zero[i] | (is_diag[(size_t)zero[i]] ? POS_DIAG : 0));
+    }
   }
   S.diag_pos.assign((size_t)S.spt * nt, POS_NONE);
   for (int s = 0; s < m.nvar; s++) S.diag_pos[(size_t)s] = (uint16_t)m.diag[(size_t)s];
