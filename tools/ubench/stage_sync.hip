@@ -2,7 +2,7 @@
 // slot (8 x ds_read_b128), and helper waves that fill the other slot between two workgroup barriers (4 LDS gathers, 2 x ds_write_b128
 // each) — the hand-over pattern of the staged tail chain.  Reported: cycles per set for the chain, and what the
 // helpers spend working / waiting.
-//   hipcc --offload-arch=gfx950 -O2 -o stage_sync stage_sync.hip && ./stage_sync          (on the GPU box)
+//   hipcc --offload-arch=gfx950 -O2 [-DCHAIN_DPP] [-DHELPER_UNROLL=25] -o stage_sync stage_sync.hip && ./stage_sync          (on the GPU box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -32,7 +32,11 @@ __global__ __launch_bounds__(512) void k(long long* out, double* sink, int sets,
       f64x2 c[8];
 #pragma unroll
       for (int p = 0; p < 8; p++) c[p] = s[p * 64];
+#ifdef CHAIN_DPP      // the chain's arithmetic as in the kernel: dependent DPP multiply-adds behind their wait states
+      for (int i = 0; i < nwork; i++) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(1e-9));
+#else
       for (int i = 0; i < nwork; i++) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(x));
+#endif
 #pragma unroll
       for (int p = 0; p < 8; p++) x += c[p][0] * 1e-30 + c[p][1] * 1e-30;
     }
@@ -42,6 +46,9 @@ __global__ __launch_bounds__(512) void k(long long* out, double* sink, int sets,
     unsigned idx = (unsigned)(lane * 37 + wave * 101) % (unsigned)(lds_doubles - 4096);
     double v0 = lds[idx], v1 = lds[idx + 517], v2 = lds[idx + 1033], v3 = lds[idx + 1549];
     long long tp = clock64();
+#ifdef HELPER_UNROLL      // the helpers' loop body as straight-line code, each pass new to the instruction buffer (as in the kernel's unrolled form)
+#pragma unroll HELPER_UNROLL
+#endif
     for (int q = 0; q < sets; q++) {
       if (wave <= HELPERS) {
         f64x2* s = reinterpret_cast<f64x2*>(stage + (q & 1) * 1024) + lane;
@@ -71,10 +78,12 @@ int main() {
     const int lds_doubles = big ? 20000 : 6144;      // 160 KB (one workgroup per CU, like the tot kernel) | 48 KB
     const size_t bytes = (size_t)lds_doubles * 8;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    for (int helpers : {0, 4}) {
+    for (int helpers : {0, 4, 7}) {
       for (int nwork : {0, 50, 100}) {
-        if (helpers == 4) hipLaunchKernelGGL(k<4>, dim3(nblk), dim3(512), bytes, 0, d_out, d_sink, sets, nwork, lds_doubles);
+        if (helpers == 7) hipLaunchKernelGGL(k<7>, dim3(nblk), dim3(512), bytes, 0, d_out, d_sink, sets, nwork, lds_doubles);
+        else if (helpers == 4) hipLaunchKernelGGL(k<4>, dim3(nblk), dim3(512), bytes, 0, d_out, d_sink, sets, nwork, lds_doubles);
         else hipLaunchKernelGGL(k<0>, dim3(nblk), dim3(512), bytes, 0, d_out, d_sink, sets, nwork, lds_doubles);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(h, d_out, sizeof h, hipMemcpyDeviceToHost));
