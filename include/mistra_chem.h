@@ -186,12 +186,17 @@ int mistra_chem_drive_device(int mech, int ncell, double* d_s1, double* d_s3, do
  *   d_alpha, d_vmean [NSPEC]  alpha(:,k), vmean(:,k) of /kpp_2aer/ | /kpp_2tot/ (accommodation coefficients, mean molecular speeds)
  *   d_xkmt [nkc][NSPEC]       xkmt(:,1:nkc,k) of /kpp_laer/ | /kpp_ltot/: in/out — written for the 50 exchanged species of the active
  *                             bins (cm > 0 and cw > 0), everything else left as it is, like the reference
- * and for the call: d_rq [nka][nkt] = rq(1:nkt,1:nka) of /cb50/ (particle radii, um), kw [nka] (host) and ka of /blck06/, ifeed and
- * nkc_l of module config.  The summation order is the reference's: bit-identical coefficients.  The LWC-weighted sedimentation
- * velocity vt(kc,k) that the same routine integrates (consumed by SR sedl, microphysics) is outside this path and not computed. */
-int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const double* d_rq, const int32_t* kw, int ka, int ifeed,
+ *   d_t, d_p                  t(k), p(k) of /cb53/: temperature and pressure (arguments of the terminal velocity vterm, str.f90:2793)
+ *   d_vt [nkc]                vt(1:nkc,k) of /kpp_vt/: in/out — the LWC-weighted sedimentation velocity of every bin with cw > 0 ("computed
+ *                             whatever LWC", kpp.f90:2421-2432: also for bins with cm = 0), read by SR sedl (str.f90:2704, 2751); bins with
+ *                             cw <= 0 left as they are.  d_vt = NULL: not computed (then d_t, d_p may be NULL too)
+ * and for the call: d_rq [nka][nkt] = rq(1:nkt,1:nka) of /cb50/ (particle radii, um), kw [nkw] (host; nkw must be nka = 70) and ka of /blck06/,
+ * ifeed and nkc_l of module config.  The summation order is the reference's: bit-identical coefficients; vt likewise up to 10 um radius
+ * (Stokes regime), to the last place of the device log / exp above (Beard's polynomial).  With d_vt the call does everything
+ * fast_k_mt_a / fast_k_mt_t do: the Fortran call can be dropped.  Asynchronous on hip_stream; nothing is staged, kw travels with the launch. */
+int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const double* d_rq, const int32_t* kw, int nkw, int ka, int ifeed,
                                  int nkc_l, const double* d_cw, const double* d_cm, const double* d_freep, const double* d_alpha,
-                                 const double* d_vmean, double* d_xkmt, void* hip_stream);
+                                 const double* d_vmean, double* d_xkmt, const double* d_t, const double* d_p, double* d_vt, void* hip_stream);
 
 /* ---- liq_parm, second slice: the Henry constants of henry_a (mech = aer; kpp.f90:1914-2145) | henry_t (tot;
  * kpp.f90:1676-1907) and the forward / backward rate constants of the aqueous equilibria of equil_co_a (kpp.f90:3162-3363) | equil_co_t

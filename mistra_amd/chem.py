@@ -77,7 +77,7 @@ def lib():
         L.mistra_chem_unpack_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.mistra_chem_budgets_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp, vp]
         L.mistra_chem_rates_env_from_c_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp]
-        L.mistra_chem_fast_k_mt_device.argtypes = [C.c_int, C.c_int, vp, vp, _ip, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+        L.mistra_chem_fast_k_mt_device.argtypes = [C.c_int, C.c_int, vp, vp, _ip, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.mistra_chem_henry_device.argtypes = [C.c_int, C.c_int, vp, vp, vp]
         L.mistra_chem_equil_co_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.mistra_chem_drive_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp]
@@ -315,12 +315,13 @@ def drive(mech, s1, s3, sl1, sion1, scal, env, var, fix, tin, dt, ierr, stats, t
                                           float(dt), _p(ierr), _p(stats), _p(texit_hexit), _p(bg), _p(bgs), _stream(var)))
 
 
-def fast_k_mt(mech, ff, rq, kw, ka, ifeed, nkc_l, cw, cm, freep, alpha, vmean, xkmt):
-    """fast_k_mt_a (aer) / fast_k_mt_t (tot) for a batch of layers: xkmt [nlayer, nkc, NSPEC] updated in place (include/mistra_chem.h)."""
+def fast_k_mt(mech, ff, rq, kw, ka, ifeed, nkc_l, cw, cm, freep, alpha, vmean, xkmt, t=None, p=None, vt=None):
+    """fast_k_mt_a (aer) / fast_k_mt_t (tot) for a batch of layers: xkmt [nlayer, nkc, NSPEC] and, when given, the sedimentation velocity
+    vt [nlayer, nkc] (needs t, p [nlayer]) updated in place (include/mistra_chem.h)."""
     mid, _ = _mech_id(mech)
     kwa = np.ascontiguousarray(kw, np.int32)
-    _check(lib().mistra_chem_fast_k_mt_device(mid, xkmt.shape[0], _p(ff), _p(rq), kwa.ctypes.data_as(_ip), int(ka), int(ifeed), int(nkc_l), _p(cw), _p(cm),
-                                              _p(freep), _p(alpha), _p(vmean), _p(xkmt), _stream(xkmt)))
+    _check(lib().mistra_chem_fast_k_mt_device(mid, xkmt.shape[0], _p(ff), _p(rq), kwa.ctypes.data_as(_ip), int(kwa.size), int(ka), int(ifeed), int(nkc_l),
+                                              _p(cw), _p(cm), _p(freep), _p(alpha), _p(vmean), _p(xkmt), _p(t), _p(p), _p(vt), _stream(xkmt)))
 
 
 def henry(mech, tt, out):

@@ -88,6 +88,9 @@ bool mistra::PackTable::load(const std::string& path, std::string* err) {
   if (!f) { if (err) *err = "cannot open " + path; return false; }
   int32_t h[16];
   bool ok = std::fread(h, sizeof h, 1, f) == 1 && h[0] == 0x4B41504B && h[1] == 1;
+  // header counts are bounded before anything is sized by them (a stale or corrupt file must not throw out of an extern "C" entry)
+  for (int i = 2; ok && i < 16; i++) ok = h[i] >= 0 && h[i] <= (1 << 20);
+  ok = ok && h[2] > 0 && h[3] >= 0 && h[4] > 0 && h[5] > 0 && h[6] >= 1 && h[6] <= 8 && h[7] <= 1 && h[11] <= kBudSlots;
   auto rd = [&](std::vector<int32_t>& v, size_t n) { v.resize(n); return n == 0 || std::fread(v.data(), 4, n, f) == n; };
   if (ok) {
     nvar = h[2]; nfix = h[3]; j2 = h[4]; j6 = h[5]; nkc = h[6]; preclamp = h[7];
@@ -96,6 +99,31 @@ bool mistra::PackTable::load(const std::string& path, std::string* err) {
          rd(envc, (size_t)h[15] * 2);
   }
   std::fclose(f);
+  if (ok) {      // every index the kernels of pack.hip follow (reaction numbers and env slots: setup_mech, which knows NREACT and the env size)
+    const int nspec = nvar + nfix, nl = j2 * nkc, ni = j6 * nkc, nterms = (int)terms.size() / 3, nwords = (int)term_words.size();
+    for (int i = 0; ok && i < n_pack(); i++) {
+      const int32_t* e = &pack[(size_t)4 * i];
+      ok = e[0] >= 0 && e[0] < nspec && (e[1] == 0 || e[1] == 1) && e[2] >= 0 && e[2] < (e[1] == 0 ? nl : ni) && (e[3] == 0 || e[3] == 1);
+    }
+    for (int i = 0; ok && i < n_fix(); i++) {
+      const int32_t* e = &fix[(size_t)3 * i];
+      ok = e[0] >= 0 && e[0] < nspec && e[1] >= 0 && e[1] <= 3 && e[2] >= 0 && e[2] < 4;
+    }
+    for (int i = 0; ok && i < n_unpack(); i++) {
+      const int32_t* e = &unpack[(size_t)4 * i];
+      ok = (e[0] == 0 || e[0] == 1) && e[1] >= 0 && e[1] < (e[0] == 0 ? nl : ni) && e[2] >= 0 && e[2] < nvar && (e[3] == 0 || e[3] == 1);
+    }
+    for (int i = 0; ok && i < n_slots(); i++)
+      ok = slot_id[(size_t)i] >= 1 && slot_id[(size_t)i] <= kBudSlots && slot_first[(size_t)i] >= 0 && slot_first[(size_t)i] <= slot_first[(size_t)i + 1] &&
+           slot_first[(size_t)i + 1] <= nterms;
+    for (int q = 0; ok && q < nterms; q++) {
+      const int w0 = terms[(size_t)3 * q + 2], w1 = q + 1 < nterms ? terms[(size_t)3 * (q + 1) + 2] : nwords;
+      ok = terms[(size_t)3 * q + 1] >= 0 && w0 >= 0 && w0 <= w1 && w1 <= nwords;
+    }
+    for (int32_t w : term_words) ok = ok && w >= 0 && w < nvar;      // (the budget kernel reads V[] only)
+    for (size_t a = 0; ok && a < acc.size() / 2; a++) ok = acc[2 * a] >= 1 && acc[2 * a] <= acc[2 * a + 1] && acc[2 * a + 1] <= kBudSlots;
+    for (int i = 0; ok && i < n_envc(); i++) ok = envc[(size_t)2 * i] >= 0 && envc[(size_t)2 * i + 1] >= 0 && envc[(size_t)2 * i + 1] < nspec;
+  }
   if (!ok && err) *err = path + ": not a hand-over table";
   return ok;
 }
@@ -207,7 +235,7 @@ struct MechState {
   // fast_k_mt_a / fast_k_mt_t (aer, tot): the exchanged species and the size-axis limits of the last call
   bool kmt_ready = false;
   KmtTable kmt_tab;
-  DevBuf<int32_t> kmt_lex, kmt_kw;
+  DevBuf<int32_t> kmt_lex;
   // henry_x / equil_co_x (aer, tot)
   bool liq_ready = false;
   LiqTable liq_tab;
@@ -232,7 +260,7 @@ struct MechState {
     pk_pack.release(); pk_fix.release(); pk_unpack.release(); pk_slot_id.release(); pk_slot_first.release(); pk_terms.release(); pk_words.release();
     pk_acc.release(); pk_envc.release(); pk_aptr.release(); pk_afac.release(); map_gas_m2k.release(); map_gas_k2m.release(); map_rad_m2k.release();
     map_rad_k2m.release(); d_env.release(); d_rct.release(); pack_ready = maps_ready = false;
-    kmt_lex.release(); kmt_kw.release(); kmt_ready = false;
+    kmt_lex.release(); kmt_ready = false;
     lq_hkind.release(); lq_eof.release(); lq_foff.release(); lq_boff.release(); lq_fkind.release(); lq_farg.release(); lq_ha0.release(); lq_hb0.release();
     lq_fa.release(); lq_fb.release(); liq_ready = false;
     dense_rows.release(); schur_cells.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); rates_fslot.release(); s_env.release(); rates_ready = false;
@@ -354,8 +382,10 @@ int setup_mech(DeviceState& D, int mech) {
     if (S.pack_tab.load(mech_dir() + "/" + kMechName[mech] + ".pack", &perr)) {
       const PackTable& T = S.pack_tab;
       if (T.nvar != S.tab.nvar || T.nfix != S.tab.nfix) return fail(std::string(kMechName[mech]) + ".pack does not belong to this mechanism");
-      for (int32_t w : T.term_words)
-        if (w < 0 || w >= T.nvar) return fail(std::string(kMechName[mech]) + ".pack: a budget term reads a fixed species");
+      for (size_t q = 0; q < T.terms.size() / 3; q++)
+        if (T.terms[3 * q + 1] >= S.tab.nreact) return fail(std::string(kMechName[mech]) + ".pack: a budget term names a reaction the mechanism does not have");
+      for (int i = 0; i < T.n_envc(); i++)
+        if (S.rates_ready && T.envc[(size_t)2 * i] >= S.rates_nenv) return fail(std::string(kMechName[mech]) + ".pack: a concentration slot lies outside the rate evaluator's input");
       HIP_TRY(S.pk_pack.upload(T.pack)); HIP_TRY(S.pk_fix.upload(T.fix)); HIP_TRY(S.pk_unpack.upload(T.unpack));
       HIP_TRY(S.pk_slot_id.upload(T.slot_id)); HIP_TRY(S.pk_slot_first.upload(T.slot_first)); HIP_TRY(S.pk_terms.upload(T.terms));
       HIP_TRY(S.pk_words.upload(T.term_words)); HIP_TRY(S.pk_acc.upload(T.acc)); HIP_TRY(S.pk_envc.upload(T.envc));
@@ -768,12 +798,13 @@ int mistra_chem_drive_device(int mech, int ncell, double* d_s1, double* d_s3, do
   return 0;
 }
 
-int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const double* d_rq, const int32_t* kw, int ka, int ifeed, int nkc_l,
-                                 const double* d_cw, const double* d_cm, const double* d_freep, const double* d_alpha, const double* d_vmean,
-                                 double* d_xkmt, void* hip_stream) {
+int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const double* d_rq, const int32_t* kw, int nkw, int ka, int ifeed,
+                                 int nkc_l, const double* d_cw, const double* d_cm, const double* d_freep, const double* d_alpha,
+                                 const double* d_vmean, double* d_xkmt, const double* d_t, const double* d_p, double* d_vt, void* hip_stream) {
   if (int rc = check_call(mech, 1)) return rc;
   if (nlayer == 0) return 0;
   if (!d_ff || !d_rq || !kw || !d_cw || !d_cm || !d_freep || !d_alpha || !d_vmean || !d_xkmt) return fail("null pointer");
+  if (d_vt && (!d_t || !d_p)) return fail("the sedimentation velocity needs the layers' temperature and pressure (d_t, d_p)");
   hipPointerAttribute_t attr;
   if (hipPointerGetAttributes(&attr, d_xkmt) != hipSuccess) return fail("d_xkmt is not a device pointer");
   DeviceState* D = device_slot(attr.device);
@@ -781,17 +812,15 @@ int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const
   MechState& S = D->mech[mech];
   if (!S.kmt_ready) return fail(std::string("the ") + kMechName[mech] + " mechanism has no mass-transfer routine (fast_k_mt_a: aer, fast_k_mt_t: tot)");
   const KmtTable& T = S.kmt_tab;
+  if (nkw != T.nka || T.nka > kKmtMaxNka) return fail("kw does not have nka entries");
   if (ka < 0 || ka > T.nka || nkc_l < 1 || nkc_l > T.nkc) return fail("ka / nkc_l out of range");
-  std::vector<int32_t> kwv(kw, kw + T.nka);
-  for (int32_t v : kwv)
-    if (v < 0 || v > T.nkt) return fail("kw out of range");      // the kernel's loop limits: checked here, on the host
+  KmtDev K{S.kmt_lex.p, {0}, T.nx, T.nka, T.nkt, T.nkc, S.tab.nvar + S.tab.nfix, ka, ifeed, nkc_l};
+  for (int i = 0; i < T.nka; i++) {
+    if (kw[i] < 0 || kw[i] > T.nkt) return fail("kw out of range");      // the kernel's loop limits: checked here, on the host
+    K.kw[i] = kw[i];
+  }
   HIP_TRY(hipSetDevice(D->id));
-  std::lock_guard<std::mutex> lock(g_mu);
-  HIP_TRY(S.kmt_kw.reserve(kwv.size()));
-  HIP_TRY(hipMemcpyAsync(S.kmt_kw.p, kwv.data(), kwv.size() * sizeof(int32_t), hipMemcpyHostToDevice, static_cast<hipStream_t>(hip_stream)));
-  HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));      // (kwv is a local)
-  const KmtDev K{S.kmt_lex.p, S.kmt_kw.p, T.nx, T.nka, T.nkt, T.nkc, S.tab.nvar + S.tab.nfix, ka, ifeed, nkc_l};
-  LAUNCH_TRY(launch_fast_k_mt(K, nlayer, d_ff, d_rq, d_cw, d_cm, d_freep, d_alpha, d_vmean, d_xkmt, static_cast<hipStream_t>(hip_stream)));
+  LAUNCH_TRY(launch_fast_k_mt(K, nlayer, d_ff, d_rq, d_cw, d_cm, d_freep, d_alpha, d_vmean, d_xkmt, d_t, d_p, d_vt, static_cast<hipStream_t>(hip_stream)));
   return 0;
 }
 

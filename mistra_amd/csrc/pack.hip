@@ -16,6 +16,10 @@ namespace {
 
 constexpr int kNT = 256;
 
+// MAX(0.d0, x) as flang compiles it (x86 maxsd with the constant first: "0 > x ? 0 : x"): -0.0 stays -0.0 and a NaN stays a NaN —
+// checked with the box's flang at -O2 on the scalar and on the whole-array form (the drivers use both, tot.f:226-227, gas.f:151-156)
+__device__ __forceinline__ double fmax0(double v) { return 0.0 > v ? 0.0 : v; }
+
 __global__ __launch_bounds__(kNT) void pack_kernel(const PackDev P, int ncell, const double* __restrict__ s1, const double* __restrict__ s3,
                                                    double* __restrict__ sl1, double* __restrict__ sion1, const double* __restrict__ scal,
                                                    double* __restrict__ var, double* __restrict__ fix) {
@@ -31,8 +35,8 @@ __global__ __launch_bounds__(kNT) void pack_kernel(const PackDev P, int ncell, c
     else F[c0 - P.nvar] = v;
   };
   if (P.preclamp) {      // sl1(:,:,k)=max(0.d0,sl1(:,:,k)); sion1 likewise (tot.f:226-227): the model's arrays themselves
-    for (int i = t; i < nl; i += kNT) L[i] = L[i] > 0.0 ? L[i] : 0.0;      // max(0.d0, x): NaN -> 0 as flang's MAX does here (first argument wins)
-    for (int i = t; i < ni; i += kNT) I[i] = I[i] > 0.0 ? I[i] : 0.0;
+    for (int i = t; i < nl; i += kNT) L[i] = fmax0(L[i]);
+    for (int i = t; i < ni; i += kNT) I[i] = fmax0(I[i]);
     __syncthreads();
   }
   // C(gas_m2k(1,j)) = s1(gas_m2k(2,j),k); C(rad_m2k(1,j)) = s3(rad_m2k(2,j),k)
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(kNT) void pack_kernel(const PackDev P, int ncell, c
   for (int i = t; i < P.n_pack; i += kNT) {
     const int c0 = P.pack[4 * i], arr = P.pack[4 * i + 1], at = P.pack[4 * i + 2], clamp = P.pack[4 * i + 3];
     double v = arr == 0 ? L[at] : I[at];
-    if (clamp) v = v > 0.0 ? v : 0.0;
+    if (clamp) v = fmax0(v);
     put(c0, v);
   }
 }
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(kNT) void unpack_kernel(const PackDev P, int ncell,
   for (int i = t; i < P.n_unpack; i += kNT) {
     const int arr = P.unpack[4 * i], at = P.unpack[4 * i + 1], c0 = P.unpack[4 * i + 2], clamp = P.unpack[4 * i + 3];
     double v = V[c0];
-    if (clamp) v = v > 0.0 ? v : 0.0;
+    if (clamp) v = fmax0(v);
     (arr == 0 ? L : I)[at] = v;
   }
 }
@@ -117,23 +121,52 @@ __global__ __launch_bounds__(kNT) void env_from_c_kernel(const PackDev P, int nc
   env[(size_t)cell * nenv + slot] = c0 < P.nvar ? var[(size_t)cell * P.nvar + c0] : fix[(size_t)cell * P.nfix + (c0 - P.nvar)];
 }
 
+// vterm(a, t, p) (str.f90:2793-2863): terminal velocity of a droplet of radius a [m] — Stokes with the Cunningham correction up to 10 um,
+// Beard's polynomial in the logarithm of the Best number above (Pruppacher & Klett ch. 10).  The PARAMETER constants are formed as the
+// compiler folds them (left to right in double precision); one rounding per operation; a**3 = (a*a)*a as flang expands it; log / exp are
+// the device library's (regime 2 only: last-place differences against the host libm).
+__device__ double vterm_dev(double a, double t, double p) {
+  constexpr double g = 9.80665, r0 = 8.3144743 / 28.96546e-3, rhow = 1000.0;      // constants.f90:48,61,65,73,79
+  constexpr double b0 = -.318657e+1, b1 = .992696e+0, b2 = -.153193e-2, b3 = -.987059e-3, b4 = -.578878e-3, b5 = +.855176e-4, b6 = -.327815e-5;
+  constexpr double c1 = 2.0 * g / 9.0, c2 = 1.26, P0 = 101325.0, T0 = 293.15, lambda0 = 6.6e-8, c3 = c2 * lambda0 * P0 / T0, c4 = 32.0 * g / 3.0;
+  const double rho_a = p / (r0 * t);
+  const double eta = 3.7957e-06 + 4.9e-08 * t;
+  if (a <= 1.0e-5) return c1 * a * a * (rhow - rho_a) / eta * (1.0 + c3 * t / (a * p));
+  const double best = c4 * ((a * a) * a) * (rhow - rho_a) * rho_a / (eta * eta);
+  const double x = log(best);
+  double y = b6 * x + b5;
+  y = y * x + b4;
+  y = y * x + b3;
+  y = y * x + b2;
+  y = y * x + b1;
+  y = y * x + b0;
+  return eta * exp(y) / (2.0 * rho_a * a);
+}
+
 // fast_k_mt_a / fast_k_mt_t (kpp.f90:2683-2947 | 2421-2676): the mass-transfer coefficient of every exchanged species l into every
 // active chemical bin kc of a layer, integrated over the bin's part of the 2-D particle spectrum ff(jt,ia):
 //     xk1 = sum_ia sum_jt  vmean / (r/freep + 4/(3 alpha)) * r*r * ff(jt,ia) * 1e6       r = rq(jt,ia)*1e-6 [m]
 //     xkmt(lex(l),kc) = 4 pi / (3 cw(kc)) * xk1                                          where cm(kc) > 0 and cw(kc) > 0
+// and, "whatever LWC" (kpp.f90:2421-2432: also where cm(kc) = 0), the LWC-weighted sedimentation velocity of the bin that SR sedl reads
+// (str.f90:2704, 2751):
+//     xx1 = sum_ia sum_jt  r*r*r * vterm(r, t, p) * ff(jt,ia) * 1e6                       (the routine's l = 1 pass)
+//     vt(kc) = 4 pi / (3 cw(kc)) * xx1                                                    where cw(kc) > 0
 // One thread per (layer, bin, species) walks its sum in the reference's order (ia outer, jt inner; one rounding per operation), so the
 // coefficients are bit-identical; the lanes of a wave are the species of one (layer, bin): they read the same ff / rq element at a time
-// (broadcast).  The sedimentation velocity vt the routine also integrates (for sedl, microphysics) is not part of this path.
+// (broadcast).  Lane 0 carries the vt sum beside its species' (vt == nullptr: the caller does not want it).
 __global__ __launch_bounds__(64) void fast_k_mt_kernel(const KmtDev K, int nlayer, const double* __restrict__ ff, const double* __restrict__ rq,
                                                        const double* __restrict__ cw, const double* __restrict__ cm, const double* __restrict__ freep,
-                                                       const double* __restrict__ alpha, const double* __restrict__ vmean, double* __restrict__ xkmt) {
+                                                       const double* __restrict__ alpha, const double* __restrict__ vmean, double* __restrict__ xkmt,
+                                                       const double* __restrict__ tt, const double* __restrict__ pp, double* __restrict__ vt) {
   const int layer = blockIdx.x, kc = blockIdx.y + 1, l = threadIdx.x;      // kc 1-based as in the Fortran
   if (layer >= nlayer || kc > K.nkc_l || l >= K.nx) return;
   const double cmk = cm[(size_t)layer * K.nkc + (kc - 1)], cwk = cw[(size_t)layer * K.nkc + (kc - 1)];
-  if (!(cmk > 0.0)) return;                       // (the dry case only integrates vt)
+  const bool llchem = cmk > 0.0, do_vt = vt != nullptr && l == 0;      // (the dry case only integrates vt: lmax = 1, kpp.f90:2560-2566)
+  if (!llchem && !do_vt) return;
   const int sp = K.lex[l] - 1;
   const double al = alpha[(size_t)layer * K.nspec + sp], vm = vmean[(size_t)layer * K.nspec + sp], fp = freep[layer];
-  double x1 = 0.0, xk1 = 0.0;
+  const double tk = do_vt ? tt[layer] : 0.0, pk = do_vt ? pp[layer] : 0.0;
+  double x1 = 0.0, xk1 = 0.0, xx1 = 0.0;
   if (al > 0.0) x1 = 4.0 / (3.0 * al);            // 4./(3.*alpha): default-REAL literals, exact
   int ia0, ia1;                                   // summation limits (1): the aerosol-size axis, 1-based inclusive
   if (kc == 1 || kc == 3) { ia0 = K.ifeed == 2 ? 2 : 1; ia1 = K.ka; }
@@ -145,13 +178,21 @@ __global__ __launch_bounds__(64) void fast_k_mt_kernel(const KmtDev K, int nlaye
     else { jt0 = K.kw[ia - 1] + 1; jt1 = K.nkt; }
     for (int jt = jt0; jt <= jt1; jt++) {
       const double rqq = rq[(size_t)(ia - 1) * K.nkt + (jt - 1)] * 1.0e-6;      // rqm = rq * 1.d-6
-      const double x2 = vm / (rqq / fp + x1);
-      xk1 = xk1 + (((x2 * rqq) * rqq) * F[(size_t)(ia - 1) * K.nkt + (jt - 1)]) * 1.0e6;
+      const double fv = F[(size_t)(ia - 1) * K.nkt + (jt - 1)];
+      if (llchem) {
+        const double x2 = vm / (rqq / fp + x1);
+        xk1 = xk1 + (((x2 * rqq) * rqq) * fv) * 1.0e6;
+      }
+      if (do_vt) {
+        const double xvs = vterm_dev(rqq, tk, pk);
+        xx1 = xx1 + ((((rqq * rqq) * rqq) * xvs) * fv) * 1.0e6;
+      }
     }
   }
   if (cwk > 0.0) {
     constexpr double z4pi3 = 4.0 * 3.1415926535897932 / 3.0;      // z4pi3 = 4._dp * pi / 3._dp (constants.f90:54)
-    xkmt[((size_t)layer * K.nkc + (kc - 1)) * K.nspec + sp] = z4pi3 / cwk * xk1;
+    if (llchem) xkmt[((size_t)layer * K.nkc + (kc - 1)) * K.nspec + sp] = z4pi3 / cwk * xk1;
+    if (do_vt) vt[(size_t)layer * K.nkc + (kc - 1)] = z4pi3 / cwk * xx1;
   }
 }
 
@@ -230,10 +271,10 @@ hipError_t launch_equil_co(const LiqDev& L, int nlayer, int nkc, int j6, const d
 }
 
 hipError_t launch_fast_k_mt(const KmtDev& K, int nlayer, const double* ff, const double* rq, const double* cw, const double* cm, const double* freep,
-                            const double* alpha, const double* vmean, double* xkmt, hipStream_t stream) {
+                            const double* alpha, const double* vmean, double* xkmt, const double* tt, const double* pp, double* vt, hipStream_t stream) {
   if (nlayer <= 0) return hipSuccess;
-  if (K.nx > 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fast_k_mt_kernel, dim3((unsigned)nlayer, (unsigned)K.nkc_l), dim3(64), 0, stream, K, nlayer, ff, rq, cw, cm, freep, alpha, vmean, xkmt);
+  if (K.nx > 64 || K.nka > kKmtMaxNka) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fast_k_mt_kernel, dim3((unsigned)nlayer, (unsigned)K.nkc_l), dim3(64), 0, stream, K, nlayer, ff, rq, cw, cm, freep, alpha, vmean, xkmt, tt, pp, vt);
   return hipGetLastError();
 }
 

@@ -51,13 +51,15 @@ struct KmtTable {
   std::vector<int32_t> lex;        // C index (1-based) of each exchanged species
   bool load(const std::string& path, std::string* err);
 };
+constexpr int kKmtMaxNka = 96;
 struct KmtDev {
   const int32_t* lex;              // [nx], 1-based
-  const int32_t* kw;               // [nka], as COMMON /blck06/ holds it (1-based jt limits)
+  int32_t kw[kKmtMaxNka];          // [nka], as COMMON /blck06/ holds it (1-based jt limits): travels with the launch — calls on different
+                                   // streams cannot overwrite each other's limits, and nothing is staged or waited for
   int nx, nka, nkt, nkc, nspec, ka, ifeed, nkc_l;
 };
 hipError_t launch_fast_k_mt(const KmtDev& K, int nlayer, const double* ff, const double* rq, const double* cw, const double* cm, const double* freep,
-                            const double* alpha, const double* vmean, double* xkmt, hipStream_t stream);
+                            const double* alpha, const double* vmean, double* xkmt, const double* tt, const double* pp, double* vt, hipStream_t stream);
 }  // namespace mistra
 
 // ---- Henry constants and equilibrium rate constants (kpp.f90: henry_a 1914-2145, henry_t 1676-1907, equil_co_a 3162-3363,

@@ -4,10 +4,12 @@
 ! Linked with -Wl,--wrap=fast_k_mt_a_ / fast_k_mt_t_: liq_parm's calls (kpp.f90:617,637) land here.  For the calls selected by
 ! MISTRA_CAPTURE_KMT_SKIP_x / _EVERY_x / _MAX_x (x = a | t) and, inside them, up to MISTRA_CAPTURE_KMT_LAYERS layers with an active
 ! bin (cm > 0), it records what the routine READS for that layer — the particle spectrum ff(:,:,k), cw(:,k), cm(:,k), freep(k),
-! alpha(:,k), vmean(:,k), plus once per record rq, kw, ka, ifeed, nkc_l — and xkmt(:,:,k) before and after the real call, into
-! MISTRA_CAPTURE_KMT_FILE.  No reference source is modified.
+! alpha(:,k), vmean(:,k), t(k), p(k) (the terminal velocity's arguments), plus once per record rq, kw, ka, ifeed, nkc_l — and xkmt(:,:,k)
+! and the LWC-weighted sedimentation velocity vt(:,k) of /kpp_vt/ before and after the real call, into MISTRA_CAPTURE_KMT_FILE.  No
+! reference source is modified.
 ! record: int32 {magic 'KMTC', variant (1 a | 2 t), k, nspec, nka, nkt, nkc, ka, ifeed, nkc_l}, int32 kw(nka),
-!         doubles rq(nkt,nka), ff(nkt,nka), cw(nkc), cm(nkc), freep, alpha(nspec), vmean(nspec), xkmt_before(nspec,nkc), xkmt_after(nspec,nkc)
+!         doubles rq(nkt,nka), ff(nkt,nka), cw(nkc), cm(nkc), freep, alpha(nspec), vmean(nspec), xkmt_before(nspec,nkc), xkmt_after(nspec,nkc),
+!         t(k), p(k), vt_before(nkc), vt_after(nkc)
 module capture_kmt_state
   implicit none
   integer :: unit_out = 0, nlayers = 4
@@ -64,7 +66,10 @@ subroutine wrap_fast_k_mt_a(freep, box, n_bl) bind(C, name="__wrap_fast_k_mt_a_"
   common /cb52/ ff(nkt, nka, n), fsum(n), nar(n)
   common /kpp_2aer/ alpha(NSPEC, nf), vmean(NSPEC, nf)
   common /kpp_laer/ henry(NSPEC, nf), xkmt(NSPEC, nkc, nf), xkef(NSPEC, nkc, nf), xkeb(NSPEC, nkc, nf)
-  double precision, allocatable :: before(:, :, :)
+  double precision :: theta, thetl, t, talt, p, rho, vt, vd, vdm
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  common /kpp_vt/ vt(nkc, nf), vd(nkt, nka), vdm(nkc)
+  double precision, allocatable :: before(:, :, :), vt_before(:, :)
   interface
      subroutine real_fast_k_mt_a(freep, box, n_bl) bind(C, name="__real_fast_k_mt_a_")
        double precision :: freep(*)
@@ -84,9 +89,10 @@ subroutine wrap_fast_k_mt_a(freep, box, n_bl) bind(C, name="__wrap_fast_k_mt_a_"
            end if
         end if
      end do
-     allocate (before(NSPEC, nkc, taken))
+     allocate (before(NSPEC, nkc, taken), vt_before(nkc, taken))
      do i = 1, taken
         before(:, :, i) = xkmt(:, :, klist(i))
+        vt_before(:, i) = vt(:, klist(i))
      end do
   end if
   call real_fast_k_mt_a(freep, box, n_bl)
@@ -95,7 +101,8 @@ subroutine wrap_fast_k_mt_a(freep, box, n_bl) bind(C, name="__wrap_fast_k_mt_a_"
         k = klist(i)
         write (unit_out) int(z'4B4D5443'), 1, k, NSPEC, nka, nkt, nkc, ka, ifeed, nkc_l
         write (unit_out) kw
-        write (unit_out) rq, ff(:, :, k), cw(:, k), cm(:, k), freep(k), alpha(:, k), vmean(:, k), before(:, :, i), xkmt(:, :, k)
+        write (unit_out) rq, ff(:, :, k), cw(:, k), cm(:, k), freep(k), alpha(:, k), vmean(:, k), before(:, :, i), xkmt(:, :, k), &
+             t(k), p(k), vt_before(:, i), vt(:, k)
      end do
      if (taken > 0) nrec(1) = nrec(1) + 1
   end if
@@ -118,7 +125,10 @@ subroutine wrap_fast_k_mt_t(freep, box, n_bl) bind(C, name="__wrap_fast_k_mt_t_"
   common /cb52/ ff(nkt, nka, n), fsum(n), nar(n)
   common /kpp_2tot/ alpha(NSPEC, nf), vmean(NSPEC, nf)
   common /kpp_ltot/ henry(NSPEC, nf), xkmt(NSPEC, nkc, nf), xkef(NSPEC, nkc, nf), xkeb(NSPEC, nkc, nf)
-  double precision, allocatable :: before(:, :, :)
+  double precision :: theta, thetl, t, talt, p, rho, vt, vd, vdm
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  common /kpp_vt/ vt(nkc, nf), vd(nkt, nka), vdm(nkc)
+  double precision, allocatable :: before(:, :, :), vt_before(:, :)
   interface
      subroutine real_fast_k_mt_t(freep, box, n_bl) bind(C, name="__real_fast_k_mt_t_")
        double precision :: freep(*)
@@ -138,9 +148,10 @@ subroutine wrap_fast_k_mt_t(freep, box, n_bl) bind(C, name="__wrap_fast_k_mt_t_"
            end if
         end if
      end do
-     allocate (before(NSPEC, nkc, taken))
+     allocate (before(NSPEC, nkc, taken), vt_before(nkc, taken))
      do i = 1, taken
         before(:, :, i) = xkmt(:, :, klist(i))
+        vt_before(:, i) = vt(:, klist(i))
      end do
   end if
   call real_fast_k_mt_t(freep, box, n_bl)
@@ -149,7 +160,8 @@ subroutine wrap_fast_k_mt_t(freep, box, n_bl) bind(C, name="__wrap_fast_k_mt_t_"
         k = klist(i)
         write (unit_out) int(z'4B4D5443'), 2, k, NSPEC, nka, nkt, nkc, ka, ifeed, nkc
         write (unit_out) kw
-        write (unit_out) rq, ff(:, :, k), cw(:, k), cm(:, k), freep(k), alpha(:, k), vmean(:, k), before(:, :, i), xkmt(:, :, k)
+        write (unit_out) rq, ff(:, :, k), cw(:, k), cm(:, k), freep(k), alpha(:, k), vmean(:, k), before(:, :, i), xkmt(:, :, k), &
+             t(k), p(k), vt_before(:, i), vt(:, k)
      end do
      if (taken > 0) nrec(2) = nrec(2) + 1
   end if

@@ -13,6 +13,11 @@ MECH_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mistr
 O21, O79, K5555 = float(np.float32(0.21)), float(np.float32(0.79)), float(np.float32(55.55))      # default-REAL literals
 
 
+def fmax0(v):
+    """MAX(0.d0, x) as flang compiles it (0 > x ? 0 : x): -0.0 and NaN pass through"""
+    return np.where(0.0 > np.asarray(v, np.float64), 0.0, v)
+
+
 def load(mech):
     return json.load(open(os.path.join(MECH_DIR, mech + ".pack.json")))
 
@@ -26,7 +31,7 @@ def pack(tab, c_prev, s1, s3, sl1, sion1, air, h2o, cvv, gas_m2k, rad_m2k):
     driver does not set keep it)."""
     C, L, I = np.array(c_prev, np.float64), np.array(sl1, np.float64), np.array(sion1, np.float64)
     if tab["preclamp"]:
-        L, I = np.maximum(0.0, L), np.maximum(0.0, I)
+        L, I = fmax0(L), fmax0(I)
     for c, src in gas_m2k:
         C[c - 1] = s1[src - 1]
     for c, src in rad_m2k:
@@ -36,7 +41,7 @@ def pack(tab, c_prev, s1, s3, sl1, sion1, air, h2o, cvv, gas_m2k, rad_m2k):
     src = {"sl1": L, "sion1": I}
     for c, arr, i, kc, clamp in tab["pack"]:
         v = src[arr][flat(tab, arr, i, kc)]
-        C[c - 1] = max(0.0, v) if clamp else v
+        C[c - 1] = fmax0(v) if clamp else v
     return C, L, I
 
 
@@ -49,7 +54,7 @@ def unpack(tab, C, s1, s3, sl1, sion1, gas_k2m, rad_k2m):
         s3[j] = C[c - 1]
     dst = {"sl1": L, "sion1": I}
     for arr, i, kc, c, clamp in tab["unpack"]:
-        dst[arr][flat(tab, arr, i, kc)] = max(0.0, C[c - 1]) if clamp else C[c - 1]
+        dst[arr][flat(tab, arr, i, kc)] = fmax0(C[c - 1]) if clamp else C[c - 1]
     return s1, s3, L, I
 
 

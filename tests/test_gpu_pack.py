@@ -86,6 +86,52 @@ def test_pack_budgets_unpack_against_captured_driver_calls(chem, mech):
 
 
 @pytest.mark.parametrize("mech", MECHS)
+def test_clamps_keep_minus_zero_and_nan_like_the_compiled_max(chem, mech):
+    """MAX(0.d0, x) of the drivers as flang compiles it: -0.0 stays -0.0 and NaN stays NaN (oracle/pack_py.py: fmax0, pinned on the CPU).  The
+    liquid-phase arrays of a captured call get -0.0, NaN and negative entries; pack (clamped sl1 / sion1 and C) and the hand-over must agree
+    with the restatement bit for bit, signs of zero and NaN payload-free positions included."""
+    import torch
+    from oracle import pack_py
+    dev = torch.device("cuda", 0)
+    g = _load(mech)
+    nv = NVAR[mech]
+    T = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    chem.set_species_maps(mech, g["gas_m2k"], g["gas_k2m"], g["rad_m2k"], g["rad_k2m"])
+    tab = pack_py.load(mech)
+    sc, dt = _scal(mech, g["args"])
+    sl1, sion1 = g["sl1_in"][:1].copy(), g["sion1_in"][:1].copy()
+    rng = np.random.default_rng(7)
+    for arr in (sl1, sion1):
+        idx = rng.permutation(arr.shape[1])
+        arr[0, idx[0::4]] = -0.0
+        arr[0, idx[1::4]] = np.nan
+        arr[0, idx[2::4]] = -1.5e-9
+    want_c, want_l, want_i = pack_py.pack(tab, g["c_in"][0], g["s1_in"][0], g["s3_in"][0], sl1[0], sion1[0], sc[0, 0], sc[0, 1], sc[0, 2:6], g["gas_m2k"], g["rad_m2k"])
+    var, fix, tl, ti = T(g["c_in"][:1, :nv]), T(g["c_in"][:1, nv:]), T(sl1), T(sion1)
+    chem.pack(mech, T(g["s1_in"][:1]), T(g["s3_in"][:1]), tl, ti, T(sc[:1]), var, fix)
+    torch.cuda.synchronize()
+    def same(a, b):      # NaN in the same places, every other entry the same BITS (the sign of a zero included)
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.where(np.isnan(a), 0.0, a).view(np.uint64), np.where(np.isnan(b), 0.0, b).view(np.uint64))
+    got_c = np.concatenate([var.cpu().numpy()[0], fix.cpu().numpy()[0]])
+    assert same(got_c, want_c), "C"
+    if tab["preclamp"]:
+        assert same(tl.cpu().numpy()[0], want_l) and same(ti.cpu().numpy()[0], want_i), "clamped model arrays"
+    # hand-over of a state with -0.0 / NaN / negative liquid-phase species
+    c_out = g["c_out"][0].copy()
+    lst = sorted({c for _, _, _, c, cl in tab["unpack"] if cl})
+    if lst:
+        c_out[np.array(lst[0::3]) - 1] = -0.0
+        c_out[np.array(lst[1::3]) - 1] = np.nan
+        c_out[np.array(lst[2::3]) - 1] = -2.0e-12
+    ws1, ws3, wl, wi = pack_py.unpack(tab, c_out, g["s1_in"][0], g["s3_in"][0], want_l, want_i, g["gas_k2m"], g["rad_k2m"])
+    s1, s3 = T(g["s1_in"][:1]), T(g["s3_in"][:1])
+    chem.unpack(mech, T(c_out[None, :nv]), s1, s3, tl, ti)
+    torch.cuda.synchronize()
+    assert same(tl.cpu().numpy()[0], wl) and same(ti.cpu().numpy()[0], wi) and same(s1.cpu().numpy()[0], ws1) and same(s3.cpu().numpy()[0], ws3)
+
+
+@pytest.mark.parametrize("mech", MECHS)
 def test_device_resident_driver_chain(chem, mech, oracles):
     """mistra_chem_drive_device: the whole driver for a batch of layers — pack -> env <- C -> Update_RCONST_x -> INTEGRATE_x -> budgets ->
     hand-over — with only the model arrays and the rate evaluator's inputs crossing PCIe.  The inputs are those of captured driver

@@ -68,6 +68,23 @@ def test_mass_transfer_coefficients_of_captured_layers(mech):
         assert np.array_equal(got, g["xkmt_after"][i]), "xkmt of layer k=%d differs" % int(g["k"][i])
         rewritten += int((got != g["xkmt_before"][i]).sum())
     assert rewritten > 0
+    # the LWC-weighted sedimentation velocity vt(kc,k) the same routine leaves in /kpp_vt/ for SR sedl ("whatever LWC": bins without
+    # chemistry too), every captured layer, from a poisoned start: bit for bit (Stokes and Beard regimes; the host libm is the reference's)
+    dry = 0
+    for i in range(g["ff"].shape[0]):
+        got = kmt_py.vt_layer(tab, g["ff"][i], g["rq"], g["kw"], int(g["ka"]), int(g["ifeed"]), int(g["nkc_l"]), g["cw"][i], float(g["t"][i]), float(g["p"][i]),
+                              np.full(g["vt_after"].shape[1], -7.0))
+        wet = g["cw"][i] > 0.0
+        assert np.array_equal(got[wet], g["vt_after"][i][wet]) and np.all(got[~wet] == -7.0), "vt of layer k=%d differs" % int(g["k"][i])
+        dry += int((wet & (g["cm"][i] <= 0.0)).sum())
+    assert dry >= 1, "no bin without chemistry but with liquid water in the fixture"
+
+
+def test_clamps_follow_the_compiled_max():
+    """MAX(0.d0, x) as flang compiles it (checked with the box's flang -O2, scalar and whole-array forms): -0.0 stays -0.0, NaN stays NaN."""
+    from oracle import pack_py
+    v = pack_py.fmax0(np.array([-0.0, 0.0, -1.0, 2.5, np.nan, -np.inf]))
+    assert np.signbit(v[0]) and v[0] == 0.0 and not np.signbit(v[1]) and v[2] == 0.0 and not np.signbit(v[2]) and v[3] == 2.5 and np.isnan(v[4]) and v[5] == 0.0
 
 
 @pytest.mark.parametrize("mech", ["aer", "tot"])
