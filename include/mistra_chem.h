@@ -223,6 +223,12 @@ int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const dou
 int mistra_chem_debug_first_step(int mech, int ncell, const double* var_in, const double* fix, const double* rconst,
                                  double tin, double tout, double* dump);
 
+/* Test hook for the one exit of RosenbrockIntegrator_x that INTEGRATE_x's fixed options put out of a test's reach: IERR = -6, "No of steps
+ * exceeds maximum bound" (gas.f:1199-1202), taken when Nstp > Max_no_steps = IPAR(3), which INTEGRATE_x leaves at its default of 100000
+ * (gas.f:729-732, 845-846, 1042).  Sets that bound for every later integrate call of the process; max_steps <= 0 restores 100000.  The
+ * compiled reference is driven the same way (Rosenbrock_x called with IPAR(3) set) in tests/test_oracle.py. */
+int mistra_chem_debug_set_max_steps(int max_steps);
+
 /* Text of the last error on this thread ("" if none). */
 const char* mistra_chem_last_error(void);
 

@@ -249,6 +249,11 @@ def update_rconst(mech, env):
     return out
 
 
+def debug_set_max_steps(n=0):
+    """Test hook: Max_no_steps of the integrator (0 = the reference's 100000); makes IERR = -6 reachable (include/mistra_chem.h)."""
+    _check(lib().mistra_chem_debug_set_max_steps(int(n)))
+
+
 def integrate_into(mech, var, fix, rconst, out, ierr, stats, tin=0.0, tout=10.0, texit_hexit=None, hstart=None):
     """Device path with caller-owned output tensors (no allocation inside the timed region of bench.py).  texit_hexit
     [ncell, 2]: exit time and last step size per cell (what INTEGRATE_x leaves in TIN and STEPMIN).  hstart [ncell]: OPT-IN

@@ -291,6 +291,7 @@ struct DeviceState {
 
 std::mutex g_mu;
 bool g_inited = false;
+int g_max_steps = 100000;      // Max_no_steps (gas.f:1042); only mistra_chem_debug_set_max_steps changes it
 std::vector<DeviceState> g_devs;
 
 DeviceState* device_slot(int hip_device) {
@@ -431,7 +432,7 @@ KernelArgs make_args(const MechState& S, int ncell, const double* var_in, const 
                      double tout, double* var_out, int32_t* ierr, int32_t* stats, double* th) {
   KernelArgs a;
   a.var_in = var_in; a.fix = fix; a.rconst = rconst; a.var_out = var_out; a.ierr = ierr; a.stats = stats;
-  a.texit_hexit = th; a.h_last = nullptr; a.hstart = nullptr; a.prof = nullptr; a.dump = nullptr; a.sing_rows = nullptr; a.n_temps = S.n_temps; a.tin = tin; a.tout = tout; a.ncell = ncell;
+  a.texit_hexit = th; a.h_last = nullptr; a.hstart = nullptr; a.prof = nullptr; a.dump = nullptr; a.sing_rows = nullptr; a.n_temps = S.n_temps; a.max_steps = g_max_steps; a.tin = tin; a.tout = tout; a.ncell = ncell;
   a.consts = S.consts.p; a.fun_fac = S.fun_fac.p; a.jac_fac = S.jac_fac.p; a.jvs_pos = S.jvs_pos.p;
   a.zero_pos = S.zero_pos.p; a.diag_pos = S.diag_pos.p;
   a.vdot = S.vdot.dev(); a.jvs = S.jvs.dev(); a.lu = S.lu.dev();
@@ -870,6 +871,12 @@ int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const dou
     if (T.fkind[i] == 3 && T.farg[i] > j6) return fail("j6 is smaller than an activity-coefficient index the routine reads");
   HIP_TRY(hipSetDevice(D->id));
   LAUNCH_TRY(launch_equil_co(liq_dev(*S), nlayer, nkc, j6, d_tt, d_conv2, d_xgamma, d_xkef, d_xkeb, static_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
+int mistra_chem_debug_set_max_steps(int max_steps) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_max_steps = max_steps > 0 ? max_steps : 100000;
   return 0;
 }
 

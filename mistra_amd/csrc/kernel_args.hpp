@@ -55,6 +55,7 @@ struct KernelArgs {
   double tin, tout;
   int32_t ncell;
   int32_t n_temps;             // partial-sum cells the solve programs use (zeroed per solve)
+  int32_t max_steps;           // Max_no_steps of RosenbrockIntegrator_x (gas.f:1199): 100000, the default INTEGRATE_x leaves (capi.cpp: make_args)
   // mechanism schedule
   const double* consts;        // [NCONST]
   const uint64_t* fun_fac;

@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   double ynew[SPT], fcn0[SPT], fcn[SPT], k1[SPT], k2[SPT], k3[SPT], yerr[SPT];
 
   while (fabs(Tend - T) >= Roundoff) {
-    if (nstp > 100000) { ierr = -6; break; }
+    if (nstp > a.max_steps) { ierr = -6; break; }      // Max_no_steps: 100000 (gas.f:1042, 1199)
     {
       const double H = Hget();
       if (((T + scalar_const(0.1) * H) == T) || (H <= Roundoff)) { ierr = -7; break; }

@@ -96,6 +96,10 @@ void kpp_set_variant(int v) { kpp_variant = v; }
  * the "truth" the opt-in Hstart-reuse mode of the kernel is measured against (tools/hstart_study.py).  0 = the reference's value. */
 static double opt_rtol = 0.0, opt_atol = 0.0, opt_hstart = 0.0;
 void kpp_set_options(double rtol, double atol, double hstart) { opt_rtol = rtol; opt_atol = atol; opt_hstart = hstart; }
+/* IPAR(3) of Rosenbrock_x, "maximum number of integration steps" (gas.f:845-846): INTEGRATE_x leaves it 0 = the default 100000 (gas.f:729-732).
+ * A smaller value makes the IERR = -6 exit (gas.f:1199-1202) reachable in a test; 0 = the reference's value. */
+static int opt_max_steps = 0;
+void kpp_set_max_steps(int n) { opt_max_steps = n; }
 
 /* factor lookup into X = [V | F | consts] */
 static inline double xval(const kpp_mech *m, const double *V, const double *F, int code) {
@@ -235,7 +239,7 @@ static int ros_integrator(const kpp_mech *m, double *Y, const double *FIX, const
   const int n = m->nvar, nnz = m->nnz;
   const double Roundoff = DBL_EPSILON, Hmin = 0.0, FacMin = 0.2, FacMax = 6.0, FacRej = 0.1, FacSafe = 0.9;
   const double AbsTol = opt_atol > 0.0 ? opt_atol : 1.0e-25, RelTol = opt_rtol > 0.0 ? opt_rtol : 1.0e-3, DeltaMin = 1.0e-5;
-  const int Max_no_steps = 100000;
+  const int Max_no_steps = opt_max_steps > 0 ? opt_max_steps : 100000;
   const double Hmax = fabs(Tend - Tstart);
   const double Hstart = fmin_f(fabs(opt_hstart > 0.0 ? opt_hstart : 1.0e-3), fabs(Tend - Tstart));
   double *K1 = w->K, *K2 = w->K + n, *K3 = w->K + 2 * n;

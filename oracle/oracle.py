@@ -72,6 +72,11 @@ def set_options(rtol=0.0, atol=0.0, hstart=0.0):
     _oracle_lib().kpp_set_options(float(rtol), float(atol), float(hstart))
 
 
+def set_max_steps(n=0):
+    """IPAR(3) of Rosenbrock_x (0 = INTEGRATE_x's 100000): makes the IERR = -6 exit testable."""
+    _oracle_lib().kpp_set_max_steps(int(n))
+
+
 class Oracle:
     def __init__(self, mech):
         self.mech = mech
@@ -242,6 +247,24 @@ class Reference:
         out = np.ctypeslib.as_array(g.c)[:self.nvar].copy()
         st = np.array(list(self.stats), np.int32)
         return out, st, t0.value, g.stepmin
+
+
+    def rosenbrock(self, var, fix, rconst, tin=0.0, tout=10.0, max_steps=0):
+        """Rosenbrock_x (gas.f:777) called as INTEGRATE_x calls it (gas.f:729-750) but with IPAR(3) = max_steps, the one option that makes
+        the "too many steps" exit (IERR = -6, gas.f:1199-1202) reachable -> (VAR, IERR, IPAR(11:18), Texit, Hexit)."""
+        g, s = self.gdata, SFX[self.mech]
+        np.ctypeslib.as_array(g.c)[:self.nvar] = var
+        np.ctypeslib.as_array(g.c)[self.nvar:] = fix
+        np.ctypeslib.as_array(g.rconst)[:] = rconst
+        y = np.array(var, np.float64)
+        atol, rtol = np.full(self.nvar, 1.0e-25), np.full(self.nvar, 1.0e-3)
+        ipar, rpar = np.zeros(20, np.int32), np.zeros(20, np.float64)
+        ipar[1], ipar[3], ipar[2] = 1, 2, max_steps      # IPAR(2) vector tolerances, IPAR(4) Ros3, IPAR(3) step limit
+        rpar[2] = 1.0e-3                                 # RPAR(3) starting step
+        t0, t1, ierr = C.c_double(tin), C.c_double(tout), C.c_int32(0)
+        getattr(self.lib, "rosenbrock_%s_" % s)(_d(y), C.byref(t0), C.byref(t1), _d(atol), _d(rtol), getattr(self.lib, "funtemplate_%s_" % s),
+                                                getattr(self.lib, "jactemplate_%s_" % s), _d(rpar), _i(ipar), C.byref(ierr))
+        return y, ierr.value, ipar[10:18].copy(), rpar[10], rpar[11]
 
 
 def read_capture(path):

@@ -20,7 +20,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import MECHS, REPO
+from conftest import MECHS, REPO, rel_diff
 
 pytestmark = pytest.mark.gpu
 GAMMA = (0.43586652150845899941601945119356, 0.24291996454816804366592249683314, 0.21851380027664058511513169485832e+01)
@@ -209,3 +209,33 @@ def test_backward_integration(chem, golden, oracles):
     res = chem.integrate("gas", V, F, K, 2.0e-3, 0.0)
     assert np.array_equal(res.ierr, ierr) and np.array_equal(res.stats, st)
     assert np.allclose(res.var, want, rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize("mech", MECHS)
+def test_too_many_steps_exit(chem, mech, golden, oracles):
+    """IERR = -6, "No of steps exceeds maximum bound" (gas.f:1199-1202): the bound Max_no_steps = 100000 that INTEGRATE_x leaves in place
+    is out of a test's reach, so kernel and oracle both get 5 through their test hooks (mistra_chem_debug_set_max_steps /
+    kpp_set_max_steps; the oracle's exit is pinned against the compiled reference's Rosenbrock_x called with IPAR(3) = 5,
+    tests/test_oracle.py).  Code, /Statistics/, exit time, last step and the state reached, cells that finish below the bound among them."""
+    from oracle import oracle as om
+    g, o = golden[mech], oracles[mech]
+    n = min(12, g["var_in"].shape[0])
+    V, F, K = g["var_in"][:n], g["fix"][:n], g["rconst"][:n]
+    touts = (10.0, 1.0e-6)      # (the second horizon is short enough for every cell to finish below the bound: the ordinary exit under the same hook)
+    try:
+        om.set_max_steps(5)
+        chem.debug_set_max_steps(5)
+        seen = set()
+        for tout in touts:
+            want, ierr, st = o.integrate_batch(V, F, K, 0.0, tout)
+            res = chem.integrate(mech, V, F, K, 0.0, tout)
+            assert np.array_equal(res.ierr, ierr), (res.ierr, ierr)
+            assert np.array_equal(res.stats, st)
+            assert rel_diff(res.var, want).max() <= 2e-5
+            seen |= set(int(x) for x in ierr)
+        assert seen == {1, -6}, seen
+    finally:
+        om.set_max_steps(0)
+        chem.debug_set_max_steps(0)
+    res = chem.integrate(mech, V[:2], F[:2], K[:2], 0.0, 10.0)
+    assert np.all(res.ierr == 1) and np.array_equal(res.stats[:, 2], g["stats"][:2, 2])

@@ -107,3 +107,28 @@ def test_reference_sensitivity_bounds_the_parity_tolerance(mech, golden, oracles
         set_variant(0)
     print("%s: reference spread under re-association %.3e" % (mech, worst))
     assert worst <= 5e-6
+
+
+@pytest.mark.skipif(not Reference.available(), reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("mech", MECHS)
+def test_too_many_steps_exit_matches_the_compiled_reference(mech, golden, oracles):
+    """IERR = -6 (gas.f:1199-1202): INTEGRATE_x leaves Max_no_steps at 100000, out of a test's reach, so both sides get the bound through
+    the option that exists for it — the compiled reference's Rosenbrock_x is called as INTEGRATE_x calls it but with IPAR(3) = 5, the
+    oracle through kpp_set_max_steps.  The integrator returns at the head of the first step that finds Nstp > 5 (rejected attempts count) with whatever Y it reached: code,
+    counters, exit time, last step and state must be the reference's bit for bit."""
+    from oracle import oracle as om
+    g, o, r = golden[mech], oracles[mech], Reference(mech)
+    try:
+        om.set_max_steps(5)
+        for i in (0, g["var_in"].shape[0] - 1):
+            v, ierr, st, te, he = o.integrate(g["var_in"][i], g["fix"][i], g["rconst"][i], 0.0, 10.0)
+            rv, rierr, rst, rte, rhe = r.rosenbrock(g["var_in"][i], g["fix"][i], g["rconst"][i], 0.0, 10.0, max_steps=5)
+            assert ierr == rierr == -6
+            assert np.array_equal(st, rst) and st[2] > 5
+            assert te == rte and he == rhe and te < 10.0
+            assert np.array_equal(v, rv)
+    finally:
+        om.set_max_steps(0)
+    # with the bound lifted the same call is the ordinary one again
+    v, ierr, st, te, he = o.integrate(g["var_in"][0], g["fix"][0], g["rconst"][0], 0.0, 10.0)
+    assert ierr == 1 and np.array_equal(v, g["var_out"][0])
