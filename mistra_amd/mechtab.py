@@ -62,3 +62,22 @@ def load(name):
     if name not in _cache:
         _cache[name] = MechTables(name)
     return _cache[name]
+
+
+def flop_counts(name):
+    """Floating-point operations of ONE internal Ros3 step of the reference's algorithm, COUNTED from the mechanism tables (SURVEY.md
+    §8d's accounting): KppDecomp_x's multiply-adds and quotients by walking its loops over the LU pattern (gas.f:6142-6176), three
+    KppSolve_x, three Fun_x (the reference also evaluates the one behind ros_FunTimeDerivative_x), one Jac_SP_x, the Ghimj build and the
+    stage / error vectors.  A multiply-add counts 2.  -> dict of the parts and their sum 'step'."""
+    t = load(name)
+    rows = [t.icol[t.crow[k]:t.crow[k + 1]] for k in range(t.nvar)]
+    upper = t.crow[1:] - t.diag - 1                    # entries right of the diagonal per row
+    lu_fma = sum(int(upper[j]) for k in range(t.nvar) for j in rows[k] if j < k)
+    lu_div = sum(int((rows[k] < k).sum()) for k in range(t.nvar))
+    solve = 2 * (t.nnz - t.nvar) + t.nvar              # forward + backward multiply-adds, one quotient per row
+    fun = len(t.a_fac) + len(t.vd_idx)                 # products RCT*V*..  +  signed sums
+    jac = len(t.b_fac) + len(t.jv_idx)
+    parts = {"lu": 2 * lu_fma + lu_div, "lu_fma": lu_fma, "lu_div": lu_div, "solves": 3 * solve, "fun": 3 * fun, "jac": jac,
+             "prepare": t.nnz + t.nvar, "vectors": 12 * t.nvar}
+    parts["step"] = parts["lu"] + parts["solves"] + parts["fun"] + parts["jac"] + parts["prepare"] + parts["vectors"]
+    return parts

@@ -110,3 +110,18 @@ def test_round_structure_tot(emu):
     assert 15 < n_lu < 40 and crit[:n_lu].sum() < 200
     n_sv = emu.emu_round_profile(h, 1, crit.ctypes.data_as(ip), tot.ctypes.data_as(ip), 512)
     assert 100 < n_sv < 200 and crit[:n_sv].sum() < 800
+
+
+def test_flop_counts_come_from_the_tables():
+    """bench.py's FP64 fraction uses operation counts WALKED from the mechanism tables (mistra_amd/mechtab.py: flop_counts), not scaled guesses:
+    for tot they reproduce the survey's own count of the reference's loops (KppDecomp_x 214 377 multiply-adds + 6 176
+    quotients, KppSolve_x 13 086 + 417, Fun_x 2 718 + 5 441, Jac_SP_x 2 297 + 9 423)."""
+    from mistra_amd.mechtab import flop_counts, load
+    c = flop_counts("tot")
+    assert (c["lu_fma"], c["lu_div"]) == (214377, 6176)
+    assert c["solves"] == 3 * (2 * 13086 + 417) and c["fun"] == 3 * (2718 + 5441) and c["jac"] == 2297 + 9423
+    assert c["step"] == 569818
+    assert flop_counts("gas")["step"] == 23527 and flop_counts("aer")["step"] == 213354
+    for m in ("gas", "aer"):
+        t, c = load(m), flop_counts(m)
+        assert c["lu_div"] == int(t.diag.sum() - t.crow[:-1].sum())      # one quotient per strictly-lower entry

@@ -10,22 +10,22 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 echo "== bench (tot, with cpu baseline)"; timeout -k 10 400 python3 $R/bench.py > $OUT/${TAG}_bench_tot_1gpu.json 2> $OUT/bench_tot.err
 for m in gas aer; do
-  echo "== bench $m"; timeout -k 10 200 python3 $R/bench.py --mech $m --no-cpu-baseline --no-parity > $OUT/${TAG}_bench_${m}_1gpu.json 2> $OUT/bench_$m.err
+  echo "== bench $m"; timeout -k 10 200 python3 $R/bench.py --mech $m --no-cpu-baseline --no-parity --no-extra > $OUT/${TAG}_bench_${m}_1gpu.json 2> $OUT/bench_$m.err
 done
 echo "== kernel trace + stats"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline --no-parity > $OUT/${TAG}_bench_tot_1gpu_under_rocprof.json 2> $OUT/stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline --no-parity --no-extra > $OUT/${TAG}_bench_tot_1gpu_under_rocprof.json 2> $OUT/stats.err
 for m in tot aer gas; do
   echo "== FETCH_SIZE $m"
-  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$m -- python3 $R/bench.py --mech $m --no-cpu-baseline --no-parity --steps 1 --warmup 0 > /dev/null 2> $OUT/fetch_$m.err
+  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$m -- python3 $R/bench.py --mech $m --no-cpu-baseline --no-parity --no-extra --steps 1 --warmup 0 > /dev/null 2> $OUT/fetch_$m.err
   echo "== WRITE_SIZE $m"
-  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$m -- python3 $R/bench.py --mech $m --no-cpu-baseline --no-parity --steps 1 --warmup 0 > /dev/null 2> $OUT/write_$m.err
+  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$m -- python3 $R/bench.py --mech $m --no-cpu-baseline --no-parity --no-extra --steps 1 --warmup 0 > /dev/null 2> $OUT/write_$m.err
 done
 echo "== L2 hits / misses (tot)"
-timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/tcc -- python3 $R/bench.py --no-cpu-baseline --no-parity --steps 1 --warmup 0 > /dev/null 2> $OUT/tcc.err
+timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/tcc -- python3 $R/bench.py --no-cpu-baseline --no-parity --no-extra --steps 1 --warmup 0 > /dev/null 2> $OUT/tcc.err
 echo "== SQ counters (4096 cells)"
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_IFETCH"; do
   d=$OUT/sq_$(echo $grp | cut -d' ' -f1)
-  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --no-cpu-baseline --no-parity --cells-per-gpu 4096 --steps 1 --warmup 0 > /dev/null 2>> $OUT/sq.err
+  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --no-cpu-baseline --no-parity --no-extra --cells-per-gpu 4096 --steps 1 --warmup 0 > /dev/null 2>> $OUT/sq.err
 done
 echo "== phase profile"; timeout -k 10 200 python3 $R/tools/profile_phases.py > $OUT/phases.log 2>&1
 echo "== dense tail block, cycles per section"; timeout -k 10 200 python3 $R/tools/diag_dense_stamps.py > $OUT/${TAG}_dense_lu_sections.txt 2>&1
@@ -69,7 +69,7 @@ with open(os.path.join(out, tag + "_bench_pmc_fetch_write.csv"), "w") as g:
             json.dump({"mech": mech, "cells": cells[mech], "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
                        "bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
                        "algorithmic_bytes_per_launch": cells[mech] * bench.ALG_BYTES[mech],
-                       "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --mech %s --no-cpu-baseline --no-parity --steps 1 --warmup 0`; "
+                       "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --mech %s --no-cpu-baseline --no-parity --no-extra --steps 1 --warmup 0`; "
                               "FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request), KiB -> bytes; see profiles/README.md" % mech,
                        "kernel": "ros3_integrate_kernel", "kernel_source_hash": bench.kernel_source_hash(), "round": int(tag[1:])},
                       open(os.path.join(out, "%s_traffic_%s.json" % (tag, mech)), "w"), indent=1)

@@ -8,7 +8,7 @@ grep -v "^  File\|^    \|Traceback\|amdgpu.ids" $D/ab.log
 grep -q FAILED $D/ab.log && exit 1
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 for m in aer gas tot; do for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$D/pmc_${m}_$c -- python3 $R/bench.py --mech $m --no-cpu-baseline --no-parity --steps 1 --warmup 0 > /dev/null 2> $R/$D/pmc_${m}_$c.err || exit 1
+  timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$D/pmc_${m}_$c -- python3 $R/bench.py --mech $m --no-cpu-baseline --no-parity --no-extra --steps 1 --warmup 0 > /dev/null 2> $R/$D/pmc_${m}_$c.err || exit 1
 done; done
 cd $R; python3 - $D <<'PY'
 import csv,glob,sys
