@@ -56,7 +56,10 @@ def build_lib(force=False, verbose=False):
     if force or _stale(LIB, objs):
         # the look-ahead rings of ros3_kernel.hip sit in registers the compiler does not know are busy: no library is linked
         # from a kernel object in which a ring-using function's own registers reach its ring (raises)
-        ring_register_report()
+        isa = ring_register_report()
+        hits = isa_hazard_report(isa["__isa_text__"])
+        if hits:
+            raise RuntimeError("hazards the hardware does not interlock inside hand-written assembly:\n  " + "\n  ".join(hits))
         cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
@@ -106,7 +109,112 @@ def ring_register_report(isa_path=None):
                 raise RuntimeError("%s: the compiler allocates v%d, inside the look-ahead ring's register blocks (v%d..)" % (name, hi, limit))
         elif name in ring_users and "ros3_integrate_kernel" not in name:
             raise RuntimeError("%s issues look-ahead ring loads but is not covered by the register check" % name)
+    report["__isa_text__"] = "\n".join(lines)
     return report
+
+
+# ---- hazards inside hand-written assembly.  The compiler's hazard recogniser and its s_waitcnt insertion do not look inside asm statements,
+#      and ros3_kernel.hip carries ~4 000 lines of hand-written / generated instructions (vm_exec_asm.inc, gsum_exec_asm.inc, the ring
+#      helpers, the DPP chains).  Three classes are checked on the ISA the compiler emits, each the cause of a wrong result or a GPU
+#      memory fault met while those were written:
+#   (i)   an SGPR written by v_readfirstlane / v_readlane and used as the scalar base of a vector-memory instruction less than 5 wait
+#         states later (round 3: a table base moved to scalar registers in front of a global_load -> memory access fault);
+#   (ii)  a DPP instruction whose DPP-read source (src0) was written by a VALU instruction less than 2 wait states earlier (the hardware
+#         does not interlock the read: tools/ubench/dpp.hip returns wrong sums with none);
+#   (iii) an `s_waitcnt vmcnt(N)` inside an asm block with N not below the number of distinct registers-in-flight slots the function's own
+#         asm loads fill (such a wait can never guarantee that the oldest slot has landed).
+# An instruction is one wait state, `s_nop N` is N + 1.  The scan is linear per function (labels are ignored: conservative for the
+# straight-line blocks these sequences are).
+def isa_hazard_report(isa_text, sgpr_vmem_wait=5, dpp_wait=2, seen=None):
+    """-> list of findings (empty = clean).  seen: optional dict that receives how many instructions of each class were examined."""
+    import re
+    hits = []
+    seen = seen if seen is not None else {}
+    for k in ("vmem_scalar_base", "dpp", "vmcnt", "functions"):
+        seen.setdefault(k, 0)
+    func, insts = None, []
+
+    def regs(tok, kind):
+        """register numbers named by an operand token of class `kind` ('s' or 'v'): s3, s[2:3], -v[4:5], |v7| ..."""
+        tok = tok.strip().lstrip("-").strip("|")
+        m = re.match(r"^%s(\d+)$" % kind, tok)
+        if m:
+            return {int(m.group(1))}
+        m = re.match(r"^%s\[(\d+):(\d+)\]$" % kind, tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        return set()
+
+    def flush():
+        if func is None:
+            return
+        seen["functions"] += 1
+        depth = len({i["ops"][0] for i in insts if i["asm"] and i["op"].startswith(("global_load", "buffer_load")) and i["ops"]})
+        for n, it in enumerate(insts):
+            if not it["asm"]:
+                continue
+            op, ops = it["op"], it["ops"]
+            if op.startswith(("global_", "buffer_", "scratch_", "flat_")):
+                base = set()
+                for o in ops:
+                    if re.match(r"^s\[\d+:\d+\]$", o.strip()):
+                        base |= regs(o, "s")
+                if base:
+                    seen["vmem_scalar_base"] += 1
+                    waited, k = 0, n - 1
+                    while k >= 0 and waited < sgpr_vmem_wait:
+                        p = insts[k]
+                        if p["op"] in ("v_readfirstlane_b32", "v_readlane_b32") and p["ops"] and regs(p["ops"][0], "s") & base:
+                            hits.append("%s: line %d `%s` reads a scalar base written by `%s` %d wait state(s) earlier (needs %d)" %
+                                        (func, it["line"], it["text"], p["text"], waited, sgpr_vmem_wait))
+                            break
+                        waited += p["wait"]
+                        k -= 1
+            if "_dpp" in op or re.search(r"\b(row_newbcast|row_shr|row_shl|row_ror|row_bcast|quad_perm|row_mirror|row_half_mirror|row_share|row_xmask):?", it["text"]):
+                src0 = regs(ops[1], "v") if len(ops) > 1 else set()
+                seen["dpp"] += 1
+                waited, k = 0, n - 1
+                while src0 and k >= 0 and waited < dpp_wait:
+                    p = insts[k]
+                    if p["op"].startswith("v_") and p["ops"] and regs(p["ops"][0], "v") & src0:
+                        hits.append("%s: line %d `%s` DPP-reads a register written by `%s` %d wait state(s) earlier (needs %d)" %
+                                    (func, it["line"], it["text"], p["text"], waited, dpp_wait))
+                        break
+                    waited += p["wait"]
+                    k -= 1
+            if op == "s_waitcnt" and depth:
+                m = re.search(r"vmcnt\((\d+)\)", it["text"])
+                seen["vmcnt"] += 1 if m else 0
+                if m and int(m.group(1)) >= depth:
+                    hits.append("%s: line %d `%s` waits for at most %s loads in flight, the function's asm loads fill only %d slots" %
+                                (func, it["line"], it["text"], m.group(1), depth))
+
+    in_asm = False
+    for ln, raw in enumerate(isa_text.split("\n"), 1):
+        if re.match(r"^[A-Za-z_.$][\w.$]*:", raw) and not raw.startswith(".L"):
+            flush()
+            func, insts, in_asm = raw.split(":")[0], [], False
+            continue
+        if "ASMSTART" in raw:
+            in_asm = True
+            continue
+        if "ASMEND" in raw:
+            in_asm = False
+            continue
+        t = raw.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        parts = t.split(None, 1)
+        op = parts[0]
+        ops = [o.strip() for o in re.split(r",(?![^\[]*\])", parts[1].split(" offset")[0])] if len(parts) > 1 else []
+        # modifiers that follow the last operand without a comma (row_newbcast:3 row_mask:0x1 ...) stay glued to it: cut them off
+        ops = [o.split()[0] if o.split() else o for o in ops]
+        wait = 1
+        if op == "s_nop" and ops:
+            wait = int(ops[0], 0) + 1
+        insts.append({"op": op, "ops": ops, "asm": in_asm, "line": ln, "text": t, "wait": wait})
+    flush()
+    return hits
 
 
 if __name__ == "__main__":
