@@ -177,6 +177,25 @@ int mistra_chem_drive_device(int mech, int ncell, double* d_s1, double* d_s3, do
                              double* d_env, double* d_var, double* d_fix, double tin, double dt, int32_t* d_ierr, int32_t* d_stats,
                              double* d_texit_hexit, double* d_bg, double* d_bgs, void* hip_stream);
 
+/* The same from the model's own arrays in HOST memory: what a Fortran caller hands over (shim/mistra_kpp_drive.f90: KPP_DRIVE_RUN) —
+ * ONE call per mechanism and 10-s step for all layers that run it (kpp.f90:4454-4467 chooses the mechanism per layer), instead of one
+ * x_drive per layer.  The arrays are the model's, dimensioned for n layers, layer k at its Fortran place:
+ *   layer [nlayer]            the k of each layer of the batch, 1-based, in the order of the layer loop
+ *   s1 [n][j1], s3 [n][j5]    s1(1:j1,1:n), s3(1:j5,1:n) of module gas_common (j1, j5: as given to mistra_chem_set_species_maps)
+ *   sl1 [n][nkc][j2]          COMMON /blck17/ sl1(j2,nkc,n); sion1 [n][nkc][j6] likewise
+ *   scal [nlayer][6], env [nlayer][rates_env_size]      per layer of the batch (not per k): air, h2o, cvv1..4 and the rate evaluator's input
+ *                             with the caller's part filled in (MISTRA_RATES_ENV_x); the concentrations in it are refilled on the device
+ *   bg [nlev][nrxn][2]        COMMON /budg/ bg(2,nrxn,nlev) (global_params.f90:110-115), or NULL; bg_level [nlayer]: kl (1-based) where layer
+ *                             i is the budget level il(kl), else 0 (gas.f:179-184)
+ *   bgs [n][122][2]           COMMON /budgs/ bgs(2,122,n), or NULL
+ * in/out: s1, s3, sl1, sion1 (rows of the batch's layers), bg (rows of its levels), bgs.  Out, per layer of the batch, each may be NULL: ierr,
+ * stats [8], t_h [3] as mistra_chem_integrate_ex returns them; c_packed [nlayer][NVAR+NFIX]: C = VAR | FIX as the pack half handed it to
+ * INTEGRATE_x (diagnostics / tests).  KPP's dummy products, which the drivers never set, start from 0 in every layer (the reference carries
+ * the previous layer's leftovers: INTEGRATION.md §4).  Synchronous; one pinned block up, the device chain on a private stream, one block down. */
+int mistra_chem_drive(int mech, int nlayer, const int32_t* layer, int n, double* s1, double* s3, double* sl1, double* sion1, const double* scal,
+                      const double* env, double tin, double dt, int32_t* ierr, int32_t* stats, double* t_h, double* bg, int nrxn,
+                      const int32_t* bg_level, double* bgs, double* c_packed);
+
 /* ---- liq_parm, first slice: the gas <-> particle mass-transfer coefficients of fast_k_mt_a (mech = aer;
  * kpp.f90:2683-2947) and fast_k_mt_t (mech = tot; kpp.f90:2421-2676), called by liq_parm every 120 s (kpp.f90:617,637), for nlayer
  * layers at once.  Per layer, as the COMMON blocks hold them for that k:

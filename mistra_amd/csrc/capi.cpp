@@ -232,6 +232,12 @@ struct MechState {
   DevBuf<int32_t> map_gas_m2k, map_gas_k2m, map_rad_m2k, map_rad_k2m;
   int map_j1 = 0, map_j5 = 0;
   DevBuf<double> d_env, d_rct;      // scratch of mistra_chem_drive_device (grow-only)
+  // mistra_chem_drive (host buffers): ONE device block and ONE pinned host mirror hold everything that crosses PCIe for a batch of layers
+  // (model slabs, scal, env, budgets in; slabs, budgets, exit data out), a private stream carries the two copies and the kernel chain
+  double* drv_dev = nullptr;
+  double* drv_host = nullptr;
+  size_t drv_cap = 0;               // doubles
+  hipStream_t drv_stream = nullptr;
   // fast_k_mt_a / fast_k_mt_t (aer, tot): the exchanged species and the size-axis limits of the last call
   bool kmt_ready = false;
   KmtTable kmt_tab;
@@ -266,6 +272,10 @@ struct MechState {
     dense_rows.release(); schur_cells.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); rates_fslot.release(); s_env.release(); rates_ready = false;
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release(); s_sing.release();
     sing_count = 0; sing_one = false;
+    if (drv_dev) (void)hipFree(drv_dev);
+    if (drv_host) (void)hipHostFree(drv_host);
+    if (drv_stream) (void)hipStreamDestroy(drv_stream);
+    drv_dev = drv_host = nullptr; drv_cap = 0; drv_stream = nullptr;
     if (one_dev) (void)hipFree(one_dev);
     if (one_host) (void)hipHostFree(one_host);
     if (one_stream) (void)hipStreamDestroy(one_stream);
@@ -796,6 +806,120 @@ int mistra_chem_drive_device(int mech, int ncell, double* d_s1, double* d_s3, do
   if (int rc = mistra_chem_integrate_device(mech, ncell, d_var, d_fix, S.d_rct.p, tin, tin + dt, d_var, d_ierr, d_stats, d_texit_hexit, hip_stream)) return rc;
   if (d_bg || d_bgs) LAUNCH_TRY(launch_budgets(P, ncell, d_var, d_fix, S.d_rct.p, dt, d_bg, d_bgs, st));
   LAUNCH_TRY(launch_unpack(P, ncell, d_var, d_s1, d_s3, d_sl1, d_sion1, st));
+  return 0;
+}
+
+// x_drive for a batch of layers from the model's own arrays in HOST memory (include/mistra_chem.h).  The layers' slabs are gathered into one
+// pinned block, go up in one copy, the device chain of mistra_chem_drive_device runs on a private stream, everything the model gets back
+// comes down in one copy and is scattered into the model arrays.  Primary device only: a column step is 148 layers.
+int mistra_chem_drive(int mech, int nlayer, const int32_t* layer, int n, double* s1, double* s3, double* sl1, double* sion1, const double* scal,
+                      const double* env, double tin, double dt, int32_t* ierr, int32_t* stats, double* t_h, double* bg, int nrxn,
+                      const int32_t* bg_level, double* bgs, double* c_packed) {
+  if (int rc = lazy_init()) return rc;
+  if (int rc = check_call(mech, nlayer)) return rc;
+  if (nlayer == 0) return 0;
+  if (!layer || !s1 || !s3 || !sl1 || !sion1 || !scal || !env) return fail("null host pointer");
+  if (bg && (!bg_level || nrxn < kDims[mech][2])) return fail("bg needs bg_level and nrxn >= NREACT");
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  MechState& S = D.mech[mech];
+  if (!S.pack_ready) return fail(std::string("no hand-over table for the ") + kMechName[mech] + " mechanism");
+  if (!S.maps_ready) return fail("mistra_chem_set_species_maps has not been called for this mechanism");
+  if (!S.rates_ready) return fail("no device rate table for this mechanism");
+  for (int i = 0; i < nlayer; i++) {
+    if (layer[i] < 1 || layer[i] > n) return fail("layer index out of range");
+    if (bg && (bg_level[i] < 0)) return fail("bg_level out of range");
+  }
+  HIP_TRY(hipSetDevice(D.id));
+  const PackTable& T = S.pack_tab;
+  const size_t nl = (size_t)nlayer, j1 = (size_t)S.map_j1, j5 = (size_t)S.map_j5, nsl = (size_t)T.j2 * T.nkc, nsi = (size_t)T.j6 * T.nkc;
+  const size_t nv = (size_t)kDims[mech][0], nf = (size_t)kDims[mech][1], nr = (size_t)kDims[mech][2], ne = (size_t)S.rates_nenv, nb = 2 * (size_t)kBudSlots;
+  // block layout (doubles): in/out part first — s1 | s3 | sl1 | sion1 | bg | bgs — then in-only — scal | env — then out-only — th(2) | hlast | int32 ierr, stats
+  size_t off = 0;
+  auto take = [&](size_t count) { const size_t at = off; off += (count + 31) & ~(size_t)31; return at; };      // 256-byte aligned sub-blocks
+  const size_t o_s1 = take(nl * j1), o_s3 = take(nl * j5), o_sl1 = take(nl * nsl), o_si = take(nl * nsi), o_bg = take(bg ? nl * 2 * nr : 0), o_bgs = take(bgs ? nl * nb : 0);
+  const size_t io_end = off;
+  const size_t o_scal = take(nl * 6), o_env = take(nl * ne);
+  const size_t in_end = off;
+  const size_t o_th = take(nl * 2), o_hl = take(nl), o_int = take((nl * 9 + 1) / 2), o_cp = take(c_packed ? nl * (nv + nf) : 0);
+  const size_t out_end = off;
+  const size_t o_var = take(nl * nv), o_fix = take(nl * nf), o_rct = take(nl * nr);      // device only
+  if (off > S.drv_cap) {
+    if (S.drv_dev) (void)hipFree(S.drv_dev);
+    if (S.drv_host) (void)hipHostFree(S.drv_host);
+    S.drv_dev = S.drv_host = nullptr; S.drv_cap = 0;
+    const size_t cap = off + off / 2;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&S.drv_dev), cap * sizeof(double)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S.drv_host), cap * sizeof(double), hipHostMallocDefault));
+    S.drv_cap = cap;
+  }
+  if (!S.drv_stream) HIP_TRY(hipStreamCreateWithFlags(&S.drv_stream, hipStreamNonBlocking));
+  double* H = S.drv_host;
+  double* Dv = S.drv_dev;
+  // ---- gather the layers (the model arrays hold layer k at stride j1 / j5 / j2*nkc / j6*nkc; bg at stride 2*nrxn per level; bgs at 2*122 per layer)
+  for (size_t i = 0; i < nl; i++) {
+    const size_t k = (size_t)layer[i] - 1;
+    std::memcpy(H + o_s1 + i * j1, s1 + k * j1, j1 * sizeof(double));
+    std::memcpy(H + o_s3 + i * j5, s3 + k * j5, j5 * sizeof(double));
+    std::memcpy(H + o_sl1 + i * nsl, sl1 + k * nsl, nsl * sizeof(double));
+    std::memcpy(H + o_si + i * nsi, sion1 + k * nsi, nsi * sizeof(double));
+    if (bg) {
+      if (bg_level[i] > 0) std::memcpy(H + o_bg + i * 2 * nr, bg + ((size_t)bg_level[i] - 1) * 2 * (size_t)nrxn, 2 * nr * sizeof(double));
+      else std::memset(H + o_bg + i * 2 * nr, 0, 2 * nr * sizeof(double));
+    }
+    if (bgs) std::memcpy(H + o_bgs + i * nb, bgs + k * nb, nb * sizeof(double));
+  }
+  std::memcpy(H + o_scal, scal, nl * 6 * sizeof(double));
+  std::memcpy(H + o_env, env, nl * ne * sizeof(double));
+  hipStream_t st = S.drv_stream;
+  HIP_TRY(hipMemcpyAsync(Dv, H, in_end * sizeof(double), hipMemcpyHostToDevice, st));
+  // KPP's dummy product species are not set by the drivers; the reference carries over what the previous LAYER left in COMMON /GDATA_x/
+  // (INTEGRATION.md §4): a batch gives every layer zeros
+  HIP_TRY(hipMemsetAsync(Dv + o_var, 0, nl * nv * sizeof(double), st));
+  int32_t* d_int = reinterpret_cast<int32_t*>(Dv + o_int);      // [nl] ierr, then [nl][8] stats
+  PackDev P{S.pk_pack.p, S.pk_fix.p, S.pk_unpack.p, S.pk_slot_id.p, S.pk_slot_first.p, S.pk_terms.p, S.pk_words.p, S.pk_acc.p, S.pk_envc.p,
+            T.n_pack(), T.n_fix(), T.n_unpack(), T.n_slots(), (int)T.terms.size() / 3, (int)T.term_words.size(), (int)T.acc.size() / 2, T.n_envc(),
+            T.nvar, T.nfix, S.tab.nreact, T.j2, T.j6, T.nkc, T.preclamp,
+            S.map_gas_m2k.p, S.map_gas_k2m.p, S.map_rad_m2k.p, S.map_rad_k2m.p, S.map_j1, S.map_j5, S.pk_aptr.p, S.pk_afac.p, S.consts.p};
+  LAUNCH_TRY(launch_pack(P, nlayer, Dv + o_s1, Dv + o_s3, Dv + o_sl1, Dv + o_si, Dv + o_scal, Dv + o_var, Dv + o_fix, st));
+  if (c_packed) {
+    HIP_TRY(hipMemcpy2DAsync(Dv + o_cp, (nv + nf) * sizeof(double), Dv + o_var, nv * sizeof(double), nv * sizeof(double), nl, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(Dv + o_cp + nv, (nv + nf) * sizeof(double), Dv + o_fix, nf * sizeof(double), nf * sizeof(double), nl, hipMemcpyDeviceToDevice, st));
+  }
+  LAUNCH_TRY(launch_env_from_c(P, nlayer, S.rates_nenv, Dv + o_var, Dv + o_fix, Dv + o_env, st));
+  {
+    const RatesDev R{S.rates_consts.p, S.rates_offs.p, S.rates_words.p, S.rates_fslot.p, S.tab.nreact, S.rates_nenv};
+    LAUNCH_TRY(launch_update_rconst(R, Dv + o_env, Dv + o_rct, nlayer, st));
+  }
+  {
+    HIP_TRY(S.s_sing.reserve(nl * 8));
+    KernelArgs a = make_args(S, nlayer, Dv + o_var, Dv + o_fix, Dv + o_rct, tin, tin + dt, Dv + o_var, d_int, d_int + nl, Dv + o_th);
+    a.h_last = Dv + o_hl;
+    a.sing_rows = S.s_sing.p;
+    S.sing_start = 0; S.sing_count = nl; S.sing_one = false;
+    if (int rc = launch(D, mech, a, st)) return rc;
+  }
+  if (bg || bgs) LAUNCH_TRY(launch_budgets(P, nlayer, Dv + o_var, Dv + o_fix, Dv + o_rct, dt, bg ? Dv + o_bg : nullptr, bgs ? Dv + o_bgs : nullptr, st));
+  LAUNCH_TRY(launch_unpack(P, nlayer, Dv + o_var, Dv + o_s1, Dv + o_s3, Dv + o_sl1, Dv + o_si, st));
+  // what comes back: the in/out part and the out-only part (two copies: the in-only part between them stays up)
+  HIP_TRY(hipMemcpyAsync(H, Dv, io_end * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(H + in_end, Dv + in_end, (out_end - in_end) * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  // ---- scatter
+  const int32_t* h_int = reinterpret_cast<const int32_t*>(H + o_int);
+  for (size_t i = 0; i < nl; i++) {
+    const size_t k = (size_t)layer[i] - 1;
+    std::memcpy(s1 + k * j1, H + o_s1 + i * j1, j1 * sizeof(double));
+    std::memcpy(s3 + k * j5, H + o_s3 + i * j5, j5 * sizeof(double));
+    std::memcpy(sl1 + k * nsl, H + o_sl1 + i * nsl, nsl * sizeof(double));
+    std::memcpy(sion1 + k * nsi, H + o_si + i * nsi, nsi * sizeof(double));
+    if (bg && bg_level[i] > 0) std::memcpy(bg + ((size_t)bg_level[i] - 1) * 2 * (size_t)nrxn, H + o_bg + i * 2 * nr, 2 * nr * sizeof(double));
+    if (bgs) std::memcpy(bgs + k * nb, H + o_bgs + i * nb, nb * sizeof(double));
+    if (ierr) ierr[i] = h_int[i];
+    if (stats) std::memcpy(stats + i * 8, h_int + nl + i * 8, 8 * sizeof(int32_t));
+    if (t_h) { t_h[3 * i] = H[o_th + 2 * i]; t_h[3 * i + 1] = H[o_th + 2 * i + 1]; t_h[3 * i + 2] = H[o_hl + i]; }
+  }
+  if (c_packed) std::memcpy(c_packed, H + o_cp, nl * (nv + nf) * sizeof(double));
   return 0;
 }
 

@@ -1,0 +1,82 @@
+! TEST INFRASTRUCTURE — stands in for libmistra_chem.so's mistra_chem_drive in the CPU validation build of the single-pass batched
+! kpp_driver (oracle/build_drive.sh; shim/kpp_drive.patch, shim/mistra_kpp_drive.f90, shim/mistra_kpp_model.f90 — all unmodified).
+! There is no GPU in the build container, so the call is served by the REFERENCE's own drivers: for every staged layer the x_drive
+! argument list is rebuilt from nothing but what crossed the C boundary — the layer number, scal (air, h2o, cvv1..4) and the rate
+! evaluator's input vector (its /cb_1/ members, switches and photolysis rates by their slots, oracle/_ref/drive/drive_standin_idx.inc,
+! generated from mistra_amd/mech/<mech>.rates_env.json) — and gas_drive / aer_drive / tot_drive run serially (kpp_pass = 0) on the model
+! arrays that were handed over.  oracle/capture_wrap.c records every INTEGRATE_x call as in the unpatched model; identical records prove
+! that (1) staging + one deferred call per mechanism changes nothing, and (2) layer, scal and env carry EVERYTHING a driver call
+! depends on.  What the device then does with them is checked on the GPU (tests/test_gpu_drive.py).  Never part of the product.
+module drive_standin_idx
+  implicit none
+  include 'drive_standin_idx.inc'
+end module drive_standin_idx
+
+function mistra_chem_set_species_maps(mech, j1, gas_m2k, gas_k2m, j5, rad_m2k, rad_k2m) bind(C, name="mistra_chem_set_species_maps") result(rc)
+  use iso_c_binding
+  implicit none
+  integer(c_int), value :: mech, j1, j5
+  integer(c_int32_t) :: gas_m2k(2, *), gas_k2m(*), rad_m2k(2, *), rad_k2m(*)
+  integer(c_int) :: rc
+  rc = 0
+end function mistra_chem_set_species_maps
+
+function mistra_chem_drive(mech, nlayer, layer, n, s1, s3, sl1, sion1, scal, env, tin, dt, ierr, stats, t_h, bg, nrxn, bg_level, bgs, c_packed) &
+     bind(C, name="mistra_chem_drive") result(rc)
+  use iso_c_binding
+  use drive_standin_idx
+  use mistra_kpp_batch, only: kpp_pass
+  implicit none
+  integer(c_int), value :: mech, nlayer, n, nrxn
+  integer(c_int32_t) :: layer(*), bg_level(*), ierr(*), stats(8, *)
+  real(c_double) :: s1(*), s3(*), sl1(*), sion1(*), bg(*), bgs(*), scal(6, *), env(*), t_h(3, *)
+  real(c_double), value :: tin, dt
+  type(c_ptr), value :: c_packed
+  integer(c_int) :: rc
+  double precision :: aircc, te, h2oppm, pk
+  common /cb_1/ aircc, te, h2oppm, pk
+  integer :: Nfun, Njac, Nstp, Nacc, Nrej, Ndec, Nsol, Nsng
+  common /Statistics/ Nfun, Njac, Nstp, Nacc, Nrej, Ndec, Nsol, Nsng
+  double precision :: tk, dtc, ph(47), sw(8), cb(4)
+  integer :: i, j, k, ne, base
+  external :: gas_drive, aer_drive, tot_drive
+  if (kpp_pass /= 0) error stop 'drive stand-in: the drivers must run serially here'
+  ne = nenv_of(mech + 1)
+  do i = 1, nlayer
+     base = (i - 1) * ne
+     do j = 1, 4
+        cb(j) = pick(ix_cb(j, mech + 1))
+     end do
+     do j = 1, 8
+        sw(j) = pick(ix_sw(j, mech + 1))
+     end do
+     do j = 1, 47
+        ph(j) = pick(ix_ph(j, mech + 1))
+     end do
+     aircc = cb(1); te = cb(2); h2oppm = cb(3); pk = cb(4)      ! what kpp_driver sets per layer (kpp.f90:4314-4321)
+     k = layer(i)
+     tk = tin
+     dtc = dt
+     select case (mech)      ! sw = xhal, xiod, xliq1..4, xhet1, xhet2
+     case (0)
+        call gas_drive(tk, dtc, k, sw(1), sw(2), sw(7), sw(8), scal(1, i), scal(2, i), ph)
+     case (1)
+        call aer_drive(tk, dtc, k, scal(3, i), scal(4, i), sw(1), sw(2), sw(3), sw(4), sw(7), sw(8), scal(1, i), scal(2, i), ph)
+     case (2)
+        call tot_drive(tk, dtc, k, scal(3, i), scal(4, i), scal(5, i), scal(6, i), sw(1), sw(2), sw(3), sw(4), sw(5), sw(6), sw(7), sw(8), &
+                       scal(1, i), scal(2, i), ph)
+     end select
+     ierr(i) = 1                    ! (the reference prints its own messages; the code is not returned)
+     stats(:, i) = [Nfun, Njac, Nstp, Nacc, Nrej, Ndec, Nsol, Nsng]
+     t_h(1, i) = tk
+     t_h(2, i) = 0.d0
+     t_h(3, i) = 0.d0
+  end do
+  rc = 0
+contains
+  double precision function pick(slot)      ! an input the generated Update_RCONST_x does not read is not in the vector: nothing depends on it
+    integer, intent(in) :: slot
+    pick = 0.d0
+    if (slot > 0) pick = env(base + slot)
+  end function pick
+end function mistra_chem_drive

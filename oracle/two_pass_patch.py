@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE — applies the two-pass kpp_driver patch of INTEGRATION.md §4 to scratch copies of four reference files
+"""TEST INFRASTRUCTURE — applies one of the two batched-driver patches of INTEGRATION.md §4 to scratch copies of four reference files
 (kpp.f90, gas.f, aer.f, tot.f) and writes the unified diff a maintainer would apply.
 
-    two_pass_patch.py <reference src dir> <scratch dir> [<diff out>]
+    two_pass_patch.py [--mode two-pass|drive] <reference src dir> <scratch dir> [<diff out>]
+
+two-pass (shim/kpp_two_pass.patch): the layer loop runs twice around one batched INTEGRATE_x per mechanism; pack, rates, budgets and
+hand-over stay in Fortran.  drive (shim/kpp_drive.patch): the loop runs once, x_drive stages its layer behind its /kpp_rate_x/ prologue
+and ONE mistra_chem_drive call per mechanism does pack -> rates -> integrator -> budgets -> hand-over on the device (shim/mistra_kpp_drive.f90).
 
 Nothing under the reference tree is touched; the scratch copies live under oracle/_ref/ (git-ignored).  The edits are
 anchored on the exact reference lines they follow or replace (kpp.f90:4168-4470, gas.f:172-173, aer.f:216-217,
@@ -48,19 +52,60 @@ def patch_drive(t, sfx, indent):
     return t
 
 
+def patch_kpp_single(t):
+    t = edit(t, "subroutine kpp_driver (box,dd_ch,n_bl)\n", "subroutine kpp_driver (box,dd_ch,n_bl)\n\n  USE mistra_kpp_drive, ONLY : kpp_drive_begin   ! batched layer loop: one device call per mechanism (shim/)\n")
+    t = edit(t, "  do k=n_min,n_max\n\n! define temp, H2O, air, ..",
+             "  call kpp_drive_begin      ! from here on x_drive stages its layer instead of integrating it (kpp_pass = 3)\n  do k=n_min,n_max\n\n! define temp, H2O, air, ..")
+    t = edit(t, "  enddo ! k\n\n! eliminate negative values\n  where (s1 < 0.d0) s1 = 0._dp",
+             "  enddo ! k\n  call KPP_DRIVE_RUN (0.d0,dd_ch)      ! pack, rates, integrator, budgets, hand-over of all staged layers on the device; kpp_pass = 0 again\n"
+             "\n! eliminate negative values\n  where (s1 < 0.d0) s1 = 0._dp")
+    return t
+
+
+def patch_drive_single(t, sfx, anchor):
+    use_anchor = {"g": "      subroutine gas_drive\n", "a": "      subroutine aer_drive\n", "t": "      subroutine tot_drive\n"}[sfx]
+    if t.count(use_anchor) != 1:
+        raise SystemExit("x_drive header not found for " + sfx)
+    head = t.index(use_anchor)
+    first_use = t.index("      USE ", head)
+    t = t[:first_use] + "      USE mistra_kpp_batch, ONLY : kpp_pass\n" + t[first_use:]
+    # behind the /kpp_rate_x/ prologue, in front of the first statement of the pack half
+    if t.count(anchor) != 1:
+        raise SystemExit("pack anchor not found exactly once for " + sfx)
+    at = t.index(anchor)
+    block = ("      if (kpp_pass.eq.3) then   ! batched driver: the layer is handed over here, the device does the rest\n"
+             "         call KPP_DRIVE_STAGE_%s (k,air,h2o)\n"
+             "         return\n"
+             "      end if\n" % sfx)
+    return t[:at] + block + t[at:]
+
+
 def main():
+    mode = "two-pass"
+    if sys.argv[1] == "--mode":
+        mode = sys.argv[2]
+        del sys.argv[1:3]
     src, scratch = sys.argv[1], sys.argv[2]
     os.makedirs(scratch, exist_ok=True)
     diff = []
-    for name, fn in (("kpp.f90", patch_kpp), ("gas.f", lambda t: patch_drive(t, "g", "      ")),
-                     ("aer.f", lambda t: patch_drive(t, "a", "      ")), ("tot.f", lambda t: patch_drive(t, "t", "         "))):
+    if mode == "drive":
+        edits = (("kpp.f90", patch_kpp_single),
+                 ("gas.f", lambda t: patch_drive_single(t, "g", "! Transfer Mistra concentration arrays towards KPP arrays\n      do j=1,j1\n         C(gas_m2k_g(1,j))")),
+                 ("aer.f", lambda t: patch_drive_single(t, "a", "c include C(ind_)=s1/3(k,)\n      do j=1,j1\n         C(gas_m2k_a(1,j))")),
+                 ("tot.f", lambda t: patch_drive_single(t, "t", "! Transfer Mistra concentration arrays towards KPP arrays\n      do j=1,j1\n         C(gas_m2k_t(1,j))")))
+    elif mode == "two-pass":
+        edits = (("kpp.f90", patch_kpp), ("gas.f", lambda t: patch_drive(t, "g", "      ")),
+                 ("aer.f", lambda t: patch_drive(t, "a", "      ")), ("tot.f", lambda t: patch_drive(t, "t", "         ")))
+    else:
+        raise SystemExit("unknown mode " + mode)
+    for name, fn in edits:
         old = open(os.path.join(src, name), errors="replace").read()
         new = fn(old)
         open(os.path.join(scratch, name), "w").write(new)
         diff += list(difflib.unified_diff(old.splitlines(True), new.splitlines(True), "a/src/" + name, "b/src/" + name, n=2))
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write("".join(diff))
-    print("patched 4 files into", scratch, "(%d diff lines)" % len(diff))
+    print("patched 4 files into", scratch, "(%s, %d diff lines)" % (mode, len(diff)))
 
 
 if __name__ == "__main__":

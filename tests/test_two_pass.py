@@ -23,13 +23,13 @@ needs_models = pytest.mark.skipif(not (os.path.isdir("/root/reference/namelists"
                                   reason="needs the reference tree and the two model builds (oracle/build_ref.sh model, oracle/build_two_pass.sh)")
 
 
-def _run(tag, model, minutes, extra):
+def _run(tag, model, minutes, extra, case="base1"):
     env = dict(os.environ, MISTRA_RUN_TAG=tag, MISTRA_MODEL_BIN=os.path.join(REF, model), MISTRA_COLUMN_MINUTES=str(minutes),
                MISTRA_RESET_DUMMIES="1")
-    args = [os.path.join(REPO, "oracle", "capture_run.sh"), "base1", "1"] + ["%s=%s" % kv for kv in extra.items()]
+    args = [os.path.join(REPO, "oracle", "capture_run.sh"), case, "1"] + ["%s=%s" % kv for kv in extra.items()]
     subprocess.run(args, env=env, check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     from oracle.oracle import read_capture
-    return read_capture(os.path.join(REF, "capture_base1%s.bin" % tag))
+    return read_capture(os.path.join(REF, "capture_%s%s.bin" % (case, tag)))
 
 
 @needs_models
@@ -49,11 +49,40 @@ def test_two_pass_driver_reproduces_the_serial_model_bit_for_bit():
             assert x["tin_out"] == y["tin_out"] and x["stepmin_out"] == y["stepmin_out"]
 
 
-def test_patch_in_the_repo_is_what_the_generator_writes(tmp_path):
-    """shim/kpp_two_pass.patch is generated (oracle/two_pass_patch.py), not hand-edited."""
+needs_drive_model = pytest.mark.skipif(not (os.path.isdir("/root/reference/namelists") and os.path.exists(os.path.join(REF, "mistra_capture"))
+                                            and os.path.exists(os.path.join(REF, "mistra_drive"))),
+                                       reason="needs the reference tree and the two model builds (oracle/build_ref.sh model, oracle/build_drive.sh)")
+
+
+@needs_drive_model
+@pytest.mark.parametrize("case,minutes,mechs", [("base1", 6, ("gas", "aer")), ("BTZ96", 2, ("gas", "aer", "tot"))])
+def test_single_pass_batched_driver_reproduces_the_serial_model_bit_for_bit(case, minutes, mechs):
+    """shim/kpp_drive.patch: kpp_driver's loop runs ONCE, x_drive stages its layer behind its /kpp_rate_x/ prologue
+    (KPP_DRIVE_STAGE_x) and ONE mistra_chem_drive call per mechanism does the rest.  oracle/build_drive.sh links the patched model with the
+    unmodified shim/ files and oracle/drive_standin.f90 in the library's place: every staged layer is served by the reference's own x_drive
+    called with an argument list REBUILT from what crossed the C boundary — layer number, scal, the rate evaluator's input vector.  The
+    records of every INTEGRATE_x call of the last six column steps (inputs as the driver packed them, RCONST, results, /Statistics/) are
+    identical to the unpatched model's, bit for bit: deferring the layers changes nothing, and (layer, scal, env) is a complete
+    description of a driver call.  base1: gas and aer layers; BTZ96 with chem=T: all three mechanisms."""
+    window = dict(MISTRA_CAPTURE_SEQ_FROM=148 * (6 * minutes - 6), MISTRA_CAPTURE_SEQ_TO=148 * 6 * minutes)
+    a = _run("_dr_serial", "mistra_capture", minutes, window, case)
+    b = _run("_dr_batched", "mistra_drive", minutes, window, case)
+    assert len(a) == len(b) == 148 * 6
+    for mech in mechs:
+        ra, rb = [r for r in a if r["mech"] == mech], [r for r in b if r["mech"] == mech]
+        assert len(ra) == len(rb) and len(ra) > 100
+        for x, y in zip(ra, rb):
+            for k in ("var_in", "fix", "rconst", "var_out", "stats"):
+                assert np.array_equal(x[k], y[k]), (mech, k)
+            assert x["tin_out"] == y["tin_out"] and x["stepmin_out"] == y["stepmin_out"]
+
+
+@pytest.mark.parametrize("mode,name", [("two-pass", "kpp_two_pass.patch"), ("drive", "kpp_drive.patch")])
+def test_patches_in_the_repo_are_what_the_generator_writes(tmp_path, mode, name):
+    """shim/kpp_two_pass.patch and shim/kpp_drive.patch are generated (oracle/two_pass_patch.py), not hand-edited."""
     if not os.path.isdir("/root/reference/src"):
         pytest.skip("no reference tree here")
     out = tmp_path / "p.patch"
-    subprocess.run(["python3", os.path.join(REPO, "oracle", "two_pass_patch.py"), "/root/reference/src", str(tmp_path / "src"), str(out)],
+    subprocess.run(["python3", os.path.join(REPO, "oracle", "two_pass_patch.py"), "--mode", mode, "/root/reference/src", str(tmp_path / "src"), str(out)],
                    check=True, stdout=subprocess.DEVNULL)
-    assert out.read_text() == open(os.path.join(REPO, "shim", "kpp_two_pass.patch")).read()
+    assert out.read_text() == open(os.path.join(REPO, "shim", name)).read()
