@@ -81,6 +81,9 @@ def lib():
         L.mistra_chem_henry_device.argtypes = [C.c_int, C.c_int, vp, vp, vp]
         L.mistra_chem_equil_co_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.mistra_chem_drive_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp]
+        L.mistra_chem_drive.argtypes = [C.c_int, C.c_int, _ip, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _ip, _dp, _dp, C.c_int,
+                                        _ip, _dp, _dp]
+        L.mistra_chem_debug_set_max_steps.argtypes = [C.c_int]
         L.mistra_chem_last_error.restype = C.c_char_p
         L.mistra_chem_describe.restype = C.c_char_p
         L.mistra_chem_describe.argtypes = [C.c_int]
@@ -318,6 +321,28 @@ def drive(mech, s1, s3, sl1, sion1, scal, env, var, fix, tin, dt, ierr, stats, t
     mid, _ = _mech_id(mech)
     _check(lib().mistra_chem_drive_device(mid, var.shape[0], _p(s1), _p(s3), _p(sl1), _p(sion1), _p(scal), _p(env), _p(var), _p(fix), float(tin),
                                           float(dt), _p(ierr), _p(stats), _p(texit_hexit), _p(bg), _p(bgs), _stream(var)))
+
+
+def drive_host(mech, layer, s1, s3, sl1, sion1, scal, env, tin, dt, bg=None, bg_level=None, bgs=None, want_c=False):
+    """mistra_chem_drive: one x_drive per layer for the layers `layer` (k, 1-based) of the model arrays in HOST memory — numpy float64,
+    C-contiguous, s1 [n, j1], s3 [n, j5], sl1 [n, nkc*j2], sion1 [n, nkc*j6], bg [nlev, nrxn, 2], bgs [n, 122, 2], updated in place; scal
+    [nlayer, 6], env [nlayer, nenv] per layer of the batch.  -> (ierr, stats, t_h[, c_packed])"""
+    mid, name = _mech_id(mech)
+    lay = np.ascontiguousarray(layer, np.int32)
+    nl = lay.size
+    for a in (s1, s3, sl1, sion1) + ((bg,) if bg is not None else ()) + ((bgs,) if bgs is not None else ()):
+        if a.dtype != np.float64 or not a.flags.c_contiguous:
+            raise MistraChemError("model arrays must be C-contiguous float64 (they are updated in place)")
+    sc, ev = np.ascontiguousarray(scal, np.float64), np.ascontiguousarray(env, np.float64)
+    ierr, stats, th = np.zeros(nl, np.int32), np.zeros((nl, 8), np.int32), np.zeros((nl, 3))
+    nvar, nfix, _, _ = DIMS[name]
+    cp = np.zeros((nl, nvar + nfix)) if want_c else None
+    lev = np.ascontiguousarray(bg_level, np.int32) if bg_level is not None else None
+    P = lambda a: None if a is None else a.ctypes.data_as(_dp)
+    _check(lib().mistra_chem_drive(mid, nl, lay.ctypes.data_as(_ip), s1.shape[0], P(s1), P(s3), P(sl1), P(sion1), P(sc), P(ev), float(tin), float(dt),
+                                   ierr.ctypes.data_as(_ip), stats.ctypes.data_as(_ip), P(th), P(bg), 0 if bg is None else bg.shape[1],
+                                   None if lev is None else lev.ctypes.data_as(_ip), P(bgs), P(cp)))
+    return (ierr, stats, th, cp) if want_c else (ierr, stats, th)
 
 
 def fast_k_mt(mech, ff, rq, kw, ka, ifeed, nkc_l, cw, cm, freep, alpha, vmean, xkmt, t=None, p=None, vt=None):

@@ -3,7 +3,9 @@
 !
 ! Linked with -Wl,--wrap=gas_drive_ / aer_drive_ / tot_drive_: every call kpp_driver makes (kpp.f90:4454-4467) lands here.  Written
 ! in Fortran because the layer's data sits in module gas_common (s1, s3 and the species index maps, allocatable) besides the
-! COMMON blocks.  Around the real driver it records, for the calls selected by MISTRA_CAPTURE_DRIVE_SKIP_x / _EVERY_x / _MAX_x:
+! COMMON blocks.  Around the real driver it records, for the calls selected by MISTRA_CAPTURE_DRIVE_SKIP_x / _EVERY_x / _MAX_x (per
+! mechanism) or — for whole column steps in model order — by MISTRA_CAPTURE_DRIVE_SEQ_FROM / _SEQ_TO (a window of the running count of ALL
+! driver calls, 148 per 10-s step):
 !   before:  the driver's arguments, s1(:,k), s3(:,k), sl1(:,:,k), sion1(:,:,k), the index maps gas_m2k_x / gas_k2m_x / rad_m2k_x / rad_k2m_x
 !   inside:  C = VAR | FIX as x_drive handed it to INTEGRATE_x (oracle/capture_wrap.c keeps the last one: capture_last_c_in) and the inputs of
 !            its Update_RCONST_x call as MISTRA_RATES_ENV_x packs them (oracle/capture_rates_wrap.c: capture_last_env)
@@ -15,6 +17,7 @@ module capture_drive_state
   integer :: unit_out = 0
   logical :: inited = .false., opened = .false.
   integer :: ncall(3) = 0, nrec(3) = 0, nskip(3) = 0, nevery(3) = 1, nmax(3) = 16
+  integer :: seq = 0, seq_from = 0, seq_to = 0
 contains
   subroutine init()
     character(len=512) :: buf
@@ -26,6 +29,10 @@ contains
        open (newunit=unit_out, file=trim(buf), access='stream', form='unformatted', status='replace')
        opened = .true.
     end if
+    call get_environment_variable('MISTRA_CAPTURE_DRIVE_SEQ_FROM', buf, status=stat)
+    if (stat == 0) read (buf, *) seq_from
+    call get_environment_variable('MISTRA_CAPTURE_DRIVE_SEQ_TO', buf, status=stat)
+    if (stat == 0) read (buf, *) seq_to
     do m = 1, 3
        call get_environment_variable('MISTRA_CAPTURE_DRIVE_SKIP_'//sfx(m), buf, status=stat)
        if (stat == 0) read (buf, *) nskip(m)
@@ -42,6 +49,11 @@ contains
     if (.not. inited) call init()
     n = ncall(m)
     ncall(m) = n + 1
+    seq = seq + 1
+    if (seq_to > 0) then
+       want = opened .and. seq - 1 >= seq_from .and. seq - 1 < seq_to
+       return
+    end if
     want = opened .and. nrec(m) < nmax(m) .and. n >= nskip(m)
     if (want) want = mod(n - nskip(m), nevery(m)) == 0
   end function want

@@ -8,6 +8,15 @@
 !                                                      mistra_kpp_rates.f90): UPDATE_RCONST_BATCH_x, then INTEGRATE_BATCH_ENV_x (rates and
 !                                                      integrator on the device, RCONST never crosses PCIe); out.bin = per cell VAR,
 !                                                      then per cell IERR + 8 statistics, then per cell RCONST of the first call
+!          shim_driver D <in.bin> <out.bin>            one 10-s step of a column through the SINGLE-PASS batched driver (shim/mistra_kpp_drive.f90,
+!                                                      shim/kpp_drive.patch): this program plays kpp_driver and x_drive's prologue — per layer it puts the
+!                                                      recorded values into the COMMON blocks (shim_driver_env_set.f90), calls KPP_DRIVE_STAGE_x as the
+!                                                      patched x_drive does, and behind the loop kpp_drive_run_arrays on its own copies of the model
+!                                                      arrays (what KPP_DRIVE_RUN of mistra_kpp_model.f90 does inside the model).  in.bin (float64):
+!                                                      n, j1, j5, nlev, nrxn, nl, nrep | maps of the three mechanisms | il(nlev) | s1(j1,n) s3(j5,n)
+!                                                      sl1(121,4,n) sion1(55,4,n) bg(2,nrxn,nlev) bgs(2,122,n) | per layer: mech, k, air, h2o, env(nenv).
+!                                                      out.bin: the arrays after the step | per layer ierr, 8 statistics, texit, hexit | per repetition
+!                                                      the wall times (ms) of the staging loop and of the device call(s)
 ! After the call the one-cell mode also writes ATOL(1), RTOL(1) (INTEGRATE_x resets them, gas.f:745-746).
 program shim_driver
   use mistra_kpp_rates
@@ -23,6 +32,7 @@ program shim_driver
   case ('G'); call run_batch(0, 102, 3, 331, trim(fin), trim(fout))
   case ('A'); call run_batch(1, 257, 5, 979, trim(fin), trim(fout))
   case ('T'); call run_batch(2, 417, 7, 1627, trim(fin), trim(fout))
+  case ('D'); call run_drive(trim(fin), trim(fout))
   case ('E')
      select case (a1(2:2))
      case ('g'); call run_env(0, 102, 3, 331, nenv_g, trim(fin), trim(fout))
@@ -175,4 +185,69 @@ contains
     end do
     close (11); close (12)
   end subroutine run_env
+  subroutine run_drive(fin, fout)
+    use mistra_kpp_drive
+    character(len=*), intent(in) :: fin, fout
+    integer, parameter :: j2 = 121, j6 = 55, nkc = 4, nbgs = 122      ! global_params.f90:96-103, bud_s_g.f:63
+    integer, parameter :: nenv(3) = [nenv_g, nenv_a, nenv_t]
+    double precision :: hdr(7)
+    integer :: n, j1, j5, nlev, nrxn, nl, nrep, i, m, rep, cnt, k, ierr, istat(8)
+    integer, allocatable :: gm(:, :, :), gk(:, :), rm(:, :, :), rk(:, :), il(:), lmech(:), lk(:)
+    double precision, allocatable :: tmp(:), s1(:, :), s3(:, :), sl1(:, :, :), sion1(:, :, :), bg(:, :, :), bgs(:, :, :), lscal(:, :), lenv(:, :)
+    double precision, allocatable :: s1_0(:, :), s3_0(:, :), sl1_0(:, :, :), sion1_0(:, :, :), bg_0(:, :, :), bgs_0(:, :, :), times(:, :)
+    double precision :: texit, hexit
+    integer(8) :: c0, c1, c2, rate
+    external :: MISTRA_RATES_ENV_SET_g, MISTRA_RATES_ENV_SET_a, MISTRA_RATES_ENV_SET_t, KPP_DRIVE_STAGE_g, KPP_DRIVE_STAGE_a, KPP_DRIVE_STAGE_t
+    open (11, file=fin, access='stream', form='unformatted', status='old')
+    open (12, file=fout, access='stream', form='unformatted', status='replace')
+    read (11) hdr
+    n = int(hdr(1)); j1 = int(hdr(2)); j5 = int(hdr(3)); nlev = int(hdr(4)); nrxn = int(hdr(5)); nl = int(hdr(6)); nrep = int(hdr(7))
+    allocate (gm(2, j1, 3), gk(j1, 3), rm(2, j5, 3), rk(j5, 3), il(nlev), tmp(max(2 * j1, 2 * j5, nlev)))
+    do m = 1, 3
+       read (11) tmp(1:2 * j1); gm(:, :, m) = reshape(int(tmp(1:2 * j1)), [2, j1])
+       read (11) tmp(1:j1); gk(:, m) = int(tmp(1:j1))
+       read (11) tmp(1:2 * j5); rm(:, :, m) = reshape(int(tmp(1:2 * j5)), [2, j5])
+       read (11) tmp(1:j5); rk(:, m) = int(tmp(1:j5))
+    end do
+    read (11) tmp(1:nlev); il = int(tmp(1:nlev))
+    allocate (s1(j1, n), s3(j5, n), sl1(j2, nkc, n), sion1(j6, nkc, n), bg(2, nrxn, nlev), bgs(2, nbgs, n))
+    read (11) s1, s3, sl1, sion1, bg, bgs
+    allocate (lmech(nl), lk(nl), lscal(2, nl), lenv(maxval(nenv), nl), times(2, nrep))
+    do i = 1, nl
+       read (11) hdr(1:4)
+       lmech(i) = int(hdr(1)); lk(i) = int(hdr(2)); lscal(:, i) = hdr(3:4)
+       read (11) lenv(1:nenv(lmech(i)), i)
+    end do
+    s1_0 = s1; s3_0 = s3; sl1_0 = sl1; sion1_0 = sion1; bg_0 = bg; bgs_0 = bgs
+    do m = 1, 3      ! once per run, as KPP_DRIVE_RUN does on its first call (here only for the mechanisms the recorded step has layers of: the
+       if (any(lmech == m)) call kpp_drive_maps(m, j1, gm(:, :, m), gk(:, m), j5, rm(:, :, m), rk(:, m))      ! file holds real maps only for those)
+    end do
+    do rep = 1, nrep      ! (the first repetition pays the library's start-up and the first allocation of the staging blocks)
+       s1 = s1_0; s3 = s3_0; sl1 = sl1_0; sion1 = sion1_0; bg = bg_0; bgs = bgs_0
+       call system_clock(c0, rate)
+       call kpp_drive_begin
+       do i = 1, nl       ! kpp_driver's layer loop: per-layer set-up and the x_drive prologue (here: the recorded values back into the COMMON blocks), then the hand-over
+          select case (lmech(i))
+          case (1); call MISTRA_RATES_ENV_SET_g(lenv(:, i)); call KPP_DRIVE_STAGE_g(lk(i), lscal(1, i), lscal(2, i))
+          case (2); call MISTRA_RATES_ENV_SET_a(lenv(:, i)); call KPP_DRIVE_STAGE_a(lk(i), lscal(1, i), lscal(2, i))
+          case (3); call MISTRA_RATES_ENV_SET_t(lenv(:, i)); call KPP_DRIVE_STAGE_t(lk(i), lscal(1, i), lscal(2, i))
+          end select
+       end do
+       call system_clock(c1)
+       call kpp_drive_run_arrays(0.d0, 10.d0, n, s1, s3, sl1, sion1, nrxn, nlev, il, bg, bgs)
+       call system_clock(c2)
+       times(1, rep) = 1.d3 * dble(c1 - c0) / dble(rate)
+       times(2, rep) = 1.d3 * dble(c2 - c1) / dble(rate)
+    end do
+    write (12) s1, s3, sl1, sion1, bg, bgs
+    do m = 1, 3           ! per mechanism in staging order (= layer order within the mechanism)
+       cnt = kpp_drive_count(m)
+       do i = 1, cnt
+          call kpp_drive_last(m, i, k, ierr, istat, texit, hexit)
+          write (12) dble(m), dble(k), dble(ierr), dble(istat), texit, hexit
+       end do
+    end do
+    write (12) times
+    close (11); close (12)
+  end subroutine run_drive
 end program shim_driver
