@@ -234,6 +234,17 @@ int mistra_chem_henry_device(int mech, int nlayer, const double* d_tt, double* d
 int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const double* d_tt, const double* d_conv2, const double* d_xgamma,
                                 double* d_xkef, double* d_xkeb, void* hip_stream);
 
+/* The three liq_parm kernels above on HOST buffers (same layouts, layer-major as the model holds them: every array of the reference has the
+ * layer as its last dimension, so a run of layers kmin..kmax is handed over in place — ff(1,1,kmin), xkmt(1,1,kmin) ...): what the Fortran
+ * shim calls (shim/mistra_kpp_liq.f90: FAST_K_MT_BATCH, HENRY_BATCH, EQUIL_CO_BATCH; drop-ins with the reference's own signatures in
+ * shim/mistra_kpp_model.f90).  Synchronous; primary device. */
+int mistra_chem_fast_k_mt(int mech, int nlayer, const double* ff, const double* rq, const int32_t* kw, int nkw, int ka, int ifeed, int nkc_l,
+                          const double* cw, const double* cm, const double* freep, const double* alpha, const double* vmean, double* xkmt,
+                          const double* t, const double* p, double* vt);
+int mistra_chem_henry(int mech, int nlayer, const double* tt, double* henry);
+int mistra_chem_equil_co(int mech, int nlayer, int nkc, int j6, const double* tt, const double* conv2, const double* xgamma, double* xkef,
+                         double* xkeb);
+
 /* Diagnostics for the phase-level parity tests: integrates the cells like mistra_chem_integrate (results discarded) with the
  * kernel variant that writes out, per cell, the intermediate results of the FIRST attempt of the first Rosenbrock step
  * (gas.f:1201-1262): dump[cell][5*NVAR + 2*LU_NONZERO + 2] = Fcn0 (Fun_x) | Ghimj as ros_PrepareMatrix_x builds it | Ghimj

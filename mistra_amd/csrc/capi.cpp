@@ -998,6 +998,98 @@ int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const dou
   return 0;
 }
 
+// ---- host-buffer forms of the three liq_parm kernels: what a Fortran caller reaches (shim/mistra_kpp_liq.f90).  One device block per call,
+//      copies and kernel on the primary device's default stream, synchronous.
+namespace {
+struct DevBlock {      // one hipMalloc for a handful of arrays (256-byte aligned sub-blocks), freed on scope exit
+  char* base = nullptr;
+  size_t used = 0, cap = 0;
+  std::vector<std::pair<size_t, size_t>> parts;      // (offset, bytes)
+  size_t add(size_t bytes) { const size_t at = cap; parts.emplace_back(at, bytes); cap += (bytes + 255) & ~(size_t)255; return parts.size() - 1; }
+  hipError_t alloc() { return hipMalloc(reinterpret_cast<void**>(&base), cap ? cap : 256); }
+  double* dptr(size_t i) const { return reinterpret_cast<double*>(base + parts[i].first); }
+  hipError_t up(size_t i, const void* host) const { return hipMemcpy(base + parts[i].first, host, parts[i].second, hipMemcpyHostToDevice); }
+  hipError_t down(size_t i, void* host) const { return hipMemcpy(host, base + parts[i].first, parts[i].second, hipMemcpyDeviceToHost); }
+  ~DevBlock() { if (base) (void)hipFree(base); }
+};
+}  // namespace
+
+int mistra_chem_fast_k_mt(int mech, int nlayer, const double* ff, const double* rq, const int32_t* kw, int nkw, int ka, int ifeed, int nkc_l,
+                          const double* cw, const double* cm, const double* freep, const double* alpha, const double* vmean, double* xkmt,
+                          const double* t, const double* p, double* vt) {
+  if (int rc = lazy_init()) return rc;
+  if (int rc = check_call(mech, nlayer)) return rc;
+  if (nlayer == 0) return 0;
+  if (!ff || !rq || !kw || !cw || !cm || !freep || !alpha || !vmean || !xkmt) return fail("null pointer");
+  if (vt && (!t || !p)) return fail("the sedimentation velocity needs the layers' temperature and pressure (t, p)");
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  const MechState& S = D.mech[mech];
+  if (!S.kmt_ready) return fail(std::string("the ") + kMechName[mech] + " mechanism has no mass-transfer routine (fast_k_mt_a: aer, fast_k_mt_t: tot)");
+  const KmtTable& T = S.kmt_tab;
+  HIP_TRY(hipSetDevice(D.id));
+  const size_t nl = (size_t)nlayer, grid = (size_t)T.nka * T.nkt, nspec = (size_t)(S.tab.nvar + S.tab.nfix), nkc = (size_t)T.nkc, d8 = sizeof(double);
+  DevBlock B;
+  const size_t i_ff = B.add(nl * grid * d8), i_rq = B.add(grid * d8), i_cw = B.add(nl * nkc * d8), i_cm = B.add(nl * nkc * d8), i_fp = B.add(nl * d8),
+               i_al = B.add(nl * nspec * d8), i_vm = B.add(nl * nspec * d8), i_xk = B.add(nl * nkc * nspec * d8), i_t = B.add(nl * d8), i_p = B.add(nl * d8),
+               i_vt = B.add(nl * nkc * d8);
+  HIP_TRY(B.alloc());
+  HIP_TRY(B.up(i_ff, ff)); HIP_TRY(B.up(i_rq, rq)); HIP_TRY(B.up(i_cw, cw)); HIP_TRY(B.up(i_cm, cm)); HIP_TRY(B.up(i_fp, freep)); HIP_TRY(B.up(i_al, alpha));
+  HIP_TRY(B.up(i_vm, vmean)); HIP_TRY(B.up(i_xk, xkmt));
+  if (vt) { HIP_TRY(B.up(i_t, t)); HIP_TRY(B.up(i_p, p)); HIP_TRY(B.up(i_vt, vt)); }
+  if (int rc = mistra_chem_fast_k_mt_device(mech, nlayer, B.dptr(i_ff), B.dptr(i_rq), kw, nkw, ka, ifeed, nkc_l, B.dptr(i_cw), B.dptr(i_cm),
+                                            B.dptr(i_fp), B.dptr(i_al), B.dptr(i_vm), B.dptr(i_xk), vt ? B.dptr(i_t) : nullptr,
+                                            vt ? B.dptr(i_p) : nullptr, vt ? B.dptr(i_vt) : nullptr, nullptr))
+    return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.down(i_xk, xkmt));
+  if (vt) HIP_TRY(B.down(i_vt, vt));
+  return 0;
+}
+
+int mistra_chem_henry(int mech, int nlayer, const double* tt, double* henry) {
+  if (int rc = lazy_init()) return rc;
+  if (int rc = check_call(mech, nlayer)) return rc;
+  if (nlayer == 0) return 0;
+  if (!tt || !henry) return fail("null pointer");
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  const MechState& S = D.mech[mech];
+  if (!S.liq_ready) return fail(std::string("the ") + kMechName[mech] + " mechanism has no liquid-phase routines (henry_a: aer, henry_t: tot)");
+  HIP_TRY(hipSetDevice(D.id));
+  const size_t nl = (size_t)nlayer, nspec = (size_t)S.liq_tab.nspec;
+  DevBlock B;
+  const size_t i_t = B.add(nl * sizeof(double)), i_h = B.add(nl * nspec * sizeof(double));
+  HIP_TRY(B.alloc());
+  HIP_TRY(B.up(i_t, tt));
+  if (int rc = mistra_chem_henry_device(mech, nlayer, B.dptr(i_t), B.dptr(i_h), nullptr)) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.down(i_h, henry));
+  return 0;
+}
+
+int mistra_chem_equil_co(int mech, int nlayer, int nkc, int j6, const double* tt, const double* conv2, const double* xgamma, double* xkef, double* xkeb) {
+  if (int rc = lazy_init()) return rc;
+  if (int rc = check_call(mech, nlayer)) return rc;
+  if (nlayer == 0) return 0;
+  if (!tt || !conv2 || !xgamma || !xkef || !xkeb || nkc < 1 || j6 < 1) return fail("null pointer or bad dimensions");
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  const MechState& S = D.mech[mech];
+  if (!S.liq_ready) return fail(std::string("the ") + kMechName[mech] + " mechanism has no liquid-phase routines (equil_co_a: aer, equil_co_t: tot)");
+  HIP_TRY(hipSetDevice(D.id));
+  const size_t nl = (size_t)nlayer, nspec = (size_t)S.liq_tab.nspec, d8 = sizeof(double);
+  DevBlock B;
+  const size_t i_t = B.add(nl * d8), i_c = B.add(nl * nkc * d8), i_g = B.add(nl * nkc * j6 * d8), i_f = B.add(nl * nkc * nspec * d8), i_b = B.add(nl * nkc * nspec * d8);
+  HIP_TRY(B.alloc());
+  HIP_TRY(B.up(i_t, tt)); HIP_TRY(B.up(i_c, conv2)); HIP_TRY(B.up(i_g, xgamma)); HIP_TRY(B.up(i_f, xkef)); HIP_TRY(B.up(i_b, xkeb));
+  if (int rc = mistra_chem_equil_co_device(mech, nlayer, nkc, j6, B.dptr(i_t), B.dptr(i_c), B.dptr(i_g), B.dptr(i_f), B.dptr(i_b), nullptr))
+    return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.down(i_f, xkef)); HIP_TRY(B.down(i_b, xkeb));
+  return 0;
+}
+
 int mistra_chem_debug_set_max_steps(int max_steps) {
   std::lock_guard<std::mutex> lock(g_mu);
   g_max_steps = max_steps > 0 ? max_steps : 100000;

@@ -1,0 +1,67 @@
+! Fortran side of liq_parm's three kernels on the GPU (SURVEY.md §8 f3; include/mistra_chem.h: mistra_chem_fast_k_mt, _henry, _equil_co):
+!   FAST_K_MT_BATCH   fast_k_mt_a (kpp.f90:2683-2947) | fast_k_mt_t (kpp.f90:2421-2676): xkmt AND the sedimentation velocity vt, every 120 s
+!   HENRY_BATCH       henry_a (kpp.f90:1914-2145)     | henry_t (kpp.f90:1676-1907): the inverse dimensionless Henry constants, every step
+!   EQUIL_CO_BATCH    equil_co_a (kpp.f90:3162-3363)  | equil_co_t (kpp.f90:2954-3155): forward / backward equilibrium rate constants, every step
+! for a run of consecutive layers.  Every array of the reference has the layer as its LAST dimension, so the caller hands over the model
+! arrays in place, starting at the first layer of the run: ff(1,1,kmin), xkmt(1,1,kmin), cw(1,kmin), freep(kmin) ... (drop-ins with the
+! reference's own argument lists and COMMON blocks: shim/mistra_kpp_model.f90).  mech: 2 = aer, 3 = tot (1 = gas has no such routine).
+module mistra_kpp_liq
+  use iso_c_binding
+  use mistra_chem_c_api, only: mistra_chem_fail
+  implicit none
+  interface
+     function mistra_chem_fast_k_mt(mech, nlayer, ff, rq, kw, nkw, ka, ifeed, nkc_l, cw, cm, freep, alpha, vmean, xkmt, t, p, vt) &
+          bind(C, name="mistra_chem_fast_k_mt") result(rc)
+       import :: c_int, c_int32_t, c_double
+       integer(c_int), value :: mech, nlayer, nkw, ka, ifeed, nkc_l
+       integer(c_int32_t), intent(in) :: kw(*)
+       real(c_double), intent(in) :: ff(*), rq(*), cw(*), cm(*), freep(*), alpha(*), vmean(*), t(*), p(*)
+       real(c_double) :: xkmt(*), vt(*)
+       integer(c_int) :: rc
+     end function mistra_chem_fast_k_mt
+     function mistra_chem_henry(mech, nlayer, tt, henry) bind(C, name="mistra_chem_henry") result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: mech, nlayer
+       real(c_double), intent(in) :: tt(*)
+       real(c_double) :: henry(*)
+       integer(c_int) :: rc
+     end function mistra_chem_henry
+     function mistra_chem_equil_co(mech, nlayer, nkc, j6, tt, conv2, xgamma, xkef, xkeb) bind(C, name="mistra_chem_equil_co") result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: mech, nlayer, nkc, j6
+       real(c_double), intent(in) :: tt(*), conv2(*), xgamma(*)
+       real(c_double) :: xkef(*), xkeb(*)
+       integer(c_int) :: rc
+     end function mistra_chem_equil_co
+  end interface
+contains
+  ! ff(nkt,nka,nlayer), rq(nkt,nka), kw(nka), cw / cm(nkc,nlayer), freep(nlayer), alpha / vmean(NSPEC,nlayer), xkmt(NSPEC,nkc,nlayer) in/out,
+  ! t / p(nlayer), vt(nkc,nlayer) in/out
+  subroutine FAST_K_MT_BATCH(mech, nlayer, ff, rq, nka, kw, ka, ifeed, nkc_l, cw, cm, freep, alpha, vmean, xkmt, t, p, vt)
+    integer, intent(in) :: mech, nlayer, nka, kw(nka), ka, ifeed, nkc_l
+    real(c_double), intent(in) :: ff(*), rq(*), cw(*), cm(*), freep(*), alpha(*), vmean(*), t(*), p(*)
+    real(c_double) :: xkmt(*), vt(*)
+    if (nlayer <= 0) return
+    if (mistra_chem_fast_k_mt(int(mech - 1, c_int), int(nlayer, c_int), ff, rq, int(kw, c_int32_t), int(nka, c_int), int(ka, c_int), int(ifeed, c_int), &
+                              int(nkc_l, c_int), cw, cm, freep, alpha, vmean, xkmt, t, p, vt) /= 0) call mistra_chem_fail('FAST_K_MT_BATCH')
+  end subroutine FAST_K_MT_BATCH
+
+  ! tt(nlayer) -> henry(NSPEC,nlayer), written whole
+  subroutine HENRY_BATCH(mech, nlayer, tt, henry)
+    integer, intent(in) :: mech, nlayer
+    real(c_double), intent(in) :: tt(*)
+    real(c_double) :: henry(*)
+    if (nlayer <= 0) return
+    if (mistra_chem_henry(int(mech - 1, c_int), int(nlayer, c_int), tt, henry) /= 0) call mistra_chem_fail('HENRY_BATCH')
+  end subroutine HENRY_BATCH
+
+  ! tt(nlayer), conv2(nkc,nlayer), xgamma(j6,nkc,nlayer) -> xkef, xkeb(NSPEC,nkc,nlayer) in/out
+  subroutine EQUIL_CO_BATCH(mech, nlayer, nkc, j6, tt, conv2, xgamma, xkef, xkeb)
+    integer, intent(in) :: mech, nlayer, nkc, j6
+    real(c_double), intent(in) :: tt(*), conv2(*), xgamma(*)
+    real(c_double) :: xkef(*), xkeb(*)
+    if (nlayer <= 0) return
+    if (mistra_chem_equil_co(int(mech - 1, c_int), int(nlayer, c_int), int(nkc, c_int), int(j6, c_int), tt, conv2, xgamma, xkef, xkeb) /= 0) &
+         call mistra_chem_fail('EQUIL_CO_BATCH')
+  end subroutine EQUIL_CO_BATCH
+end module mistra_kpp_liq

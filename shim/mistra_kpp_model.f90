@@ -26,3 +26,112 @@ subroutine KPP_DRIVE_RUN(tkpp, dt_ch)
   end if
   call kpp_drive_run_arrays(tkpp, dt_ch, n, s1, s3, sl1, sion1, nrxn, nlev, il, bg, bgs)
 end subroutine KPP_DRIVE_RUN
+
+! ---- liq_parm's kernels (SURVEY.md §8 f3) with the reference's own argument lists: rename these to fast_k_mt_t / henry_t / equil_co_t (and
+!      the _a ones) in place of the reference's routines, or call them from liq_parm (kpp.f90:614-637).  They name the model's COMMON blocks as
+!      the reference routines do (kpp.f90:2483-2526 | 2745-2788; 1717-1722; 3008-3016) and hand the layers nmin..nmax over in place.
+subroutine FAST_K_MT_HIP_t(freep, box, n_bl)      ! fast_k_mt_t (freep,box,n_bl), kpp.f90:2421
+  USE config, ONLY : ifeed
+  USE global_params, ONLY : nf, n, nka, nkt, nkc
+  USE mistra_kpp_liq, ONLY : FAST_K_MT_BATCH
+  implicit none
+  double precision, intent(in) :: freep(n)
+  logical, intent(in) :: box
+  integer, intent(in) :: n_bl
+  integer, parameter :: NSPEC = 424                ! tot_Parameters.h
+  integer :: kw, ka, nar, nmin, nmax
+  double precision :: cw, cm, enw, ew, rn, rw, en, e, dew, rq, ff, fsum, theta, thetl, t, talt, p, rho, alpha, vmean, henry, xkmt, xkef, xkeb, vt, vd, vdm
+  common /blck06/ kw(nka), ka
+  common /blck12/ cw(nkc,n), cm(nkc,n)
+  common /cb50/ enw(nka), ew(nkt), rn(nka), rw(nkt,nka), en(nka), e(nkt), dew(nkt), rq(nkt,nka)
+  common /cb52/ ff(nkt,nka,n), fsum(n), nar(n)
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  common /kpp_2tot/ alpha(NSPEC,nf), vmean(NSPEC,nf)
+  common /kpp_ltot/ henry(NSPEC,nf), xkmt(NSPEC,nkc,nf), xkef(NSPEC,nkc,nf), xkeb(NSPEC,nkc,nf)
+  common /kpp_vt/ vt(nkc,nf), vd(nkt,nka), vdm(nkc)
+  nmin = 2; nmax = nf                              ! kpp.f90:2541-2547
+  if (box) then
+     nmin = n_bl; nmax = n_bl
+  end if
+  call FAST_K_MT_BATCH(3, nmax - nmin + 1, ff(1,1,nmin), rq, nka, kw, ka, ifeed, nkc, cw(1,nmin), cm(1,nmin), freep(nmin), alpha(1,nmin), vmean(1,nmin), &
+                       xkmt(1,1,nmin), t(nmin), p(nmin), vt(1,nmin))
+end subroutine FAST_K_MT_HIP_t
+
+subroutine FAST_K_MT_HIP_a(freep, box, n_bl)      ! fast_k_mt_a (freep,box,n_bl), kpp.f90:2683
+  USE config, ONLY : ifeed, nkc_l
+  USE global_params, ONLY : nf, n, nka, nkt, nkc
+  USE mistra_kpp_liq, ONLY : FAST_K_MT_BATCH
+  implicit none
+  double precision, intent(in) :: freep(n)
+  logical, intent(in) :: box
+  integer, intent(in) :: n_bl
+  integer, parameter :: NSPEC = 262                ! aer_Parameters.h
+  integer :: kw, ka, nar, nmin, nmax
+  double precision :: cw, cm, enw, ew, rn, rw, en, e, dew, rq, ff, fsum, theta, thetl, t, talt, p, rho, alpha, vmean, henry, xkmt, xkef, xkeb, vt, vd, vdm
+  common /blck06/ kw(nka), ka
+  common /blck12/ cw(nkc,n), cm(nkc,n)
+  common /cb50/ enw(nka), ew(nkt), rn(nka), rw(nkt,nka), en(nka), e(nkt), dew(nkt), rq(nkt,nka)
+  common /cb52/ ff(nkt,nka,n), fsum(n), nar(n)
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  common /kpp_2aer/ alpha(NSPEC,nf), vmean(NSPEC,nf)
+  common /kpp_laer/ henry(NSPEC,nf), xkmt(NSPEC,nkc,nf), xkef(NSPEC,nkc,nf), xkeb(NSPEC,nkc,nf)
+  common /kpp_vt/ vt(nkc,nf), vd(nkt,nka), vdm(nkc)
+  nmin = 2; nmax = nf
+  if (box) then
+     nmin = n_bl; nmax = n_bl
+  end if
+  call FAST_K_MT_BATCH(2, nmax - nmin + 1, ff(1,1,nmin), rq, nka, kw, ka, ifeed, nkc_l, cw(1,nmin), cm(1,nmin), freep(nmin), alpha(1,nmin), vmean(1,nmin), &
+                       xkmt(1,1,nmin), t(nmin), p(nmin), vt(1,nmin))
+end subroutine FAST_K_MT_HIP_a
+
+subroutine HENRY_HIP_t(tt, nmaxf)                  ! henry_t (tt,nmaxf), kpp.f90:1676: layers 1..nmaxf
+  USE global_params, ONLY : nf, n, nkc
+  USE mistra_kpp_liq, ONLY : HENRY_BATCH
+  implicit none
+  double precision, intent(in) :: tt(n)
+  integer, intent(in) :: nmaxf
+  integer, parameter :: NSPEC = 424
+  double precision :: henry, xkmt, xkef, xkeb
+  common /kpp_ltot/ henry(NSPEC,nf), xkmt(NSPEC,nkc,nf), xkef(NSPEC,nkc,nf), xkeb(NSPEC,nkc,nf)
+  call HENRY_BATCH(3, nmaxf, tt, henry)
+end subroutine HENRY_HIP_t
+
+subroutine HENRY_HIP_a(tt, nmaxf)                  ! henry_a (tt,nmaxf), kpp.f90:1914
+  USE global_params, ONLY : nf, n, nkc
+  USE mistra_kpp_liq, ONLY : HENRY_BATCH
+  implicit none
+  double precision, intent(in) :: tt(n)
+  integer, intent(in) :: nmaxf
+  integer, parameter :: NSPEC = 262
+  double precision :: henry, xkmt, xkef, xkeb
+  common /kpp_laer/ henry(NSPEC,nf), xkmt(NSPEC,nkc,nf), xkef(NSPEC,nkc,nf), xkeb(NSPEC,nkc,nf)
+  call HENRY_BATCH(2, nmaxf, tt, henry)
+end subroutine HENRY_HIP_a
+
+subroutine EQUIL_CO_HIP_t(tt, nmaxf)               ! equil_co_t (tt,nmaxf), kpp.f90:2954
+  USE global_params, ONLY : j6, nf, n, nkc
+  USE mistra_kpp_liq, ONLY : EQUIL_CO_BATCH
+  implicit none
+  double precision, intent(in) :: tt(n)
+  integer, intent(in) :: nmaxf
+  integer, parameter :: NSPEC = 424
+  double precision :: conv2, xgamma, henry, xkmt, xkef, xkeb
+  common /blck13/ conv2(nkc,n)
+  common /kpp_mol/ xgamma(j6,nkc,nf)
+  common /kpp_ltot/ henry(NSPEC,nf), xkmt(NSPEC,nkc,nf), xkef(NSPEC,nkc,nf), xkeb(NSPEC,nkc,nf)
+  call EQUIL_CO_BATCH(3, nmaxf - 1, nkc, j6, tt(2), conv2(1,2), xgamma(1,1,2), xkef(1,1,2), xkeb(1,1,2))      ! do k=2,nmaxf (kpp.f90:3020)
+end subroutine EQUIL_CO_HIP_t
+
+subroutine EQUIL_CO_HIP_a(tt, nmaxf)               ! equil_co_a (tt,nmaxf), kpp.f90:3162
+  USE global_params, ONLY : j6, nf, n, nkc
+  USE mistra_kpp_liq, ONLY : EQUIL_CO_BATCH
+  implicit none
+  double precision, intent(in) :: tt(n)
+  integer, intent(in) :: nmaxf
+  integer, parameter :: NSPEC = 262
+  double precision :: conv2, xgamma, henry, xkmt, xkef, xkeb
+  common /blck13/ conv2(nkc,n)
+  common /kpp_mol/ xgamma(j6,nkc,nf)
+  common /kpp_laer/ henry(NSPEC,nf), xkmt(NSPEC,nkc,nf), xkef(NSPEC,nkc,nf), xkeb(NSPEC,nkc,nf)
+  call EQUIL_CO_BATCH(2, nmaxf - 1, nkc, j6, tt(2), conv2(1,2), xgamma(1,1,2), xkef(1,1,2), xkeb(1,1,2))      ! do k=2,nmaxf (kpp.f90:3228)
+end subroutine EQUIL_CO_HIP_a

@@ -17,6 +17,10 @@
 !                                                      sl1(121,4,n) sion1(55,4,n) bg(2,nrxn,nlev) bgs(2,122,n) | per layer: mech, k, air, h2o, env(nenv).
 !                                                      out.bin: the arrays after the step | per layer ierr, 8 statistics, texit, hexit | per repetition
 !                                                      the wall times (ms) of the staging loop and of the device call(s)
+!          shim_driver <Ka|Kt|Ha|Ht|Qa|Qt> <in.bin> <out.bin>   liq_parm's kernels through shim/mistra_kpp_liq.f90 (SURVEY §8 f3): K = FAST_K_MT_BATCH
+!                                                      (in: nlayer, nka, nkt, nkc, nspec, ka, ifeed, nkc_l | kw | rq | ff cw cm freep alpha vmean xkmt t p vt;
+!                                                      out: xkmt, vt), H = HENRY_BATCH (in: nlayer, nspec | tt; out: henry), Q = EQUIL_CO_BATCH (in: nlayer,
+!                                                      nkc, j6, nspec | tt conv2 xgamma xkef xkeb; out: xkef, xkeb)
 ! After the call the one-cell mode also writes ATOL(1), RTOL(1) (INTEGRATE_x resets them, gas.f:745-746).
 program shim_driver
   use mistra_kpp_rates
@@ -33,6 +37,12 @@ program shim_driver
   case ('A'); call run_batch(1, 257, 5, 979, trim(fin), trim(fout))
   case ('T'); call run_batch(2, 417, 7, 1627, trim(fin), trim(fout))
   case ('D'); call run_drive(trim(fin), trim(fout))
+  case ('K', 'H', 'Q')
+     select case (a1(2:2))
+     case ('a'); call run_liq(a1(1:1), 2, trim(fin), trim(fout))
+     case ('t'); call run_liq(a1(1:1), 3, trim(fin), trim(fout))
+     case default; stop 'mechanism must be a or t'
+     end select
   case ('E')
      select case (a1(2:2))
      case ('g'); call run_env(0, 102, 3, 331, nenv_g, trim(fin), trim(fout))
@@ -185,6 +195,46 @@ contains
     end do
     close (11); close (12)
   end subroutine run_env
+  subroutine run_liq(what, mech, fin, fout)
+    use mistra_kpp_liq
+    character(len=1), intent(in) :: what
+    integer, intent(in) :: mech
+    character(len=*), intent(in) :: fin, fout
+    double precision :: h(8)
+    integer :: nl, nka, nkt, nkc, nspec, ka, ifeed, nkc_l, j6
+    integer, allocatable :: kw(:)
+    double precision, allocatable :: tmp(:), rq(:), ff(:), cw(:), cm(:), freep(:), alpha(:), vmean(:), xkmt(:), t(:), p(:), vt(:), henry(:), conv2(:), xgamma(:), &
+                                     xkef(:), xkeb(:)
+    open (11, file=fin, access='stream', form='unformatted', status='old')
+    open (12, file=fout, access='stream', form='unformatted', status='replace')
+    select case (what)
+    case ('K')
+       read (11) h
+       nl = int(h(1)); nka = int(h(2)); nkt = int(h(3)); nkc = int(h(4)); nspec = int(h(5)); ka = int(h(6)); ifeed = int(h(7)); nkc_l = int(h(8))
+       allocate (tmp(nka), kw(nka), rq(nkt * nka), ff(nkt * nka * nl), cw(nkc * nl), cm(nkc * nl), freep(nl), alpha(nspec * nl), vmean(nspec * nl), &
+                 xkmt(nspec * nkc * nl), t(nl), p(nl), vt(nkc * nl))
+       read (11) tmp; kw = int(tmp)
+       read (11) rq, ff, cw, cm, freep, alpha, vmean, xkmt, t, p, vt
+       call FAST_K_MT_BATCH(mech, nl, ff, rq, nka, kw, ka, ifeed, nkc_l, cw, cm, freep, alpha, vmean, xkmt, t, p, vt)
+       write (12) xkmt, vt
+    case ('H')
+       read (11) h(1:2)
+       nl = int(h(1)); nspec = int(h(2))
+       allocate (t(nl), henry(nspec * nl))
+       read (11) t
+       henry = -7.d0
+       call HENRY_BATCH(mech, nl, t, henry)
+       write (12) henry
+    case ('Q')
+       read (11) h(1:4)
+       nl = int(h(1)); nkc = int(h(2)); j6 = int(h(3)); nspec = int(h(4))
+       allocate (t(nl), conv2(nkc * nl), xgamma(j6 * nkc * nl), xkef(nspec * nkc * nl), xkeb(nspec * nkc * nl))
+       read (11) t, conv2, xgamma, xkef, xkeb
+       call EQUIL_CO_BATCH(mech, nl, nkc, j6, t, conv2, xgamma, xkef, xkeb)
+       write (12) xkef, xkeb
+    end select
+    close (11); close (12)
+  end subroutine run_liq
   subroutine run_drive(fin, fout)
     use mistra_kpp_drive
     character(len=*), intent(in) :: fin, fout

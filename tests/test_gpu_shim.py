@@ -168,3 +168,69 @@ def test_fortran_batched_column_step(name, tmp_path, capsys):
         with capsys.disabled():
             # the reference spends 69 us per gas call inside kpp_driver on one 2.1 GHz core (pack + rates + integrator)
             print("  column %s: %d cells of one 10-s step in %.2f ms through the batched Fortran surface" % (name, ncells, total_ms))
+
+
+@needs_flang
+@pytest.mark.parametrize("mech", ["aer", "tot"])
+def test_fortran_liq_parm_kernels(mech, tmp_path):
+    """SURVEY §8 f3 from Fortran: FAST_K_MT_BATCH (xkmt and the sedimentation velocity vt), HENRY_BATCH, EQUIL_CO_BATCH of
+    shim/mistra_kpp_liq.f90 — the host-buffer calls the drop-ins of shim/mistra_kpp_model.f90 make with the model's arrays in place — on the
+    layers captured from the running reference model.  The results must be the device-pointer entry points' bit for bit (same kernels), i.e.
+    what tests/test_gpu_kmt.py and test_gpu_liq.py pin against the captures."""
+    import torch
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "shim")], check=True)
+    from mistra_amd import chem
+    chem.init(0)
+    dev = torch.device("cuda", 0)
+    T = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    f8 = lambda *a: np.array(a, np.float64)
+    # ---- fast_k_mt_x
+    g = np.load(os.path.join(REPO, "tests", "golden", "kmt_%s.npz" % mech))
+    nl, nkc, nspec = g["xkmt_before"].shape
+    nka, nkt = g["rq"].shape
+    vt0 = np.full((nl, nkc), -7.0)
+    with open(fin, "wb") as f:
+        f8(nl, nka, nkt, nkc, nspec, int(g["ka"]), int(g["ifeed"]), int(g["nkc_l"])).tofile(f)
+        for a in (g["kw"].astype(np.float64), g["rq"], g["ff"], g["cw"], g["cm"], g["freep"], g["alpha"], g["vmean"], g["xkmt_before"], g["t"], g["p"], vt0):
+            np.ascontiguousarray(a, np.float64).tofile(f)
+    subprocess.run([DRIVER, "K" + mech[0], str(fin), str(fout)], check=True, timeout=300)
+    raw = np.fromfile(fout, np.float64)
+    xk, vt = raw[:nl * nkc * nspec].reshape(nl, nkc, nspec), raw[nl * nkc * nspec:].reshape(nl, nkc)
+    assert np.array_equal(xk, g["xkmt_after"]), "xkmt from Fortran differs from the reference's"
+    wet = g["cw"] > 0
+    assert np.all(vt[~wet] == -7.0) and (np.abs(vt[wet] - g["vt_after"][wet]) / np.abs(g["vt_after"][wet])).max() <= 1e-14
+    dx, dv = T(g["xkmt_before"]), T(vt0)
+    chem.fast_k_mt(mech, T(g["ff"]), T(g["rq"]), g["kw"], int(g["ka"]), int(g["ifeed"]), int(g["nkc_l"]), T(g["cw"]), T(g["cm"]), T(g["freep"]), T(g["alpha"]),
+                   T(g["vmean"]), dx, T(g["t"]), T(g["p"]), dv)
+    torch.cuda.synchronize()
+    assert np.array_equal(dx.cpu().numpy(), xk) and np.array_equal(dv.cpu().numpy(), vt)
+    # ---- henry_x, equil_co_x
+    g = np.load(os.path.join(REPO, "tests", "golden", "liq_%s.npz" % mech))
+    nl, nspec = g["henry"].shape
+    with open(fin, "wb") as f:
+        f8(nl, nspec).tofile(f)
+        np.ascontiguousarray(g["henry_tt"], np.float64).tofile(f)
+    subprocess.run([DRIVER, "H" + mech[0], str(fin), str(fout)], check=True, timeout=300)
+    hen = np.fromfile(fout, np.float64).reshape(nl, nspec)
+    dh = torch.full((nl, nspec), float("nan"), dtype=torch.float64, device=dev)
+    chem.henry(mech, T(g["henry_tt"]), dh)
+    torch.cuda.synchronize()
+    assert np.array_equal(hen, dh.cpu().numpy())
+    nz = g["henry"] != 0
+    assert np.array_equal(hen == 0, ~nz) and (np.abs(hen[nz] - g["henry"][nz]) / np.abs(g["henry"][nz])).max() <= 1e-14
+    nl, nkc, j6 = g["xgamma"].shape
+    with open(fin, "wb") as f:
+        f8(nl, nkc, j6, nspec).tofile(f)
+        for a in (g["equil_tt"], g["conv2"], g["xgamma"], g["xkef_before"], g["xkeb_before"]):
+            np.ascontiguousarray(a, np.float64).tofile(f)
+    subprocess.run([DRIVER, "Q" + mech[0], str(fin), str(fout)], check=True, timeout=300)
+    raw = np.fromfile(fout, np.float64)
+    ef, eb = raw[:nl * nkc * nspec].reshape(nl, nkc, nspec), raw[nl * nkc * nspec:].reshape(nl, nkc, nspec)
+    df, db = T(g["xkef_before"]), T(g["xkeb_before"])
+    chem.equil_co(mech, T(g["equil_tt"]), T(g["conv2"]), T(g["xgamma"]), df, db)
+    torch.cuda.synchronize()
+    assert np.array_equal(ef, df.cpu().numpy()) and np.array_equal(eb, db.cpu().numpy())
+    for got, want in ((ef, g["xkef"]), (eb, g["xkeb"])):
+        nz = want != 0
+        assert np.array_equal(got == 0, ~nz) and (np.abs(got[nz] - want[nz]) / np.abs(want[nz])).max() <= 1e-14
