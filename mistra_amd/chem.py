@@ -81,9 +81,10 @@ def lib():
         L.mistra_chem_henry_device.argtypes = [C.c_int, C.c_int, vp, vp, vp]
         L.mistra_chem_equil_co_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.mistra_chem_drive_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp]
-        L.mistra_chem_drive.argtypes = [C.c_int, C.c_int, _ip, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _ip, _dp, _dp, C.c_int,
-                                        _ip, _dp, _dp]
-        L.mistra_chem_debug_set_max_steps.argtypes = [C.c_int]
+        if hasattr(L, "mistra_chem_drive"):      # (an older build of the library loaded for a same-box A/B, tools/ab_many.sh, does not have these)
+            L.mistra_chem_drive.argtypes = [C.c_int, C.c_int, _ip, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _ip, _dp, _dp, C.c_int,
+                                            _ip, _dp, _dp]
+            L.mistra_chem_debug_set_max_steps.argtypes = [C.c_int]
         L.mistra_chem_last_error.restype = C.c_char_p
         L.mistra_chem_describe.restype = C.c_char_p
         L.mistra_chem_describe.argtypes = [C.c_int]

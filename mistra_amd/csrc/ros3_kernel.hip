@@ -1060,16 +1060,37 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     const int s = q * NT + t;
     y[q] = s < NVAR ? G_(a.var_in)[(size_t)cell * NVAR + s] : 0.0;
   }
-  auto load_rct = [&](bool opaque) {      // this thread's rate constants (the register-starved kernel fetches them per use, like its factor words)
+  // (the register-starved kernels fetch them per use, like their factor words; MISTRA_RCT_RESIDENT_SLOTS of the RPT values per thread stay in
+  //  registers all the same: every value kept is one global re-read per Fun / Jac_SP less — the re-reads that miss the L2 are what is left
+  //  of aer's HBM-side excess)
+#ifndef MISTRA_RCT_RESIDENT_SLOTS
+#define MISTRA_RCT_RESIDENT_SLOTS 0
+#endif
+  constexpr int RCT_KEEP = MT::WAVES_PER_SIMD <= MISTRA_RESIDENT_MAX_WPS ? RPT : (MISTRA_RCT_RESIDENT_SLOTS < RPT ? MISTRA_RCT_RESIDENT_SLOTS : RPT);
+  auto load_rct = [&](bool opaque) {      // this thread's rate constants; opaque: the per-use fetch of the values that are not kept
     const double* rc = a.rconst;
     if (opaque) asm volatile("" : "+s"(rc));
+    int tt = t;
+    if (opaque) asm volatile("" : "+v"(tt));      // (addresses derived where they are used: hoisted out of the step loop they are registers that spill)
 #pragma unroll
-    for (int q = 0; q < RPT; q++) {
-      const int r = q * NT + t;
+    for (int q = opaque ? RCT_KEEP : 0; q < RPT; q++) {
+      const int r = q * NT + tt;
+      if constexpr (L::RCT_IN_LDS) {      // (per use: out of the cell's copy in LDS, put there once, below)
+        if (opaque) { rct[q] = r < NREACT ? lds_ld(8u * (uint32_t)(L::RCT + r)) : 0.0; continue; }
+      }
       rct[q] = r < NREACT ? G_(rc)[(size_t)cell * NREACT + r] : 0.0;
     }
   };
-  load_rct(false);
+  if constexpr (L::RCT_IN_LDS) {      // global -> LDS, once; read back by the same thread that wrote them (r = q*NT + t): no barrier involved
+#pragma unroll
+    for (int q = 0; q < RPT; q++) {
+      const int r = q * NT + t;
+      if (r < NREACT) lds[L::RCT + r] = G_(a.rconst)[(size_t)cell * NREACT + r];
+      rct[q] = 0.0;
+    }
+  } else {
+    load_rct(false);
+  }
   // Ghimj slots this thread fills in ros_PrepareMatrix (static per mechanism): fetched once, not once per attempt
   // (two 16-bit positions per register)
   // RESIDENT: the kernel with 256 registers (tot) keeps these words for the whole call; the 128-register ones (aer, gas: four
@@ -1095,14 +1116,21 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   // spill nine of the twelve and reload them one at a time, each load's latency exposed.  jac() fetches them in one batch of
   // coalesced loads instead (48 KB table, L2-resident; measured: the batch lands in ~380 cycles, Jac_SP's products went from
   // 11 000 to 7 400 cycles per call, the kernel's scratch from 104 to 8 bytes per lane).
+  // (tot, round 4: with the four words resident the kernel was 3 registers over what it can keep across its calls — one of these words and an
+  //  LDS address went through scratch, reloaded right behind a barrier in every Fun, a memory round trip each; fetched per use they ride in
+  //  the batch of Jac_SP's words that fun_jac issues anyway, and the kernel has no scratch)
+#ifndef MISTRA_FFAC_RESIDENT
+#define MISTRA_FFAC_RESIDENT 0
+#endif
+  constexpr bool FFAC_RESIDENT = RESIDENT && MISTRA_FFAC_RESIDENT;
   uint64_t ffac[RPT];
   auto load_ffac = [&]() {
     const uint64_t* ff = a.fun_fac;
-    if constexpr (!RESIDENT) asm volatile("" : "+s"(ff));
+    if constexpr (!FFAC_RESIDENT) asm volatile("" : "+s"(ff));
 #pragma unroll
     for (int q = 0; q < RPT; q++) ffac[q] = G_(ff)[q * NT + t];
   };
-  if constexpr (RESIDENT) load_ffac();
+  if constexpr (FFAC_RESIDENT) load_ffac();
   if (t < NFIX) X[NVAR + t] = G_(a.fix)[(size_t)cell * NFIX + t];
   if (t < NCONST) X[NVAR + NFIX + t] = G_(a.consts)[t];
   if constexpr (MT::DENSE_ND > 0) {      // the dense tail block's row table stays in LDS for the whole call
@@ -1153,7 +1181,8 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   // ---- Fun_x (gas.f:2043): X <- v; A(r) = RCT(r)*X*X*X; Vdot = signed sums of A
   static_assert(SPT == 1 && JPT * NT <= NNZ, "output cells of the gather-sum machine: one species per thread, JVS sums inside Ghimj");
   auto fun = [&](const double (&v)[SPT], double (&out)[SPT]) {
-    if constexpr (!RESIDENT) { load_ffac(); load_rct(true); }
+    if constexpr (!FFAC_RESIDENT) load_ffac();
+    if constexpr (!RESIDENT) load_rct(true);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
       const int s = q * NT + t;
@@ -1250,7 +1279,8 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
 #pragma unroll
       for (int q = 0; q < 3 * RPT; q++) jfac[q] = G_(jf)[q * NT + t];
     }
-    if constexpr (!RESIDENT) { load_ffac(); load_rct(true); }
+    if constexpr (!FFAC_RESIDENT) load_ffac();
+    if constexpr (!RESIDENT) load_rct(true);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
       const int s = q * NT + t;
@@ -1345,7 +1375,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       uint32_t pw = zpos[q / 2];          // slot 0 of its thread (schedule.cpp sorts them there): the other slots have nothing to select
       asm volatile("" : "+v"(pw));
       const uint32_t p = (q & 1) ? (pw >> 16) : (pw & 0xFFFFu);
-      if (q == 0) put(p, -0.0);
+      if (q == 0) put(p, scalar_const(-0.0));      // (formed in scalar registers here: as a hoisted vector-register pair the zero was the 128-register kernel's one spilled value)
       else M[p == kPosNone ? (uint32_t)(NNZ + NVAR + 2) : (p & 0x7FFFu)] = -0.0;
     }
     if (zero_diag) flags[0] = 1;
@@ -1472,6 +1502,10 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     }
 
     lap(6);
+    if constexpr (!RESIDENT) {      // (Jac_SP below defines every entry.  Said here with an empty statement that "writes" them, so that no value — not even an
+#pragma unroll                     //  undefined one — is carried around the step loop: the 128-register kernels carried one through scratch)
+      for (int q = 0; q < JPT; q++) asm volatile("" : "=v"(jac0[q]));
+    }
     if constexpr (L::MERGE_FUN_JAC) {
       fun_jac(y, fcn0);
       dump_vec(0, fcn0);
@@ -1616,10 +1650,14 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   }
 
   // ---- results
+  {
+    int tt = t;
+    asm volatile("" : "+v"(tt));      // (the output offset is formed here: shared with the input load's it was a 64-bit value kept across the whole step loop — in scratch, in the 128-register kernels)
 #pragma unroll
-  for (int q = 0; q < SPT; q++) {
-    const int s = q * NT + t;
-    if (s < NVAR) GM_(a.var_out)[(size_t)cell * NVAR + s] = y[q];
+    for (int q = 0; q < SPT; q++) {
+      const int s = q * NT + tt;
+      if (s < NVAR) GM_(a.var_out)[(size_t)cell * NVAR + s] = y[q];
+    }
   }
   if (t == 0) {
     GM_(a.ierr)[cell] = ierr;

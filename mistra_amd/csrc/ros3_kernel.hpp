@@ -57,7 +57,14 @@ struct LdsLayout {
   static constexpr int JVS_CELLS = (MT::NJNZ + NT - 1) / NT * NT;
   static constexpr bool MERGE_FUN_JAC = JVS_CELLS + round_up2(AB_TRASH + 64) <= MT::NNZ;
   static constexpr int JB = MERGE_FUN_JAC ? M + JVS_CELLS : AB;                             // base of the B products
-  static constexpr int RED = AB + round_up2(AB_TRASH + 64);                            // (one shared cell: every such store of a wave hit the same address, and LDS serialises those)                             // per-wave partial sums
+  // the A array: where B has an array of its own it holds the NREACT rate products and its spare cells (schedule.cpp: a_trash) — tot 8 KB,
+  // aer 4.9 KB smaller than the shared array was (round 4)
+  static constexpr int A_CELLS = MERGE_FUN_JAC ? MT::NREACT : AB_TRASH;
+  // ... and the kernels that are held to 128 registers (two aer cells per CU) keep the cell's RATE CONSTANTS in the room that frees: they
+  // cannot hold them in registers and used to fetch them from global memory in front of every Fun / Jac_SP (~300 times per cell)
+  static constexpr bool RCT_IN_LDS = MERGE_FUN_JAC && MT::WAVES_PER_SIMD > MISTRA_RESIDENT_MAX_WPS;
+  static constexpr int RCT = AB + round_up2(A_CELLS + 64);
+  static constexpr int RED = RCT + (RCT_IN_LDS ? round_up2(MT::NREACT) : 0);                            // (one shared cell: every such store of a wave hit the same address, and LDS serialises those)                             // per-wave partial sums
   static constexpr int FLAGS = RED + 32;
   static constexpr int DINFO = FLAGS + 2;                                               // dense tail block: row table of the block's 64 rows, 16 bytes each (schedule.hpp: DenseTail)
   static constexpr int SCHUR = DINFO + (MT::DENSE_ND > 0 ? 64 * 2 : 0);                 // ... and the Schur steps' operand cells, uint16 x 8 x DENSE_KB x 64
@@ -67,7 +74,7 @@ struct LdsLayout {
   // two buffers of [64][4] panel columns + [64][4] panel rows, two 64-entry broadcast rows of the eliminating wave
   static constexpr int PANEL = AB;
   static constexpr int PANEL_CELLS = 2 * 2 * 64 * 4 + 2 * 64 + 4;      // (+ the panel's four pivot reciprocals)
-  static_assert(MT::DENSE_ND == 0 || PANEL_CELLS <= AB_TRASH, "panel buffers must fit the product array");
+  static_assert(MT::DENSE_ND == 0 || PANEL_CELLS <= A_CELLS + 64, "panel buffers must fit the product array");
   static_assert(TOTAL * 8 <= 160 * 1024, "cell state does not fit the 160 KiB LDS of a gfx950 CU");
   static_assert(NT % 64 == 0 && NT <= 1024 && NT / 64 <= 32, "workgroup size");
 };

@@ -788,9 +788,13 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   const uint64_t one = (uint64_t)(m.nvar + m.nfix);       // X slot of the constant 1.0
 
   // ---- Fun_x products
-  const uint64_t ab_trash = (uint64_t)std::max(m.nreact, m.nb);     // spare cells behind the A/B product array, one per lane (LdsLayout::AB_TRASH)
+  const uint64_t ab_trash = (uint64_t)std::max(m.nreact, m.nb);     // spare cells behind the B products (and the A products where they share the array), one per lane (LdsLayout::AB_TRASH)
+  // where Jac_SP's B products have an array of their own (jb_base_bytes: inside the Ghimj area), the A array holds NREACT products and its
+  // spare cells come right behind them (LdsLayout::A_CELLS)
+  const uint64_t a_trash = jb_base_bytes ? (uint64_t)m.nreact : ab_trash;
+  S.a_trash = (int)a_trash;
   S.fun_fac.resize((size_t)S.rpt * nt);
-  for (size_t i = 0; i < S.fun_fac.size(); i++) S.fun_fac[i] = one | (one << 16) | (one << 32) | ((ab_trash + (i % (size_t)nt) % 64) << 48);
+  for (size_t i = 0; i < S.fun_fac.size(); i++) S.fun_fac[i] = one | (one << 16) | (one << 32) | ((a_trash + (i % (size_t)nt) % 64) << 48);
   for (int r = 0; r < m.nreact; r++) {
     uint64_t f[3] = {one, one, one};
     int nf = m.a_ptr[r + 1] - m.a_ptr[r];

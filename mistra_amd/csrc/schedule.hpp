@@ -211,7 +211,8 @@ struct KernelSchedule {
   int n_jnz = 0, n_jzero = 0;
   uint32_t ab_base_bytes = 0, jb_base_bytes = 0;      // LDS byte addresses of the A products and of the B products (ros3_kernel.hpp: LdsLayout::AB, JB)
   // Fun_x products: A(r) = RCT(r)*X[f1]*X[f2]*X[f3], padded with the constant 1.0
-  std::vector<uint64_t> fun_fac;                // [rpt*nt]  f1 | f2<<16 | f3<<32 | out<<48   (out = reaction, or the spare cell max(nreact,nb) for a thread without one)
+  int a_trash = 0;                              // first spare cell of the A array: nreact where B has an array of its own, else max(nreact, nb)
+  std::vector<uint64_t> fun_fac;                // [rpt*nt]  f1 | f2<<16 | f3<<32 | out<<48   (out = reaction, or a spare cell a_trash + lane for a thread without one)
   GsumProgram vdot;                             // src = A (LDS), output (q,t) = species q*nt+t
   // Jac_SP_x products, grouped under the reaction that owns the rate constant: up to 3 B's per reaction
   std::vector<uint64_t> jac_fac;                // [(q*3 + b)*nt + t]  f1 | f2<<16 | f3<<32 | out<<48 (the spare cell = none)

@@ -376,7 +376,7 @@ void emu_fun(void* h, const double* V, const double* F, const double* RCT, doubl
     for (int t = 0; t < s.nt; t++) {
       uint64_t w = s.fun_fac[(size_t)q * s.nt + t];
       const int out = (int)((w >> 48) & 0xFFFF), r = q * s.nt + t;
-      if (out >= std::max(e->m.nreact, e->m.nb)) continue;       // a spare cell (one per lane): this thread owns no reaction in slot q
+      if (out >= s.a_trash) continue;       // a spare cell (one per lane): this thread owns no reaction in slot q
       if (out != r) std::abort();
       double a = RCT[r];
       a = a * X[w & 0xFFFF];
