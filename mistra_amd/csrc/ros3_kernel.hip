@@ -1179,7 +1179,15 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   };
 
   // ---- Fun_x (gas.f:2043): X <- v; A(r) = RCT(r)*X*X*X; Vdot = signed sums of A
-  static_assert(SPT == 1 && JPT * NT <= NNZ, "output cells of the gather-sum machine: one species per thread, JVS sums inside Ghimj");
+  static_assert(SPT <= 2 && JPT * NT <= NNZ, "output cells of the gather-sum machine: at most two species per thread, JVS sums inside Ghimj");
+  // Fun_x's sums land in the thread's own cells of XS: species t and, where a thread owns two (one wavefront per cell: NT = 64 < NVAR), t + NT.
+  // A thread whose second species does not exist parks that (empty) sum in the trash cell: the stride between a lane's outputs is per lane.
+  auto vdot_out = [&](int tt, uint32_t& addr, uint32_t& stride) {
+    constexpr uint32_t trash = 8u * (uint32_t)(NNZ + NVAR + 2);
+    addr = tt < NVAR ? 8u * (uint32_t)(NNZ + tt) : trash;
+    if constexpr (SPT == 1) stride = tt < NVAR ? 8u * (uint32_t)NT : 0u;
+    else stride = tt + NT < NVAR ? 8u * (uint32_t)NT : trash - addr;
+  };
   auto fun = [&](const double (&v)[SPT], double (&out)[SPT]) {
     if constexpr (!FFAC_RESIDENT) load_ffac();
     if constexpr (!RESIDENT) load_rct(true);
@@ -1218,8 +1226,9 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     {
       int tt = t;
       if constexpr (!RESIDENT) asm volatile("" : "+v"(tt));      // (derived here: kept across the step loop, the stride was one more register stored to scratch per step)
-      gsum_run<NT, MT::RING_LOW>(a.vdot, hdr.vdot_row0, hdr.vdot_rows, lane, tt < NVAR ? 8u * (uint32_t)(NNZ + tt) : 8u * (uint32_t)(NNZ + NVAR + 2),
-                                 tt < NVAR ? 8u * (uint32_t)NT : 0u);
+      uint32_t oa, os;
+      vdot_out(tt, oa, os);
+      gsum_run<NT, MT::RING_LOW>(a.vdot, hdr.vdot_row0, hdr.vdot_rows, lane, oa, os);
     }
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
@@ -1330,8 +1339,9 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     {
       int tt = t;
       if constexpr (!RESIDENT) asm volatile("" : "+v"(tt));
-      gsum_run<NT, MT::RING_LOW>(a.vdot, hdr.vdot_row0, hdr.vdot_rows, lane, tt < NVAR ? 8u * (uint32_t)(NNZ + tt) : 8u * (uint32_t)(NNZ + NVAR + 2),
-                                 tt < NVAR ? 8u * (uint32_t)NT : 0u);
+      uint32_t oa, os;
+      vdot_out(tt, oa, os);
+      gsum_run<NT, MT::RING_LOW>(a.vdot, hdr.vdot_row0, hdr.vdot_rows, lane, oa, os);
     }
     gsum_run<NT, MT::RING_LOW>(a.jvs, hdr.jvs_row0, hdr.jvs_rows, lane, 8u * (uint32_t)t, 8u * (uint32_t)NT);      // (other cells, another source array: no barrier between)
     lap(14);
@@ -1472,15 +1482,15 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   auto Hget = [&]() -> double {
     int wv = wave;
     asm volatile("" : "+v"(wv));
-    return wave_uniform(*(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + 16 + wv)));
+    return wave_uniform(*(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + L::RED_H + wv)));
   };
   auto Hset = [&](double v) {
     int wv = wave;
     asm volatile("" : "+v"(wv));
-    if (lane == 0) *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + 16 + wv)) = v;
+    if (lane == 0) *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + L::RED_H + wv)) = v;
   };
-  static_assert(NW <= 15, "red[]: partial sums | H per wave | Hexit");
-  if (t == 0) *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + 31)) = 0.0;
+  static_assert(NW <= L::RED_H && L::RED_H + NW <= L::RED_HEXIT, "red[]: partial sums | H per wave | Hexit");
+  if (t == 0) *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + L::RED_HEXIT)) = 0.0;
   {
     double H0 = fmin_f(fmin_f(hstart0, fabs(Tend - Tstart)), Hmax);
     if (fabs(H0) <= 10.0 * Roundoff) H0 = 1.0e-5;
@@ -1497,7 +1507,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     {
       const double H = Hget();
       if (((T + scalar_const(0.1) * H) == T) || (H <= Roundoff)) { ierr = -7; break; }
-      if (t == 0) *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + 31)) = H;
+      if (t == 0) *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + L::RED_HEXIT)) = H;
       Hset(fmin_f(H, fabs(Tend - T)));
     }
 
@@ -1540,8 +1550,12 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
             // untouched until their own turn, so the test sees the prepared value); ros_PrepareMatrix_x prints it (gas.f:1456).  Rare
             // path: Ghimj is still as prepared (no LU ran), every species' thread looks at its diagonal slot.
             if (a.sing_rows && nsng < 8) {
-              const uint32_t dp = t < NVAR ? (uint32_t)G_(a.diag_pos)[t] : (uint32_t)kPosNone;
-              if (dp != kPosNone && M[dp] == 0.0) atomicMin(&flags[1], t + 1);
+#pragma unroll
+              for (int q = 0; q < SPT; q++) {      // every species' thread looks at its diagonal slot(s)
+                const int sp = q * NT + t;
+                const uint32_t dp = sp < NVAR ? (uint32_t)G_(a.diag_pos)[sp] : (uint32_t)kPosNone;
+                if (dp != kPosNone && M[dp] == 0.0) atomicMin(&flags[1], sp + 1);
+              }
               lds_barrier();
               if (t == 0) GM_(a.sing_rows)[(size_t)cell * 8 + nsng] = flags[1];
             }
@@ -1569,7 +1583,8 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
             if constexpr (DUMP) {
               if (MT::DENSE_ND == 0) lds_barrier();      // (the dense tail's caller has just passed one)
               dump_matrix(NVAR + NNZ);      // the factors as the kernel keeps them; R(k) = 1/U(k,k) behind them
-              if (dumping && t < NVAR) dump[NVAR + 2 * NNZ + t] = M[NNZ + NVAR + 4 + t];
+              if (dumping)
+                for (int i = t; i < NVAR; i += NT) dump[NVAR + 2 * NNZ + i] = M[NNZ + NVAR + 4 + i];
             }
           }
         }
@@ -1670,7 +1685,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
     }
     if (a.texit_hexit) {
       GM_(a.texit_hexit)[(size_t)cell * 2] = T;
-      GM_(a.texit_hexit)[(size_t)cell * 2 + 1] = *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + 31));
+      GM_(a.texit_hexit)[(size_t)cell * 2 + 1] = *(volatile lds_f64*)(uintptr_t)(8u * (uint32_t)(L::RED + L::RED_HEXIT));
     }
     if (a.h_last) GM_(a.h_last)[cell] = Hget();
   }

@@ -15,8 +15,8 @@ namespace mistra {
 // Workgroup sizes and register budgets (waves per SIMD the compiler must leave room for) of the three instantiations; the
 // macros exist for same-box A/B builds (tools/build_variant.sh), the product library is built without them.
 #ifndef MISTRA_GAS_NT
-#define MISTRA_GAS_NT 128
-#endif
+#define MISTRA_GAS_NT 64             // ONE WAVEFRONT PER CELL (round 4): no workgroup barrier in the whole step loop, two species per lane; same box, 1e5 cells:
+#endif                               // 128 threads / 8 cells per CU 2.96 M, 64 threads 9 cells per CU 3.26 M (128 registers, 64 B scratch) / 3.45 M (168 registers, none)
 #ifndef MISTRA_AER_NT
 #define MISTRA_AER_NT 512
 #endif
@@ -24,7 +24,7 @@ namespace mistra {
 #define MISTRA_TOT_NT 512
 #endif
 #ifndef MISTRA_GAS_WPS
-#define MISTRA_GAS_WPS 4
+#define MISTRA_GAS_WPS 3             // 168 registers: LDS (16.0 KB per cell) admits 10 one-wave cells per CU, i.e. at most three waves per SIMD anyway
 #endif
 #ifndef MISTRA_AER_WPS
 #define MISTRA_AER_WPS 4
@@ -33,15 +33,18 @@ namespace mistra {
 #define MISTRA_TOT_VM_SLOTS 4        // (the kernels held to 128 registers have room for 4)
 #endif
 #ifndef MISTRA_RESIDENT_MAX_WPS      // kernels with more waves per SIMD than this fetch their static per-thread words where they are used (ros3_kernel.hip)
-#define MISTRA_RESIDENT_MAX_WPS 3
+#define MISTRA_RESIDENT_MAX_WPS 2
 #endif
 constexpr int kGasNT = MISTRA_GAS_NT, kAerNT = MISTRA_AER_NT, kTotNT = MISTRA_TOT_NT;
 
-struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 16, WAVES_PER_SIMD = MISTRA_GAS_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; static constexpr int VM_SLOTS = 4; };
+struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 10, WAVES_PER_SIMD = MISTRA_GAS_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; static constexpr int VM_SLOTS = 4; };
 struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2, MAX_TEMPS = 192, WAVES_PER_SIMD = MISTRA_AER_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; static constexpr int VM_SLOTS = 4; };
 struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2, MAX_TEMPS = 768, WAVES_PER_SIMD = 2, DENSE_ND = 64, DENSE_KB = 14; static constexpr bool RING_LOW = false, SCALE_PASS = true; static constexpr int VM_SLOTS = MISTRA_TOT_VM_SLOTS; };
 
 constexpr int round_up2(int x) { return (x + 1) & ~1; }
+// spare cells behind a product array (slots no reaction owns write there, one cell per lane of a wave — two lanes per cell in the one-wave
+// workgroups, whose LDS budget decides how many cells share a CU): schedule.cpp builds the tables with the same count
+constexpr int spare_cells(int nt) { return nt >= 128 ? 64 : 32; }
 constexpr int max_i(int a, int b) { return a > b ? a : b; }
 
 // offsets in doubles into the dynamic LDS block
@@ -55,7 +58,8 @@ struct LdsLayout {
   // the JVS sums land in: the step's first Fun and its Jac_SP then form their products in ONE phase and sum them back to back
   // (ros3_kernel.hip: fun_jac).  Where the area is too small for that (gas) B shares the array of A as before.
   static constexpr int JVS_CELLS = (MT::NJNZ + NT - 1) / NT * NT;
-  static constexpr bool MERGE_FUN_JAC = JVS_CELLS + round_up2(AB_TRASH + 64) <= MT::NNZ;
+  static constexpr int SPARE = spare_cells(NT);
+  static constexpr bool MERGE_FUN_JAC = JVS_CELLS + round_up2(AB_TRASH + SPARE) <= MT::NNZ;
   static constexpr int JB = MERGE_FUN_JAC ? M + JVS_CELLS : AB;                             // base of the B products
   // the A array: where B has an array of its own it holds the NREACT rate products and its spare cells (schedule.cpp: a_trash) — tot 8 KB,
   // aer 4.9 KB smaller than the shared array was (round 4)
@@ -63,9 +67,11 @@ struct LdsLayout {
   // ... and the kernels that are held to 128 registers (two aer cells per CU) keep the cell's RATE CONSTANTS in the room that frees: they
   // cannot hold them in registers and used to fetch them from global memory in front of every Fun / Jac_SP (~300 times per cell)
   static constexpr bool RCT_IN_LDS = MERGE_FUN_JAC && MT::WAVES_PER_SIMD > MISTRA_RESIDENT_MAX_WPS;
-  static constexpr int RCT = AB + round_up2(A_CELLS + 64);
+  static constexpr int RCT = AB + round_up2(A_CELLS + SPARE);
   static constexpr int RED = RCT + (RCT_IN_LDS ? round_up2(MT::NREACT) : 0);                            // (one shared cell: every such store of a wave hit the same address, and LDS serialises those)                             // per-wave partial sums
-  static constexpr int FLAGS = RED + 32;
+  // RED: per-wave partial sums of the error norm [RED_H) | the step size H, one cell per wave [RED_H, RED_HEXIT) | Hexit
+  static constexpr int RED_H = NT == 64 ? 1 : 16, RED_HEXIT = NT == 64 ? 2 : 31, RED_CELLS = NT == 64 ? 4 : 32;
+  static constexpr int FLAGS = RED + RED_CELLS;
   static constexpr int DINFO = FLAGS + 2;                                               // dense tail block: row table of the block's 64 rows, 16 bytes each (schedule.hpp: DenseTail)
   static constexpr int SCHUR = DINFO + (MT::DENSE_ND > 0 ? 64 * 2 : 0);                 // ... and the Schur steps' operand cells, uint16 x 8 x DENSE_KB x 64
   static constexpr int SCHUR_WORDS = MT::DENSE_ND > 0 ? 8 * MT::DENSE_KB * 64 / 2 : 0;   // in 32-bit words
@@ -74,7 +80,7 @@ struct LdsLayout {
   // two buffers of [64][4] panel columns + [64][4] panel rows, two 64-entry broadcast rows of the eliminating wave
   static constexpr int PANEL = AB;
   static constexpr int PANEL_CELLS = 2 * 2 * 64 * 4 + 2 * 64 + 4;      // (+ the panel's four pivot reciprocals)
-  static_assert(MT::DENSE_ND == 0 || PANEL_CELLS <= A_CELLS + 64, "panel buffers must fit the product array");
+  static_assert(MT::DENSE_ND == 0 || PANEL_CELLS <= A_CELLS + SPARE, "panel buffers must fit the product array");
   static_assert(TOTAL * 8 <= 160 * 1024, "cell state does not fit the 160 KiB LDS of a gfx950 CU");
   static_assert(NT % 64 == 0 && NT <= 1024 && NT / 64 <= 32, "workgroup size");
 };

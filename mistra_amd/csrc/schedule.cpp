@@ -792,9 +792,10 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   // where Jac_SP's B products have an array of their own (jb_base_bytes: inside the Ghimj area), the A array holds NREACT products and its
   // spare cells come right behind them (LdsLayout::A_CELLS)
   const uint64_t a_trash = jb_base_bytes ? (uint64_t)m.nreact : ab_trash;
+  const int spare = nt >= 128 ? 64 : 32;      // ros3_kernel.hpp: spare_cells
   S.a_trash = (int)a_trash;
   S.fun_fac.resize((size_t)S.rpt * nt);
-  for (size_t i = 0; i < S.fun_fac.size(); i++) S.fun_fac[i] = one | (one << 16) | (one << 32) | ((a_trash + (i % (size_t)nt) % 64) << 48);
+  for (size_t i = 0; i < S.fun_fac.size(); i++) S.fun_fac[i] = one | (one << 16) | (one << 32) | ((a_trash + (i % (size_t)nt) % (size_t)spare) << 48);
   for (int r = 0; r < m.nreact; r++) {
     uint64_t f[3] = {one, one, one};
     int nf = m.a_ptr[r + 1] - m.a_ptr[r];
@@ -814,7 +815,7 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
 
   // ---- Jac_SP_x products, under the owning reaction
   S.jac_fac.resize((size_t)S.rpt * 3 * nt);
-  for (size_t i = 0; i < S.jac_fac.size(); i++) S.jac_fac[i] = one | (one << 16) | (one << 32) | ((ab_trash + (i % (size_t)nt) % 64) << 48);
+  for (size_t i = 0; i < S.jac_fac.size(); i++) S.jac_fac[i] = one | (one << 16) | (one << 32) | ((ab_trash + (i % (size_t)nt) % (size_t)spare) << 48);
   {
     std::vector<int> used((size_t)m.nreact, 0);
     for (int b = 0; b < m.nb; b++) {

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p tools/diaglib
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math"
-T=/tmp/variant_$NAME; mkdir -p $T
+T=/tmp/variant_$NAME; rm -rf $T; mkdir -p $T
 for f in schedule.cpp mech_tables.cpp capi.cpp ros3_kernel.hip rates.hip pack.hip; do
   hipcc --offload-arch=gfx950 $FLAGS "$@" -c mistra_amd/csrc/$f -o $T/${f%.*}.o || exit 1
 done
