@@ -1400,9 +1400,14 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   auto tail = [&](auto swept_tag) {
     constexpr bool SWEPT = decltype(swept_tag)::value;
     constexpr uint32_t xs_tail = 8u * (NNZ + NVAR - 64 * MT::TAIL_REGS), r_tail = 8u * (NNZ + NVAR + 4 + NVAR - 64 * MT::TAIL_REGS);
-    if constexpr (MT::RING_LOW) {
+#ifndef MISTRA_LOW_BLOCK_TAIL      // 1: the kernels with the low ring placement whose tail is ONE register (gas) run the block form too
+#define MISTRA_LOW_BLOCK_TAIL 1
+#endif
+    if constexpr (MT::RING_LOW && !(MISTRA_LOW_BLOCK_TAIL && MT::TAIL_REGS == 1)) {
       static_assert(MT::DENSE_ND == 0, "the column form has no dense-block variant");
       tail_solve_columns<MT::TAIL_REGS, SWEPT ? MT::TAIL_REGS : 0, true>(a.tail, xs_tail, r_tail, lane);
+    } else if constexpr (MT::RING_LOW) {
+      tail_solve<MT::TAIL_REGS, SWEPT ? 4 * MT::TAIL_REGS : 0, true>(a.tail, xs_tail, r_tail, lane);
     } else {
       tail_solve<MT::TAIL_REGS, !SWEPT ? 0 : MT::DENSE_ND ? 4 * (MT::TAIL_REGS - 1) : 4 * MT::TAIL_REGS, false>(a.tail, xs_tail, r_tail, lane);
     }

@@ -460,3 +460,11 @@ extern "C" int emu_head_profile(void* h, int which, int* crit, int* total, int c
   }
   return P.nrounds;
 }
+
+// rows of each wave's gather-sum stream (which: 0 = Fun_x's sums, 1 = Jac_SP_x's); returns the number of waves
+extern "C" int emu_gsum_rows(void* h, int which, int* rows, int cap) {
+  Emu* e = (Emu*)h;
+  const GsumProgram& P = which ? e->s.jvs : e->s.vdot;
+  for (int w = 0; w < P.nw && w < cap; w++) rows[w] = P.rows[(size_t)w];
+  return P.nw;
+}
