@@ -1066,7 +1066,8 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
 #ifndef MISTRA_RCT_RESIDENT_SLOTS
 #define MISTRA_RCT_RESIDENT_SLOTS 0
 #endif
-  constexpr int RCT_KEEP = MT::WAVES_PER_SIMD <= MISTRA_RESIDENT_MAX_WPS ? RPT : (MISTRA_RCT_RESIDENT_SLOTS < RPT ? MISTRA_RCT_RESIDENT_SLOTS : RPT);
+  constexpr bool RCT_PER_USE = MT::WAVES_PER_SIMD > MISTRA_RESIDENT_MAX_WPS || L::RCT_IN_LDS;
+  constexpr int RCT_KEEP = !RCT_PER_USE ? RPT : (MISTRA_RCT_RESIDENT_SLOTS < RPT ? MISTRA_RCT_RESIDENT_SLOTS : RPT);
   auto load_rct = [&](bool opaque) {      // this thread's rate constants; opaque: the per-use fetch of the values that are not kept
     const double* rc = a.rconst;
     if (opaque) asm volatile("" : "+s"(rc));
@@ -1190,7 +1191,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
   };
   auto fun = [&](const double (&v)[SPT], double (&out)[SPT]) {
     if constexpr (!FFAC_RESIDENT) load_ffac();
-    if constexpr (!RESIDENT) load_rct(true);
+    if constexpr (RCT_PER_USE) load_rct(true);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
       const int s = q * NT + t;
@@ -1246,7 +1247,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       asm volatile("" : "+s"(jf));      // opaque: loads through it are not hoisted out of the step loop (and spilled there)
 #pragma unroll
       for (int q = 0; q < 3 * RPT; q++) jfac[q] = G_(jf)[q * NT + t];
-      if constexpr (!RESIDENT) load_rct(true);
+      if constexpr (RCT_PER_USE) load_rct(true);
     }
     lds_barrier();   // every lane is done reading AB as A
 #pragma unroll
@@ -1289,7 +1290,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
       for (int q = 0; q < 3 * RPT; q++) jfac[q] = G_(jf)[q * NT + t];
     }
     if constexpr (!FFAC_RESIDENT) load_ffac();
-    if constexpr (!RESIDENT) load_rct(true);
+    if constexpr (RCT_PER_USE) load_rct(true);
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
       const int s = q * NT + t;
@@ -1403,7 +1404,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
 #ifndef MISTRA_LOW_BLOCK_TAIL      // 1: the kernels with the low ring placement whose tail is ONE register (gas) run the block form too
 #define MISTRA_LOW_BLOCK_TAIL 1
 #endif
-    if constexpr (MT::RING_LOW && !(MISTRA_LOW_BLOCK_TAIL && MT::TAIL_REGS == 1)) {
+    if constexpr (MT::RING_LOW && !(MISTRA_LOW_BLOCK_TAIL && MT::TAIL_REGS <= MISTRA_LOW_BLOCK_TAIL)) {
       static_assert(MT::DENSE_ND == 0, "the column form has no dense-block variant");
       tail_solve_columns<MT::TAIL_REGS, SWEPT ? MT::TAIL_REGS : 0, true>(a.tail, xs_tail, r_tail, lane);
     } else if constexpr (MT::RING_LOW) {

@@ -18,8 +18,8 @@ namespace mistra {
 #define MISTRA_GAS_NT 64             // ONE WAVEFRONT PER CELL (round 4): no workgroup barrier in the whole step loop, two species per lane; same box, 1e5 cells:
 #endif                               // 128 threads / 8 cells per CU 2.96 M, 64 threads 9 cells per CU 3.26 M (128 registers, 64 B scratch) / 3.45 M (168 registers, none)
 #ifndef MISTRA_AER_NT
-#define MISTRA_AER_NT 512
-#endif
+#define MISTRA_AER_NT 256            // round 4: FOUR waves per cell with 256 registers (two species per lane, everything resident, the block-form tail chain), still two
+#endif                               // cells per CU: 54.0 k -> 60.4 k timesteps/s on the same box (eight waves per cell were held to 128 registers)
 #ifndef MISTRA_TOT_NT
 #define MISTRA_TOT_NT 512
 #endif
@@ -27,7 +27,19 @@ namespace mistra {
 #define MISTRA_GAS_WPS 3             // 168 registers: LDS (16.0 KB per cell) admits 10 one-wave cells per CU, i.e. at most three waves per SIMD anyway
 #endif
 #ifndef MISTRA_AER_WPS
-#define MISTRA_AER_WPS 4
+#define MISTRA_AER_WPS 2
+#endif
+#ifndef MISTRA_AER_RING_LOW          // 1: look-ahead ring in v64.. (kernels held to 128 registers), 0: in v192.. (256 registers: the block-form tail chain)
+#define MISTRA_AER_RING_LOW 0
+#endif
+#ifndef MISTRA_AER_SCALE_PASS        // whether the schedule compiler gives the factorisation's scaling its own pass at this workgroup size (schedule.cpp: >= 16 cells per thread)
+#define MISTRA_AER_SCALE_PASS 1
+#endif
+#ifndef MISTRA_TOT_DENSE             // 0: A/B builds without the dense tail block (the whole LU as an LDS-VM program; schedule.hpp: dense_config follows)
+#define MISTRA_TOT_DENSE 1
+#endif
+#ifndef MISTRA_TOT_WPS
+#define MISTRA_TOT_WPS 2
 #endif
 #ifndef MISTRA_TOT_VM_SLOTS          // ring depth of the LDS VM executor (table rows in flight per lane): 4, 6 or 8 slots of 8 registers from v48 up
 #define MISTRA_TOT_VM_SLOTS 4        // (the kernels held to 128 registers have room for 4)
@@ -37,9 +49,9 @@ namespace mistra {
 #endif
 constexpr int kGasNT = MISTRA_GAS_NT, kAerNT = MISTRA_AER_NT, kTotNT = MISTRA_TOT_NT;
 
-struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 10, WAVES_PER_SIMD = MISTRA_GAS_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; static constexpr int VM_SLOTS = 4; };
-struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2, MAX_TEMPS = 192, WAVES_PER_SIMD = MISTRA_AER_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false; static constexpr int VM_SLOTS = 4; };
-struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2, MAX_TEMPS = 768, WAVES_PER_SIMD = 2, DENSE_ND = 64, DENSE_KB = 14; static constexpr bool RING_LOW = false, SCALE_PASS = true; static constexpr int VM_SLOTS = MISTRA_TOT_VM_SLOTS; };
+struct GasTraits { static constexpr int NVAR = 102, NFIX = 3, NREACT = 331, NNZ = 1110, NB = 568, NCONST = 2, NJNZ = 945, TAIL_REGS = 1, MAX_TEMPS = 10, WAVES_PER_SIMD = MISTRA_GAS_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = true, SCALE_PASS = false, RCT_LDS = false; static constexpr int VM_SLOTS = 4; };
+struct AerTraits { static constexpr int NVAR = 257, NFIX = 5, NREACT = 979, NNZ = 6579, NB = 1598, NCONST = 2, NJNZ = 2831, TAIL_REGS = 2, MAX_TEMPS = 192, WAVES_PER_SIMD = MISTRA_AER_WPS, DENSE_ND = 0, DENSE_KB = 0; static constexpr bool RING_LOW = MISTRA_AER_RING_LOW, SCALE_PASS = MISTRA_AER_SCALE_PASS, RCT_LDS = true; static constexpr int VM_SLOTS = 4; };
+struct TotTraits { static constexpr int NVAR = 417, NFIX = 7, NREACT = 1627, NNZ = 13503, NB = 2628, NCONST = 2, NJNZ = 4709, TAIL_REGS = 2, MAX_TEMPS = 768, WAVES_PER_SIMD = MISTRA_TOT_WPS, DENSE_ND = MISTRA_TOT_DENSE ? 64 : 0, DENSE_KB = MISTRA_TOT_DENSE ? 14 : 0; static constexpr bool RING_LOW = false, SCALE_PASS = true, RCT_LDS = false; static constexpr int VM_SLOTS = MISTRA_TOT_VM_SLOTS; };
 
 constexpr int round_up2(int x) { return (x + 1) & ~1; }
 // spare cells behind a product array (slots no reaction owns write there, one cell per lane of a wave — two lanes per cell in the one-wave
@@ -64,9 +76,9 @@ struct LdsLayout {
   // the A array: where B has an array of its own it holds the NREACT rate products and its spare cells (schedule.cpp: a_trash) — tot 8 KB,
   // aer 4.9 KB smaller than the shared array was (round 4)
   static constexpr int A_CELLS = MERGE_FUN_JAC ? MT::NREACT : AB_TRASH;
-  // ... and the kernels that are held to 128 registers (two aer cells per CU) keep the cell's RATE CONSTANTS in the room that frees: they
-  // cannot hold them in registers and used to fetch them from global memory in front of every Fun / Jac_SP (~300 times per cell)
-  static constexpr bool RCT_IN_LDS = MERGE_FUN_JAC && MT::WAVES_PER_SIMD > MISTRA_RESIDENT_MAX_WPS;
+  // ... and aer (two cells per CU) keeps the cell's RATE CONSTANTS in the room that frees (traits: RCT_LDS) instead of fetching them from
+  // global memory in front of every Fun / Jac_SP (~300 times per cell, round 3) or giving them eight registers
+  static constexpr bool RCT_IN_LDS = MERGE_FUN_JAC && MT::RCT_LDS;
   static constexpr int RCT = AB + round_up2(A_CELLS + SPARE);
   static constexpr int RED = RCT + (RCT_IN_LDS ? round_up2(MT::NREACT) : 0);                            // (one shared cell: every such store of a wave hit the same address, and LDS serialises those)                             // per-wave partial sums
   // RED: per-wave partial sums of the error norm [RED_H) | the step size H, one cell per wave [RED_H, RED_HEXIT) | Hexit

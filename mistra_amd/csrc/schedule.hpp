@@ -200,7 +200,10 @@ struct DenseTail {
 
 // which mechanisms the product runs with the dense tail block (the kernel's traits, ros3_kernel.hpp, must agree)
 struct DenseConfig { int nd, kb; };
-inline DenseConfig dense_config(const MechTables& m) { return m.nvar == 417 ? DenseConfig{64, 14} : DenseConfig{0, 0}; }
+#ifndef MISTRA_TOT_DENSE
+#define MISTRA_TOT_DENSE 1
+#endif
+inline DenseConfig dense_config(const MechTables& m) { return m.nvar == 417 && MISTRA_TOT_DENSE ? DenseConfig{64, 14} : DenseConfig{0, 0}; }
 
 struct KernelSchedule {
   int nt = 0, nw = 0;

@@ -76,7 +76,7 @@ def first_step(chem, mech, var, fix, rconst, tin=0.0, tout=10.0):
 def test_phases_of_the_first_step(chem, emu, mech, golden, oracles):
     from mistra_amd.mechtab import load
     o, g, t = oracles[mech], golden[mech], load(mech)
-    nt = 64 if mech == "gas" else 512      # the workgroup sizes ros3_kernel.hpp instantiates (gas: one wavefront per cell)
+    nt = {"gas": 64, "aer": 256, "tot": 512}[mech]      # the workgroup sizes ros3_kernel.hpp instantiates (gas: one wavefront per cell)
     h_emu = emu.emu_create(os.path.join(REPO, "mistra_amd", "mech", mech + ".mech").encode(), nt)
     cells = [0, 7, len(g["var_in"]) - 1]
     V, F, K = g["var_in"][cells], g["fix"][cells], g["rconst"][cells]
