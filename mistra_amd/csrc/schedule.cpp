@@ -60,92 +60,164 @@ int lds_pass_cycles(const int* cell64) {
   return total;
 }
 
-// Deal the items of one round (sorted by decreasing record count) over lanes.  Lane LOADS follow the snake deal (pass p
-// gives every lane its p-th item, alternate passes run backwards); small sets are packed into few waves.  WHICH item of a
-// run of equally long items goes to which lane of the pass is chosen against LDS bank conflicts: the dense LU rounds are
-// bound by the LDS pipe, whose gathers cost ~4 array cycles per wave instruction when the 32 lanes of a pass are
-// thrown at the banks at random and 1 when they are spread.  Records of one pass sit in (nearly) the same rows of
-// their lanes, i.e. are issued together; an item goes to the half-wave in which its operand cells meet the fewest
-// distinct cells of their bank classes already placed there.
-std::vector<int> deal(const std::vector<Item>& items, const std::vector<VmEntry>& entries, int nt, int upr) {
+// Deal the items of one round (sorted by decreasing record count) over lanes.  row0: the items' first record rows within their lanes
+// (a lane walks its items in the order of their rows).
+//   * Rows: longest-first into lanes that still have room under the bound R = max(longest item, records / lanes) keeps every lane at
+//     or below R (until round 4 a snake deal — pass p gives every lane its p-th item — left the lanes that drew the long items of pass 0
+//     up to three rows above the rest: tot's LU program had 102 critical rows where 79 suffice).
+//   * Reciprocals: the record that publishes a pivot's reciprocal carries an IEEE division (~150 cycles of dependent work, paid by its
+//     whole wave) behind its row.  Those items go first, side by side into the LAST waves, whose lanes then take one row less than the
+//     others: the division runs while the other waves walk their last row.  (The snake deal hid it by accident — a post-pass moved
+//     the record into a wave that happened to be emptier; with level waves and the division on top of a full one the 23 rows saved
+//     bought nothing: measured.)
+//   * Banks: an 8-byte gather costs one LDS array cycle per half-wave when its 32 lanes are spread over the bank pairs and as many as the
+//     fullest bank pair holds DIFFERENT cells otherwise (equal cells are broadcast).  Lanes of one half-wave with the same load are
+//     interchangeable, so the choice is (half-wave, first row): the one where the item's operand cells raise those maxima least, then
+//     where they meet the fewest cells of their bank classes.
+// Small sets are packed into few waves.  Which lane walks an item changes no arithmetic: every entry keeps its update order.
+// (Tried on top, dropped: sweeps of pairwise swaps between half-waves of one-record items that share a row, accepted where the modelled
+// cycles of both half-waves' seven gathers drop — 1.7 % fewer modelled cycles for 1.6 s of start-up time per sweep.)
+std::vector<int> deal(const std::vector<Item>& items, const std::vector<VmEntry>& entries, int nt, int upr, std::vector<int>& row0) {
   const int n = (int)items.size();
   std::vector<int> lane((size_t)n);
-  static const bool plain_deal = diag_env("MISTRA_DIAG_PLAIN_DEAL") != nullptr;   // A/B diagnostic: positions as sorted
-  const int waves_used = std::max(1, std::min(nt / 64, (n + 63) / 64));
-  const int lanes = waves_used * 64, groups = lanes / 32;
+  row0.assign((size_t)n, 0);
+  static const bool plain_deal = diag_env("MISTRA_DIAG_PLAIN_DEAL") != nullptr;   // A/B diagnostic: the snake deal, positions as sorted
   auto nrec = [upr](const Item& it) { return std::max(1, (it.count + upr - 1) / upr); };
-  struct Slot { std::vector<uint16_t> cells; int cnt[32]; };
-  for (int p0 = 0; p0 < n; p0 += lanes) {                 // one pass
-    const int pn = std::min(lanes, n - p0), pass = p0 / lanes;
-    std::vector<int> pos_lane((size_t)pn);
-    for (int j = 0; j < pn; j++) pos_lane[(size_t)j] = (pass & 1) ? (lanes - 1 - j) : j;
-    const int rmax = nrec(items[(size_t)p0]);
-    std::vector<Slot> slot((size_t)groups * rmax * 7);      // [group][record][operand]: cells present, per bank class
-    for (Slot& sl : slot) std::fill(sl.cnt, sl.cnt + 32, 0);
-    auto operands = [&](const Item& it, int r, int* cell /*7*/) {
-      const VmEntry& E = entries[(size_t)it.entry];
-      cell[0] = E.tgt;
-      const int per = upr == 2 ? 3 : 2;      // operand cells per update: (a, r, u), or (a, u) in records of three updates
-      for (int u = 0; u < upr; u++) {
-        const int i = r * upr + u;
-        if (i < it.count) {
-          const VmUpd& up = E.upd[(size_t)(it.first + i)];
-          cell[1 + per * u] = up.a;
-          if (upr == 2) { cell[2 + 3 * u] = up.r; cell[3 + 3 * u] = up.u; }
-          else cell[2 + 2 * u] = up.u;
-        } else {
-          for (int o = 0; o < per; o++) cell[1 + per * u + o] = -1;      // the 0.0 cell in every lane: broadcast
-        }
-      }
-    };
-    for (int j0 = 0; j0 < pn;) {                          // one run of equally long items
-      int j1 = j0;
-      while (j1 < pn && nrec(items[(size_t)(p0 + j1)]) == nrec(items[(size_t)(p0 + j0)])) j1++;
-      const int nr = nrec(items[(size_t)(p0 + j0)]);
-      std::vector<std::vector<int>> free_lanes((size_t)groups);      // lanes of this run, by half-wave
-      for (int j = j0; j < j1; j++) free_lanes[(size_t)(pos_lane[(size_t)j] / 32)].push_back(pos_lane[(size_t)j]);
-      for (int j = j0; j < j1; j++) {
-        const Item& it = items[(size_t)(p0 + j)];
-        int best = -1, best_cost = 0;
-        for (int g = 0; g < groups; g++) {
-          if (free_lanes[(size_t)g].empty()) continue;
-          int cost = 0;
-          for (int r = 0; r < nr; r++) {
-            int cell[7];
-            operands(it, r, cell);
-            for (int o = 0; o < 7; o++) {
-              if (cell[o] < 0) continue;
-              const Slot& sl = slot[((size_t)g * rmax + r) * 7 + o];
-              if (std::find(sl.cells.begin(), sl.cells.end(), (uint16_t)cell[o]) != sl.cells.end()) continue;   // broadcast
-              cost += (o == 0 ? 2 : 1) * sl.cnt[bank_class(cell[o])];      // the target is read and written
-            }
-          }
-          if (best < 0 || cost < best_cost) { best = g; best_cost = cost; }
-        }
-        if (plain_deal) best = pos_lane[(size_t)j] / 32;
-        if (plain_deal) {
-          std::vector<int>& fl = free_lanes[(size_t)best];
-          fl.erase(std::find(fl.begin(), fl.end(), pos_lane[(size_t)j]));
-          lane[(size_t)(p0 + j)] = pos_lane[(size_t)j];
-        } else {
-          lane[(size_t)(p0 + j)] = free_lanes[(size_t)best].back();
-          free_lanes[(size_t)best].pop_back();
-        }
-        for (int r = 0; r < nr; r++) {
-          int cell[7];
-          operands(it, r, cell);
-          for (int o = 0; o < 7; o++) {
-            if (cell[o] < 0) continue;
-            Slot& sl = slot[((size_t)best * rmax + r) * 7 + o];
-            if (std::find(sl.cells.begin(), sl.cells.end(), (uint16_t)cell[o]) != sl.cells.end()) continue;
-            sl.cells.push_back((uint16_t)cell[o]);
-            sl.cnt[bank_class(cell[o])]++;
-          }
-        }
-      }
-      j0 = j1;
+  auto publishes = [&](const Item& it) { return it.final && entries[(size_t)it.entry].rcp >= 0; };
+  long total = 0;
+  int n_rcp = 0, longest = 1;
+  for (const Item& it : items) { total += nrec(it); n_rcp += publishes(it); longest = std::max(longest, nrec(it)); }
+  // How many waves take part: W waves of R = max(longest item, records / 64 W) rows; the W with the smaller  max(c_lds W R, c_row R),
+  // then the fewer rows, then the shorter round.  c_lds = 0 (as shipped): the fewest waves that reach the smallest R.
+  static const int c_lds = diag_env("MISTRA_DIAG_DEAL_CLDS") ? std::atoi(diag_env("MISTRA_DIAG_DEAL_CLDS")) : 0;
+  static const int c_row = diag_env("MISTRA_DIAG_DEAL_CROW") ? std::atoi(diag_env("MISTRA_DIAG_DEAL_CROW")) : 200;
+  static const bool rcp_slack = diag_env("MISTRA_DIAG_NO_RCP_SLACK") == nullptr;
+  const int rcp_waves = rcp_slack ? (n_rcp + 63) / 64 : 0;
+  int waves_used = 1;
+  {
+    long best_t = -1, best_rows = 0;
+    for (int w = 1; w <= nt / 64 && !plain_deal; w++) {
+      const long r = std::max<long>(longest, (total + 64L * std::min(rcp_waves, w) + 64L * w - 1) / (64L * w));
+      const long t = std::max<long>((long)c_lds * w * r, (long)c_row * r);
+      if (best_t < 0 || t < best_t || (t == best_t && w * r <= best_rows)) { best_t = t; best_rows = w * r; waves_used = w; }
     }
+    if (plain_deal) waves_used = std::max(1, std::min(nt / 64, (n + 63) / 64));
   }
+  const int lanes = waves_used * 64, groups = lanes / 32;
+  if (plain_deal) {
+    for (int k = 0; k < n; k++) {
+      const int pass = k / lanes, j = k % lanes;
+      lane[(size_t)k] = (pass & 1) ? (lanes - 1 - j) : j;
+    }
+    std::vector<int> ld((size_t)lanes, 0);
+    for (int k = 0; k < n; k++) { row0[(size_t)k] = ld[(size_t)lane[(size_t)k]]; ld[(size_t)lane[(size_t)k]] += nrec(items[(size_t)k]); }
+    return lane;
+  }
+  const int rw = std::min(rcp_waves, waves_used);      // the last rw waves take the publishing items and one row less
+  int R = std::max<int>(longest, (int)((total + 64L * rw + lanes - 1) / lanes));
+  auto cap = [&](int l) { return (l / 64 >= waves_used - rw && R > 1) ? R - 1 : R; };
+  struct Slot { uint16_t cells[32]; uint8_t cnt[32]; uint8_t n, worst; };      // one gather of one half-wave: distinct cells, per bank class
+  std::vector<Slot> slot;                                                     // [group][row][operand]
+  int rows_cap = 0;
+  auto grow = [&](int rows) {
+    if (rows <= rows_cap) return;
+    std::vector<Slot> s2((size_t)groups * rows * 7);
+    for (Slot& sl : s2) { std::fill(sl.cnt, sl.cnt + 32, 0); sl.n = 0; sl.worst = 0; }
+    for (int g = 0; g < groups; g++)
+      for (int r = 0; r < rows_cap; r++)
+        for (int o = 0; o < 7; o++) s2[((size_t)g * rows + r) * 7 + o] = slot[((size_t)g * rows_cap + r) * 7 + o];
+    slot.swap(s2);
+    rows_cap = rows;
+  };
+  grow(R + 2);
+  auto operands = [&](const Item& it, int r, int* cell /*7*/) {
+    const VmEntry& E = entries[(size_t)it.entry];
+    cell[0] = E.tgt;
+    const int per = upr == 2 ? 3 : 2;      // operand cells per update: (a, r, u), or (a, u) in records of three updates
+    for (int u = 0; u < upr; u++) {
+      const int i = r * upr + u;
+      if (i < it.count) {
+        const VmUpd& up = E.upd[(size_t)(it.first + i)];
+        cell[1 + per * u] = up.a;
+        if (upr == 2) { cell[2 + 3 * u] = up.r; cell[3 + 3 * u] = up.u; }
+        else cell[2 + 2 * u] = up.u;
+      } else {
+        for (int o = 0; o < per; o++) cell[1 + per * u + o] = -1;      // the 0.0 cell in every lane: broadcast
+      }
+    }
+  };
+  auto present = [](const Slot& sl, int c) {
+    for (int k = 0; k < sl.n; k++)
+      if (sl.cells[k] == (uint16_t)c) return true;
+    return false;
+  };
+  std::vector<int> load((size_t)lanes, 0);
+  std::vector<int> cells((size_t)16 * 7);
+  // place item k into one of the half-waves [g_lo, g_hi)
+  auto place = [&](int k, int g_lo, int g_hi) {
+    const Item& it = items[(size_t)k];
+    const int nr = nrec(it);
+    if ((int)cells.size() < nr * 7) cells.resize((size_t)nr * 7);
+    for (int r = 0; r < nr; r++) operands(it, r, &cells[(size_t)r * 7]);
+    int best_lane = -1;
+    long best_hard = 0, best_soft = 0;
+    for (int pass = 0; pass < 2 && best_lane < 0; pass++) {      // second pass (nothing fits under the bound): the bound gives way
+      for (int g = g_lo; g < g_hi; g++) {
+        // candidates: one lane per distinct load of the half-wave (a one-record item fits wherever a row is free; longer ones go to
+        // the emptiest lane only, so that the lanes do not fragment under the bound)
+        uint64_t tried = 0;
+        int lmin = g * 32;
+        for (int q = 1; q < 32; q++)
+          if (load[(size_t)(g * 32 + q)] < load[(size_t)lmin]) lmin = g * 32 + q;
+        for (int q = 0; q < 32; q++) {
+          const int l = (nr == 1 && pass == 0) ? g * 32 + q : lmin;
+          const int r0 = load[(size_t)l];
+          if (r0 < 64 && ((tried >> r0) & 1)) continue;
+          if (r0 < 64) tried |= 1ull << r0;
+          if (pass == 0 && r0 + nr > cap(l)) continue;
+          grow(r0 + nr);
+          long hard = 0, soft = 0;
+          for (int r = 0; r < nr; r++)
+            for (int o = 0; o < 7; o++) {
+              const int c = cells[(size_t)r * 7 + o];
+              if (c < 0) continue;
+              const Slot& sl = slot[((size_t)g * rows_cap + r0 + r) * 7 + o];
+              if (present(sl, c)) continue;                                   // broadcast
+              const int w = o == 0 ? 2 : 1;                                   // the target is read and written
+              const int cnt = sl.cnt[bank_class(c)];
+              if (cnt + 1 > std::max<int>(sl.worst, 1)) hard += w;
+              soft += w * cnt;
+            }
+          // (a later first row is a fuller lane: among equals the emptier one, which keeps the waves' row counts level)
+          if (best_lane < 0 || hard < best_hard || (hard == best_hard && (soft < best_soft || (soft == best_soft && r0 < load[(size_t)best_lane])))) {
+            best_lane = l; best_hard = hard; best_soft = soft;
+          }
+          if (!(nr == 1 && pass == 0)) break;
+        }
+      }
+    }
+    const int g = best_lane / 32, r0 = load[(size_t)best_lane];
+    lane[(size_t)k] = best_lane;
+    row0[(size_t)k] = r0;
+    load[(size_t)best_lane] += nr;
+    if (r0 + nr > cap(best_lane)) R = std::max(R + (cap(best_lane) < R ? 1 : 0), r0 + nr);      // (the bound gave way)
+    for (int r = 0; r < nr; r++)
+      for (int o = 0; o < 7; o++) {
+        const int c = cells[(size_t)r * 7 + o];
+        if (c < 0) continue;
+        Slot& sl = slot[((size_t)g * rows_cap + r0 + r) * 7 + o];
+        if (present(sl, c)) continue;
+        if (sl.n < 32) sl.cells[sl.n++] = (uint16_t)c;
+        const int b = bank_class(c);
+        sl.cnt[b]++;
+        sl.worst = std::max(sl.worst, sl.cnt[b]);
+      }
+  };
+  if (rw > 0)
+    for (int k = 0; k < n; k++)
+      if (publishes(items[(size_t)k])) place(k, groups - 2 * rw, groups);
+  for (int k = 0; k < n; k++)
+    if (!(rw > 0 && publishes(items[(size_t)k]))) place(k, 0, groups);
   return lane;
 }
 
@@ -277,6 +349,8 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
   std::vector<std::vector<uint32_t>> stream((size_t)P.nw);
   const uint32_t zoff = vm_off(zero_slot, 0);
   const uint32_t one_off = vm_off(lay.one(), 0), trash_off = vm_off(lay.trash(), 0);
+  // (Measured in round 4: giving every idle lane a store target of its own instead of the one trash cell changes nothing — 25 49x
+  //  timesteps/s either way on one box; stores of many lanes to one address do not cost the VM what a bank conflict would.)
   auto idle_record = [&](std::vector<uint32_t>& out, uint32_t row_flags) {
     out.push_back(trash_off);
     out.push_back(one_off | row_flags);
@@ -287,13 +361,14 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
     std::vector<Item>& items = kv.second;
     auto nrec = [upr](const Item& it) { return std::max(1, (it.count + upr - 1) / upr); };
     std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return nrec(a) > nrec(b); });
-    std::vector<int> lane = deal(items, entries, nt, upr);
+    std::vector<int> row0;      // first record row of every item within its lane
+    std::vector<int> lane = deal(items, entries, nt, upr, row0);
     // The record that publishes a pivot's reciprocal carries an IEEE division (~150 cycles of dependent work) on top of its
     // row; every other wave then waits for it at the barrier.  Where the waves of a round do not all have the same number
     // of rows, that record goes to a wave with fewer: it swaps lanes with an equally long item there (no lane's row count
     // changes), and the division runs while the fuller waves walk their extra row.
     {
-      static const bool no_rcp_move = diag_env("MISTRA_DIAG_NO_RCP_MOVE") != nullptr;     // A/B diagnostic
+      static const bool no_rcp_move = diag_env("MISTRA_DIAG_PLAIN_DEAL") == nullptr || diag_env("MISTRA_DIAG_NO_RCP_MOVE") != nullptr;     // (the deal places these items itself; the move belongs to the snake deal kept for A/B runs)
       std::vector<int> lane_rows((size_t)nt, 0);
       for (size_t k = 0; k < items.size(); k++) lane_rows[(size_t)lane[k]] += nrec(items[k]);
       const int nw = nt / 64;
@@ -310,12 +385,17 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
         for (size_t j = 0; j < items.size(); j++)            // an equally long item in the emptier wave that publishes nothing
           if (lane[j] / 64 == w_to && nrec(items[j]) == nrec(it) && !(items[j].final && entries[(size_t)items[j].entry].rcp >= 0)) {
             std::swap(lane[k], lane[j]);
+            std::swap(row0[k], row0[j]);
             break;
           }
       }
     }
     std::vector<std::vector<uint32_t>> prog((size_t)nt);     // VM_REC_WORDS words per record
-    for (size_t k = 0; k < items.size(); k++) {
+    std::vector<size_t> by_row(items.size());                // a lane walks its items in the order of their first rows
+    std::iota(by_row.begin(), by_row.end(), (size_t)0);
+    std::stable_sort(by_row.begin(), by_row.end(), [&](size_t x, size_t y) { return row0[x] < row0[y]; });
+    for (size_t kk = 0; kk < items.size(); kk++) {
+      const size_t k = by_row[kk];
       const Item& it = items[k];
       const VmEntry& E = entries[(size_t)it.entry];
       std::vector<uint32_t>& w = prog[(size_t)lane[k]];
