@@ -231,17 +231,26 @@ int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const
  * The tables (mistra_amd/mech/<mech>.liq) are cut out of the reference source by tools/extract_liq.py; products are formed in the
  * reference's order, exp is the device library's (last-place differences against the host libm). */
 int mistra_chem_henry_device(int mech, int nlayer, const double* d_tt, double* d_henry, void* hip_stream);
+/* v_mean_a (tt,nmaxf) (kpp.f90:1472-1670) | v_mean_t (kpp.f90:1268-1465), which liq_parm calls every time step (kpp.f90:612, 632): the mean
+ * molecular speeds vmean(:,k) = sqrt(tt(k)/M)*4.60138 of the species the routine lists, 0 for the others, for nlayer layers at once.
+ *   d_tt [nlayer]             tt(k)
+ *   d_vmean [nlayer][NSPEC]   vmean(:,k) of /kpp_2aer/ | /kpp_2tot/, written whole (NSPEC = NVAR + NFIX).  The reference zeroes the layers above
+ *                             nmaxf as well (`vmean(:,:) = 0._dp`): a caller that replaces the routine does that once, they never change.
+ * Table: mistra_amd/mech/<mech>.vmean, cut out of the reference source by tools/extract_vmean.py.  Quotient, square root and product round
+ * once each as in the compiled reference: bit-identical (tests/test_gpu_liq.py). */
+int mistra_chem_v_mean_device(int mech, int nlayer, const double* d_tt, double* d_vmean, void* hip_stream);
 int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const double* d_tt, const double* d_conv2, const double* d_xgamma,
                                 double* d_xkef, double* d_xkeb, void* hip_stream);
 
-/* The three liq_parm kernels above on HOST buffers (same layouts, layer-major as the model holds them: every array of the reference has the
+/* The liq_parm kernels above on HOST buffers (same layouts, layer-major as the model holds them: every array of the reference has the
  * layer as its last dimension, so a run of layers kmin..kmax is handed over in place — ff(1,1,kmin), xkmt(1,1,kmin) ...): what the Fortran
- * shim calls (shim/mistra_kpp_liq.f90: FAST_K_MT_BATCH, HENRY_BATCH, EQUIL_CO_BATCH; drop-ins with the reference's own signatures in
+ * shim calls (shim/mistra_kpp_liq.f90: FAST_K_MT_BATCH, HENRY_BATCH, V_MEAN_BATCH, EQUIL_CO_BATCH; drop-ins with the reference's own signatures in
  * shim/mistra_kpp_model.f90).  Synchronous; primary device. */
 int mistra_chem_fast_k_mt(int mech, int nlayer, const double* ff, const double* rq, const int32_t* kw, int nkw, int ka, int ifeed, int nkc_l,
                           const double* cw, const double* cm, const double* freep, const double* alpha, const double* vmean, double* xkmt,
                           const double* t, const double* p, double* vt);
 int mistra_chem_henry(int mech, int nlayer, const double* tt, double* henry);
+int mistra_chem_v_mean(int mech, int nlayer, const double* tt, double* vmean);
 int mistra_chem_equil_co(int mech, int nlayer, int nkc, int j6, const double* tt, const double* conv2, const double* xgamma, double* xkef,
                          double* xkeb);
 

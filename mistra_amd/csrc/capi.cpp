@@ -176,6 +176,31 @@ bool mistra::LiqTable::load(const std::string& path, std::string* err) {
   return ok;
 }
 
+bool mistra::VmeanTable::load(const std::string& path, std::string* err) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) { if (err) *err = "cannot open " + path; return false; }
+  int32_t h[8];
+  bool ok = std::fread(h, sizeof h, 1, f) == 1 && h[0] == 0x544E4D56 && h[1] == 1 && h[2] > 0 && h[2] <= 4096 && h[3] >= 0 && h[3] <= h[2] &&
+            std::fread(&coef, sizeof coef, 1, f) == 1 && coef > 0.0;
+  std::vector<int32_t> j;
+  std::vector<double> m;
+  if (ok) {
+    nspec = h[2];
+    j.resize((size_t)h[3]); m.resize((size_t)h[3]);
+    ok = (h[3] == 0 || std::fread(j.data(), 4, j.size(), f) == j.size()) && (h[3] == 0 || std::fread(m.data(), 8, m.size(), f) == m.size());
+  }
+  std::fclose(f);
+  if (ok) {      // dense per-species form; every index is checked here
+    mass.assign((size_t)nspec, 0.0);
+    for (size_t i = 0; ok && i < j.size(); i++) {
+      ok = j[i] >= 1 && j[i] <= nspec && m[i] > 0.0;
+      if (ok) mass[(size_t)j[i] - 1] = m[i];
+    }
+  }
+  if (!ok && err) *err = path + ": not a table of molar masses of v_mean";
+  return ok;
+}
+
 namespace {
 
 struct VmBufs {
@@ -247,6 +272,10 @@ struct MechState {
   LiqTable liq_tab;
   DevBuf<int32_t> lq_hkind, lq_eof, lq_foff, lq_boff, lq_fkind, lq_farg;
   DevBuf<double> lq_ha0, lq_hb0, lq_fa, lq_fb;
+  // v_mean_x (aer, tot)
+  bool vmean_ready = false;
+  VmeanTable vmean_tab;
+  DevBuf<double> vm_mass;
   // staging for the host-buffer entry point (grow-only)
   DevBuf<double> s_var, s_fix, s_rct, s_out, s_th;
   DevBuf<int32_t> s_ierr, s_stats, s_sing;
@@ -269,6 +298,7 @@ struct MechState {
     kmt_lex.release(); kmt_ready = false;
     lq_hkind.release(); lq_eof.release(); lq_foff.release(); lq_boff.release(); lq_fkind.release(); lq_farg.release(); lq_ha0.release(); lq_hb0.release();
     lq_fa.release(); lq_fb.release(); liq_ready = false;
+    vm_mass.release(); vmean_ready = false;
     dense_rows.release(); schur_cells.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); rates_fslot.release(); s_env.release(); rates_ready = false;
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release(); s_sing.release();
     sing_count = 0; sing_one = false;
@@ -422,6 +452,15 @@ int setup_mech(DeviceState& D, int mech) {
       HIP_TRY(S.lq_fkind.upload(T.fkind)); HIP_TRY(S.lq_farg.upload(T.farg)); HIP_TRY(S.lq_ha0.upload(T.h_a0)); HIP_TRY(S.lq_hb0.upload(T.h_b0));
       HIP_TRY(S.lq_fa.upload(T.fa)); HIP_TRY(S.lq_fb.upload(T.fb));
       S.liq_ready = true;
+    }
+  }
+  {   // mean molecular speeds (aer, tot)
+    std::string verr;
+    VmeanTable& T = S.vmean_tab;
+    if (T.load(mech_dir() + "/" + kMechName[mech] + ".vmean", &verr)) {
+      if (T.nspec != S.tab.nvar + S.tab.nfix) return fail(std::string(kMechName[mech]) + ".vmean does not belong to this mechanism");
+      HIP_TRY(S.vm_mass.upload(T.mass));
+      S.vmean_ready = true;
     }
   }
   S.lu_scale_slots = K.lu_scale.nslots;
@@ -980,6 +1019,22 @@ int mistra_chem_henry_device(int mech, int nlayer, const double* d_tt, double* d
   return 0;
 }
 
+int mistra_chem_v_mean_device(int mech, int nlayer, const double* d_tt, double* d_vmean, void* hip_stream) {
+  if (int rc = check_call(mech, 1)) return rc;
+  if (nlayer == 0) return 0;
+  if (nlayer < 0) return fail("nlayer < 0");
+  if (!d_tt || !d_vmean) return fail("null pointer");
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, d_vmean) != hipSuccess) return fail("the output is not a device pointer");
+  DeviceState* D = device_slot(attr.device);
+  if (!D) return fail("the buffers live on a device mistra_chem_init(_devices) did not set up");
+  const MechState& S = D->mech[mech];
+  if (!S.vmean_ready) return fail(std::string("the ") + kMechName[mech] + " mechanism has no v_mean routine (v_mean_a: aer, v_mean_t: tot)");
+  HIP_TRY(hipSetDevice(D->id));
+  LAUNCH_TRY(launch_v_mean(S.vm_mass.p, S.vmean_tab.nspec, S.vmean_tab.coef, nlayer, d_tt, d_vmean, static_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
 int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const double* d_tt, const double* d_conv2, const double* d_xgamma,
                                 double* d_xkef, double* d_xkeb, void* hip_stream) {
   if (int rc = check_call(mech, 1)) return rc;
@@ -1065,6 +1120,27 @@ int mistra_chem_henry(int mech, int nlayer, const double* tt, double* henry) {
   if (int rc = mistra_chem_henry_device(mech, nlayer, B.dptr(i_t), B.dptr(i_h), nullptr)) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(B.down(i_h, henry));
+  return 0;
+}
+
+int mistra_chem_v_mean(int mech, int nlayer, const double* tt, double* vmean) {
+  if (int rc = lazy_init()) return rc;
+  if (int rc = check_call(mech, nlayer)) return rc;
+  if (nlayer == 0) return 0;
+  if (!tt || !vmean) return fail("null pointer");
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  const MechState& S = D.mech[mech];
+  if (!S.vmean_ready) return fail(std::string("the ") + kMechName[mech] + " mechanism has no v_mean routine (v_mean_a: aer, v_mean_t: tot)");
+  HIP_TRY(hipSetDevice(D.id));
+  const size_t nl = (size_t)nlayer, nspec = (size_t)S.vmean_tab.nspec;
+  DevBlock B;
+  const size_t i_t = B.add(nl * sizeof(double)), i_v = B.add(nl * nspec * sizeof(double));
+  HIP_TRY(B.alloc());
+  HIP_TRY(B.up(i_t, tt));
+  if (int rc = mistra_chem_v_mean_device(mech, nlayer, B.dptr(i_t), B.dptr(i_v), nullptr)) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.down(i_v, vmean));
   return 0;
 }
 

@@ -256,6 +256,24 @@ __global__ __launch_bounds__(256) void equil_co_kernel(const LiqDev L, int nlaye
   xkeb[at] = liq_product(L, L.boff[e], L.foff[e + 1], T, cv2, xg);
 }
 
+// v_mean_a | v_mean_t (kpp.f90:1472-1670 | 1268-1465): the mean molecular speed sqrt(8 R T / (pi M)) as the reference writes it,
+// func(a,k) = sqrt(tt(k)/a)*4.60138 (the factor a default-real literal), one thread per (layer, species); a species the routine does not
+// set stays 0 (`vmean(:,:) = 0._dp`).  Quotient, square root and product each round once, as compiled Fortran does: bit-identical.
+__global__ __launch_bounds__(256) void v_mean_kernel(const double* __restrict__ mass, int nspec, double coef, int nlayer,
+                                                      const double* __restrict__ tt, double* __restrict__ vmean) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (j >= nspec || k >= nlayer) return;
+  const double a = mass[j];
+  double v = 0.0;
+  if (a != 0.0) v = sqrt(tt[k] / a) * coef;
+  vmean[(size_t)k * nspec + j] = v;
+}
+hipError_t launch_v_mean(const double* mass, int nspec, double coef, int nlayer, const double* tt, double* vmean, hipStream_t stream) {
+  if (nlayer <= 0) return hipSuccess;
+  hipLaunchKernelGGL(v_mean_kernel, dim3((unsigned)((nspec + 255) / 256), (unsigned)nlayer), dim3(256), 0, stream, mass, nspec, coef, nlayer, tt, vmean);
+  return hipGetLastError();
+}
+
 hipError_t launch_henry(const LiqDev& L, int nlayer, const double* tt, double* henry, hipStream_t stream) {
   if (nlayer <= 0) return hipSuccess;
   hipLaunchKernelGGL(henry_kernel, dim3((unsigned)((L.nspec + 255) / 256), (unsigned)nlayer), dim3(256), 0, stream, L, nlayer, tt, henry);

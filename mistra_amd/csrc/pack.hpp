@@ -81,6 +81,14 @@ struct LiqDev {
   double henry_tref, henry_fct, equil_tref;
 };
 hipError_t launch_henry(const LiqDev& L, int nlayer, const double* tt, double* henry, hipStream_t stream);
+// ---- mean molecular speeds (kpp.f90: v_mean_a 1472-1670, v_mean_t 1268-1465).  Table: mistra_amd/mech/<mech>.vmean (tools/extract_vmean.py).
+struct VmeanTable {
+  int nspec = 0;
+  double coef = 0;
+  std::vector<double> mass;      // [nspec]: molar mass in kg/mol of the species the routine sets, 0 = not set (vmean stays 0)
+  bool load(const std::string& path, std::string* err);
+};
+hipError_t launch_v_mean(const double* mass, int nspec, double coef, int nlayer, const double* tt, double* vmean, hipStream_t stream);
 hipError_t launch_equil_co(const LiqDev& L, int nlayer, int nkc, int j6, const double* tt, const double* conv2, const double* xgamma, double* xkef,
                            double* xkeb, hipStream_t stream);
 }  // namespace mistra

@@ -1,21 +1,22 @@
-! TEST INFRASTRUCTURE — fixture capture of henry_a / henry_t / equil_co_a / equil_co_t calls of the running reference model
+! TEST INFRASTRUCTURE — fixture capture of henry_a / henry_t / equil_co_a / equil_co_t / v_mean_a / v_mean_t calls of the running reference model
 ! (oracle/build_ref.sh `model`), for those liq_parm kernels on the device (SURVEY.md §8 f3).
 !
-! Linked with -Wl,--wrap=henry_a_ ... equil_co_t_: liq_parm's calls (kpp.f90:614,616,634,636) land here.  For the calls selected by
+! Linked with -Wl,--wrap=henry_a_ ... equil_co_t_, v_mean_a_, v_mean_t_: liq_parm's calls (kpp.f90:612-616, 632-636) land here.  For the calls selected by
 ! MISTRA_CAPTURE_LIQ_SKIP / _EVERY / _MAX (counted per routine) and, inside them, up to MISTRA_CAPTURE_LIQ_LAYERS layers spread over
 ! the column, it records what the routine READS for that layer and what it leaves behind, into MISTRA_CAPTURE_LIQ_FILE:
 !   henry_x     tt(k)                                      -> henry(:,k)
+!   v_mean_x    tt(k)                                      -> vmean(:,k)
 !   equil_co_x  tt(k), conv2(:,k), xgamma(:,:,k)           -> xkef(:,:,k), xkeb(:,:,k), both also BEFORE the call (entries of species the
 !                                                             routine does not set keep what they held)
 ! No reference source is modified.
-! record: int32 {magic 'LIQC', routine (1 henry_a | 2 henry_t | 3 equil_co_a | 4 equil_co_t), k, nspec, nkc, j6}, then doubles
-!         routines 1, 2:  tt, henry(nspec)
+! record: int32 {magic 'LIQC', routine (1 henry_a | 2 henry_t | 3 equil_co_a | 4 equil_co_t | 5 v_mean_a | 6 v_mean_t), k, nspec, nkc, j6}, then doubles
+!         routines 1, 2:  tt, henry(nspec)            routines 5, 6:  tt, vmean(nspec)
 !         routines 3, 4:  tt, conv2(nkc), xgamma(j6,nkc), xkef_before(nspec,nkc), xkeb_before(nspec,nkc), xkef(nspec,nkc), xkeb(nspec,nkc)
 module capture_liq_state
   implicit none
   integer :: unit_out = 0, nlayers = 6
   logical :: inited = .false., opened = .false.
-  integer :: ncall(4) = 0, nrec(4) = 0, nskip = 0, nevery = 1, nmax = 2
+  integer :: ncall(6) = 0, nrec(6) = 0, nskip = 0, nevery = 1, nmax = 2
 contains
   subroutine init()
     character(len=512) :: buf
@@ -193,3 +194,59 @@ subroutine wrap_equil_co_t(tt, nmaxf) bind(C, name="__wrap_equil_co_t_")
      write (unit_out) tt(k), conv2(:, k), xgamma(:, :, k), bf(:, :, i), bb(:, :, i), xkef(:, :, k), xkeb(:, :, k)
   end do
 end subroutine wrap_equil_co_t
+
+subroutine wrap_v_mean_a(tt, nmaxf) bind(C, name="__wrap_v_mean_a_")
+  use capture_liq_state
+  use global_params, only: nf, n, nkc, j6
+  implicit none
+  double precision :: tt(n)
+  integer :: nmaxf
+  integer, parameter :: NSPEC = 262
+  double precision :: alpha, vmean
+  common /kpp_2aer/ alpha(NSPEC, nf), vmean(NSPEC, nf)
+  interface
+     subroutine real_v_mean_a(tt, nmaxf) bind(C, name="__real_v_mean_a_")
+       double precision :: tt(*)
+       integer :: nmaxf
+     end subroutine real_v_mean_a
+  end interface
+  integer :: klist(64), taken, i
+  logical :: keep
+  keep = want(5)
+  call real_v_mean_a(tt, nmaxf)
+  if (keep) then
+     call pick(nmaxf, klist, taken)
+     do i = 1, taken
+        write (unit_out) int(z'4C495143'), 5, klist(i), NSPEC, nkc, j6
+        write (unit_out) tt(klist(i)), vmean(:, klist(i))
+     end do
+  end if
+end subroutine wrap_v_mean_a
+
+subroutine wrap_v_mean_t(tt, nmaxf) bind(C, name="__wrap_v_mean_t_")
+  use capture_liq_state
+  use global_params, only: nf, n, nkc, j6
+  implicit none
+  double precision :: tt(n)
+  integer :: nmaxf
+  integer, parameter :: NSPEC = 424
+  double precision :: alpha, vmean
+  common /kpp_2tot/ alpha(NSPEC, nf), vmean(NSPEC, nf)
+  interface
+     subroutine real_v_mean_t(tt, nmaxf) bind(C, name="__real_v_mean_t_")
+       double precision :: tt(*)
+       integer :: nmaxf
+     end subroutine real_v_mean_t
+  end interface
+  integer :: klist(64), taken, i
+  logical :: keep
+  keep = want(6)
+  call real_v_mean_t(tt, nmaxf)
+  if (keep) then
+     call pick(nmaxf, klist, taken)
+     do i = 1, taken
+        write (unit_out) int(z'4C495143'), 6, klist(i), NSPEC, nkc, j6
+        write (unit_out) tt(klist(i)), vmean(:, klist(i))
+     end do
+  end if
+end subroutine wrap_v_mean_t

@@ -1,5 +1,5 @@
-"""TEST INFRASTRUCTURE — plain-Python restatement of the reference's henry_a / henry_t and equil_co_a / equil_co_t (kpp.f90:1676-2145 |
-2954-3363) for ONE layer from the tables tools/extract_liq.py cuts out of them (mistra_amd/mech/<mech>.liq.json): the reference's
+"""TEST INFRASTRUCTURE — plain-Python restatement of the reference's henry_a / henry_t, equil_co_a / equil_co_t and v_mean_a / v_mean_t
+(kpp.f90:1676-2145 | 2954-3363 | 1268-1670) for ONE layer from the tables tools/extract_liq.py cuts out of them (mistra_amd/mech/<mech>.liq.json): the reference's
 operation order, one rounding per operation, the host libm's exp.  Pins tables and formulas on the CPU against layers captured from the
 running reference model (tests/golden/liq_<mech>.npz, tests/test_pack.py); the device kernels are then checked against the same fixtures."""
 import json
@@ -13,6 +13,18 @@ MECH_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mistr
 
 def load(mech):
     return json.load(open(os.path.join(MECH_DIR, mech + ".liq.json")))
+
+
+def load_vmean(mech):
+    return json.load(open(os.path.join(MECH_DIR, mech + ".vmean.json")))
+
+
+def v_mean_layer(tab, tt):
+    """kpp.f90:1319-1463 (v_mean_t) | 1524-1668 (v_mean_a): vmean(:,k) of one layer, [NSPEC], from the table tools/extract_vmean.py writes"""
+    out = np.zeros(tab["nspec"])                         # vmean(:,:) = 0._dp
+    for j, a in tab["entries"]:
+        out[j - 1] = math.sqrt(tt / a) * tab["coef"]     # func(a,k) = sqrt(tt(k)/a)*4.60138
+    return out
 
 
 def henry_layer(tab, tt):

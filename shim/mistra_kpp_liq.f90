@@ -1,6 +1,7 @@
-! Fortran side of liq_parm's three kernels on the GPU (SURVEY.md §8 f3; include/mistra_chem.h: mistra_chem_fast_k_mt, _henry, _equil_co):
+! Fortran side of liq_parm's table-driven kernels on the GPU (SURVEY.md §8 f3; include/mistra_chem.h: mistra_chem_fast_k_mt, _henry, _v_mean, _equil_co):
 !   FAST_K_MT_BATCH   fast_k_mt_a (kpp.f90:2683-2947) | fast_k_mt_t (kpp.f90:2421-2676): xkmt AND the sedimentation velocity vt, every 120 s
 !   HENRY_BATCH       henry_a (kpp.f90:1914-2145)     | henry_t (kpp.f90:1676-1907): the inverse dimensionless Henry constants, every step
+!   V_MEAN_BATCH      v_mean_a (kpp.f90:1472-1670)    | v_mean_t (kpp.f90:1268-1465): the mean molecular speeds, every step
 !   EQUIL_CO_BATCH    equil_co_a (kpp.f90:3162-3363)  | equil_co_t (kpp.f90:2954-3155): forward / backward equilibrium rate constants, every step
 ! for a run of consecutive layers.  Every array of the reference has the layer as its LAST dimension, so the caller hands over the model
 ! arrays in place, starting at the first layer of the run: ff(1,1,kmin), xkmt(1,1,kmin), cw(1,kmin), freep(kmin) ... (drop-ins with the
@@ -26,6 +27,13 @@ module mistra_kpp_liq
        real(c_double) :: henry(*)
        integer(c_int) :: rc
      end function mistra_chem_henry
+     function mistra_chem_v_mean(mech, nlayer, tt, vmean) bind(C, name="mistra_chem_v_mean") result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: mech, nlayer
+       real(c_double), intent(in) :: tt(*)
+       real(c_double) :: vmean(*)
+       integer(c_int) :: rc
+     end function mistra_chem_v_mean
      function mistra_chem_equil_co(mech, nlayer, nkc, j6, tt, conv2, xgamma, xkef, xkeb) bind(C, name="mistra_chem_equil_co") result(rc)
        import :: c_int, c_double
        integer(c_int), value :: mech, nlayer, nkc, j6
@@ -54,6 +62,15 @@ contains
     if (nlayer <= 0) return
     if (mistra_chem_henry(int(mech - 1, c_int), int(nlayer, c_int), tt, henry) /= 0) call mistra_chem_fail('HENRY_BATCH')
   end subroutine HENRY_BATCH
+
+  ! tt(nlayer) -> vmean(NSPEC,nlayer), written whole
+  subroutine V_MEAN_BATCH(mech, nlayer, tt, vmean)
+    integer, intent(in) :: mech, nlayer
+    real(c_double), intent(in) :: tt(*)
+    real(c_double) :: vmean(*)
+    if (nlayer <= 0) return
+    if (mistra_chem_v_mean(int(mech - 1, c_int), int(nlayer, c_int), tt, vmean) /= 0) call mistra_chem_fail('V_MEAN_BATCH')
+  end subroutine V_MEAN_BATCH
 
   ! tt(nlayer), conv2(nkc,nlayer), xgamma(j6,nkc,nlayer) -> xkef, xkeb(NSPEC,nkc,nlayer) in/out
   subroutine EQUIL_CO_BATCH(mech, nlayer, nkc, j6, tt, conv2, xgamma, xkef, xkeb)

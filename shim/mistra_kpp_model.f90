@@ -108,6 +108,32 @@ subroutine HENRY_HIP_a(tt, nmaxf)                  ! henry_a (tt,nmaxf), kpp.f90
   call HENRY_BATCH(2, nmaxf, tt, henry)
 end subroutine HENRY_HIP_a
 
+subroutine V_MEAN_HIP_t(tt, nmaxf)                 ! v_mean_t (tt,nmaxf), kpp.f90:1268: layers 1..nmaxf, the layers above stay 0
+  USE global_params, ONLY : nf, n
+  USE mistra_kpp_liq, ONLY : V_MEAN_BATCH
+  implicit none
+  double precision, intent(in) :: tt(n)
+  integer, intent(in) :: nmaxf
+  integer, parameter :: NSPEC = 424
+  double precision :: alpha, vmean
+  common /kpp_2tot/ alpha(NSPEC,nf), vmean(NSPEC,nf)
+  vmean(:,nmaxf+1:nf) = 0.d0                       ! vmean(:,:) = 0._dp, kpp.f90:1320
+  call V_MEAN_BATCH(3, nmaxf, tt, vmean)
+end subroutine V_MEAN_HIP_t
+
+subroutine V_MEAN_HIP_a(tt, nmaxf)                 ! v_mean_a (tt,nmaxf), kpp.f90:1472
+  USE global_params, ONLY : nf, n
+  USE mistra_kpp_liq, ONLY : V_MEAN_BATCH
+  implicit none
+  double precision, intent(in) :: tt(n)
+  integer, intent(in) :: nmaxf
+  integer, parameter :: NSPEC = 262
+  double precision :: alpha, vmean
+  common /kpp_2aer/ alpha(NSPEC,nf), vmean(NSPEC,nf)
+  vmean(:,nmaxf+1:nf) = 0.d0                       ! vmean(:,:) = 0._dp, kpp.f90:1525
+  call V_MEAN_BATCH(2, nmaxf, tt, vmean)
+end subroutine V_MEAN_HIP_a
+
 subroutine EQUIL_CO_HIP_t(tt, nmaxf)               ! equil_co_t (tt,nmaxf), kpp.f90:2954
   USE global_params, ONLY : j6, nf, n, nkc
   USE mistra_kpp_liq, ONLY : EQUIL_CO_BATCH

@@ -173,7 +173,7 @@ def test_fortran_batched_column_step(name, tmp_path, capsys):
 @needs_flang
 @pytest.mark.parametrize("mech", ["aer", "tot"])
 def test_fortran_liq_parm_kernels(mech, tmp_path):
-    """SURVEY §8 f3 from Fortran: FAST_K_MT_BATCH (xkmt and the sedimentation velocity vt), HENRY_BATCH, EQUIL_CO_BATCH of
+    """SURVEY §8 f3 from Fortran: FAST_K_MT_BATCH (xkmt and the sedimentation velocity vt), HENRY_BATCH, V_MEAN_BATCH, EQUIL_CO_BATCH of
     shim/mistra_kpp_liq.f90 — the host-buffer calls the drop-ins of shim/mistra_kpp_model.f90 make with the model's arrays in place — on the
     layers captured from the running reference model.  The results must be the device-pointer entry points' bit for bit (same kernels), i.e.
     what tests/test_gpu_kmt.py and test_gpu_liq.py pin against the captures."""
@@ -219,6 +219,13 @@ def test_fortran_liq_parm_kernels(mech, tmp_path):
     assert np.array_equal(hen, dh.cpu().numpy())
     nz = g["henry"] != 0
     assert np.array_equal(hen == 0, ~nz) and (np.abs(hen[nz] - g["henry"][nz]) / np.abs(g["henry"][nz])).max() <= 1e-14
+    # ---- v_mean_x: bit for bit against the running model
+    nl, nspec = g["vmean"].shape
+    with open(fin, "wb") as f:
+        f8(nl, nspec).tofile(f)
+        np.ascontiguousarray(g["vmean_tt"], np.float64).tofile(f)
+    subprocess.run([DRIVER, "V" + mech[0], str(fin), str(fout)], check=True, timeout=300)
+    assert np.array_equal(np.fromfile(fout, np.float64).reshape(nl, nspec), g["vmean"])
     nl, nkc, j6 = g["xgamma"].shape
     with open(fin, "wb") as f:
         f8(nl, nkc, j6, nspec).tofile(f)

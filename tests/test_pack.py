@@ -109,6 +109,18 @@ def test_henry_and_equilibrium_constants_of_captured_layers(mech):
     assert wet >= 8 and dry >= 2      # both branches of the routine are in the capture
 
 
+@pytest.mark.parametrize("mech", ["aer", "tot"])
+def test_mean_molecular_speeds_of_captured_layers(mech):
+    """v_mean_a / v_mean_t (kpp.f90:1472-1670 | 1268-1465) restated from the table tools/extract_vmean.py cuts out of them, on the layers
+    captured from the running reference model: bit for bit, zeros where the routine sets nothing."""
+    from oracle import liq_py
+    tab = liq_py.load_vmean(mech)
+    g = np.load(os.path.join(REPO, "tests", "golden", "liq_%s.npz" % mech))
+    assert len(g["vmean_k"]) >= 8
+    for i in range(len(g["vmean_k"])):
+        assert np.array_equal(liq_py.v_mean_layer(tab, float(g["vmean_tt"][i])), g["vmean"][i])
+
+
 def test_tables_in_the_repo_are_what_the_extractor_writes(tmp_path):
     if not os.path.isdir("/root/reference/src"):
         pytest.skip("no reference tree here")
@@ -119,3 +131,4 @@ def test_tables_in_the_repo_are_what_the_extractor_writes(tmp_path):
         subprocess.run([sys.executable, os.path.join(REPO, "tools", "extract_pack.py"), mech], check=True, stdout=subprocess.DEVNULL)
         assert open(os.path.join(REPO, "mistra_amd", "mech", mech + ".pack"), "rb").read() == before
     subprocess.run([sys.executable, os.path.join(REPO, "tools", "extract_liq.py"), "--check"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "extract_vmean.py"), "--check"], check=True, stdout=subprocess.DEVNULL)
