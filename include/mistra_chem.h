@@ -141,7 +141,9 @@ int mistra_chem_update_rconst_device(int mech, int ncell, const double* d_env, d
  *
  * mistra_chem_set_species_maps: the model's species index maps (module gas_common, built once by mk_interface, utils.f90:82-140, from
  * the user's species lists) for one mechanism: gas_m2k [j1][2] = gas_m2k_x(1:2,j) (C index, s1 index), gas_k2m [j1] = gas_k2m_x(j)
- * (C index of s1(j)), rad_* likewise for s3; 1-based as the Fortran holds them.  Host arrays; call once after init.
+ * (C index of s1(j)), rad_* likewise for s3; 1-based as the Fortran holds them.  Host arrays; call once after init.  Restriction: every C index
+ * must be a VARIABLE species (1..NVAR) — match_mk_indexes searches all NSPEC names, so a user list naming a fixed species (O2, N2, H2O ...) is
+ * legal in the reference; here it is refused with "species map entry out of range" (no shipped gas_species / gas_radical list names one).
  * mistra_chem_drive_dims: j2, j6, nkc (global_params.f90:96-103) and the slot count of bgs.  Any pointer may be NULL. */
 int mistra_chem_set_species_maps(int mech, int j1, const int32_t* gas_m2k, const int32_t* gas_k2m, int j5,
                                  const int32_t* rad_m2k, const int32_t* rad_k2m);
