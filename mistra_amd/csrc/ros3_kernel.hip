@@ -94,6 +94,39 @@ __device__ __forceinline__ double scalar_const(double v) {
   return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
 }
 
+// Sum over the wave, the same value in every lane: six pairing steps in which both partners add the same two numbers (so all lanes
+// agree bit for bit).  Inside a lane row the partner's value comes by DPP (quad swaps, half-row mirror, row mirror: ~10 cycles a step),
+// across lane rows by v_permlane16/32_swap; __shfl_xor went through ds_bpermute, an LDS round trip per step (six of them: ~800 cycles of
+// every step's error norm).
+template <int CTRL>
+__device__ __forceinline__ double dpp_partner(double v) {
+  const uint64_t u = __builtin_bit_cast(uint64_t, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_partner<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_partner<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_partner<0x141>(v);      // row_half_mirror: quads 0 <-> 1, 2 <-> 3
+  v += dpp_partner<0x140>(v);      // row_mirror: lanes 0-7 <-> 8-15
+  {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    // permlane16_swap(a, b) from a = b: a = [r0 r0 r2 r2], b = [r1 r1 r3 r3] (lane rows): their sum pairs rows 0+1 and 2+3 in every lane
+    const auto l = __builtin_amdgcn_permlane16_swap((uint32_t)u, (uint32_t)u, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
+    v = __builtin_bit_cast(double, (uint64_t)l[0] | ((uint64_t)h[0] << 32)) + __builtin_bit_cast(double, (uint64_t)l[1] | ((uint64_t)h[1] << 32));
+  }
+  {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    // permlane32_swap(a, b) from a = b: a = [lower lower], b = [upper upper]
+    const auto l = __builtin_amdgcn_permlane32_swap((uint32_t)u, (uint32_t)u, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
+    v = __builtin_bit_cast(double, (uint64_t)l[0] | ((uint64_t)h[0] << 32)) + __builtin_bit_cast(double, (uint64_t)l[1] | ((uint64_t)h[1] << 32));
+  }
+  return v;
+}
+
 __device__ __forceinline__ double fmin_f(double a, double b) { return (a < b || b != b) ? a : b; }   // Fortran MIN
 __device__ __forceinline__ double fmax_f(double a, double b) { return (a > b || b != b) ? a : b; }   // Fortran MAX
 
@@ -1456,8 +1489,7 @@ __global__ __launch_bounds__(NT, MT::WAVES_PER_SIMD) void ros3_integrate_kernel(
         part = part + e * e;
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    part = wave_sum(part);
     lds_barrier();   // red[] may still be read from the previous step
     {
       int wv = wave;
