@@ -241,18 +241,30 @@ int mistra_chem_henry_device(int mech, int nlayer, const double* d_tt, double* d
  * Table: mistra_amd/mech/<mech>.vmean, cut out of the reference source by tools/extract_vmean.py.  Quotient, square root and product round
  * once each as in the compiled reference: bit-identical (tests/test_gpu_liq.py). */
 int mistra_chem_v_mean_device(int mech, int nlayer, const double* d_tt, double* d_vmean, void* hip_stream);
+/* st_coeff_a (kpp.f90:857-1038) | st_coeff_t (kpp.f90:664-851), which liq_parm calls every time step (kpp.f90:614, 634): the accommodation
+ * coefficients alpha(:,k) fast_k_mt_x reads, for nlayer layers at once.
+ *   lp_joyce14bc, lp_buxmann15alph   the namelist switches of module config the routine branches on (alpha(NO3), alpha(N2O5) = a_n2o5(k,1),
+ *                             kpp.f90:8377; alpha(ICl), alpha(IBr))
+ *   d_env [nlayer][5]         per layer: t(k) (/cb53/), cw(1,k), cm(1,k) (/blck12/), sion1(13,1,k), sion1(14,1,k) (/blck17/) — the last four are
+ *                             read by a_n2o5 only
+ *   d_alpha [nlayer][NSPEC]   alpha(:,k) of /kpp_2aer/ | /kpp_2tot/, written whole: 0.1 for the species the routine does not list, min(1, .)
+ *                             applied (NSPEC = NVAR + NFIX).  The reference computes layers 2..nf; layer 1 keeps the default 0.1.
+ * Tables: mistra_amd/mech/<mech>.stcoeff (tools/extract_stcoeff.py: every assignment a postfix program, run by the evaluator of the rate
+ * constants); the restated table is bit-exact against the running model on the CPU, the device to the last place of its exp. */
+int mistra_chem_st_coeff_device(int mech, int nlayer, int lp_joyce14bc, int lp_buxmann15alph, const double* d_env, double* d_alpha, void* hip_stream);
 int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const double* d_tt, const double* d_conv2, const double* d_xgamma,
                                 double* d_xkef, double* d_xkeb, void* hip_stream);
 
 /* The liq_parm kernels above on HOST buffers (same layouts, layer-major as the model holds them: every array of the reference has the
  * layer as its last dimension, so a run of layers kmin..kmax is handed over in place — ff(1,1,kmin), xkmt(1,1,kmin) ...): what the Fortran
- * shim calls (shim/mistra_kpp_liq.f90: FAST_K_MT_BATCH, HENRY_BATCH, V_MEAN_BATCH, EQUIL_CO_BATCH; drop-ins with the reference's own signatures in
+ * shim calls (shim/mistra_kpp_liq.f90: FAST_K_MT_BATCH, HENRY_BATCH, V_MEAN_BATCH, ST_COEFF_BATCH, EQUIL_CO_BATCH; drop-ins with the reference's own signatures in
  * shim/mistra_kpp_model.f90).  Synchronous; primary device. */
 int mistra_chem_fast_k_mt(int mech, int nlayer, const double* ff, const double* rq, const int32_t* kw, int nkw, int ka, int ifeed, int nkc_l,
                           const double* cw, const double* cm, const double* freep, const double* alpha, const double* vmean, double* xkmt,
                           const double* t, const double* p, double* vt);
 int mistra_chem_henry(int mech, int nlayer, const double* tt, double* henry);
 int mistra_chem_v_mean(int mech, int nlayer, const double* tt, double* vmean);
+int mistra_chem_st_coeff(int mech, int nlayer, int lp_joyce14bc, int lp_buxmann15alph, const double* env, double* alpha);
 int mistra_chem_equil_co(int mech, int nlayer, int nkc, int j6, const double* tt, const double* conv2, const double* xgamma, double* xkef,
                          double* xkeb);
 

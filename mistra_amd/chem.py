@@ -82,6 +82,8 @@ def lib():
         L.mistra_chem_equil_co_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         if hasattr(L, "mistra_chem_v_mean_device"):      # (see below: older builds in same-box A/B runs)
             L.mistra_chem_v_mean_device.argtypes = [C.c_int, C.c_int, vp, vp, vp]
+        if hasattr(L, "mistra_chem_st_coeff_device"):
+            L.mistra_chem_st_coeff_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.mistra_chem_drive_device.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp]
         if hasattr(L, "mistra_chem_drive"):      # (an older build of the library loaded for a same-box A/B, tools/ab_many.sh, does not have these)
             L.mistra_chem_drive.argtypes = [C.c_int, C.c_int, _ip, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _ip, _dp, _dp, C.c_int,
@@ -367,6 +369,13 @@ def v_mean(mech, tt, out):
     """v_mean_a (aer) / v_mean_t (tot) for a batch of layers: out [nlayer, NSPEC] <- tt [nlayer] (include/mistra_chem.h)."""
     mid, _ = _mech_id(mech)
     _check(lib().mistra_chem_v_mean_device(mid, out.shape[0], _p(tt), _p(out), _stream(out)))
+
+
+def st_coeff(mech, env, out, lp_joyce14bc=False, lp_buxmann15alph=False):
+    """st_coeff_a (aer) / st_coeff_t (tot) for a batch of layers: out [nlayer, NSPEC] <- env [nlayer, 5] = t, cw(1), cm(1), sion1(13,1), sion1(14,1)
+    (include/mistra_chem.h)."""
+    mid, _ = _mech_id(mech)
+    _check(lib().mistra_chem_st_coeff_device(mid, out.shape[0], int(bool(lp_joyce14bc)), int(bool(lp_buxmann15alph)), _p(env), _p(out), _stream(out)))
 
 
 def equil_co(mech, tt, conv2, xgamma, xkef, xkeb):

@@ -83,6 +83,33 @@ bool mistra::RatesTable::load(const std::string& path, std::string* err) {
   return ok;
 }
 
+bool mistra::StcoeffTable::load(const std::string& path, std::string* err) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) { if (err) *err = "cannot open " + path; return false; }
+  bool ok = true;
+  for (int i = 0; ok && i < 4; i++) {
+    RatesTable& T = v[i];
+    int32_t h[8];
+    ok = std::fread(h, sizeof h, 1, f) == 1 && h[0] == 0x5441524B && h[1] == 2 && h[2] > 0 && h[2] <= 4096 && h[3] >= 4 && h[3] <= 64 && h[4] >= 0 &&
+         h[4] <= 1 << 20 && h[5] >= 0 && h[5] <= 1 << 20 && h[6] == 0 && h[7] == i;
+    if (!ok) break;
+    T.nreact = h[2]; T.nenv = h[3];
+    T.consts.resize((size_t)h[4]); T.offs.resize((size_t)T.nreact + 1); T.words.resize((size_t)h[5]); T.fslot.clear();
+    ok = (T.consts.empty() || std::fread(T.consts.data(), 8, T.consts.size(), f) == T.consts.size()) &&
+         std::fread(T.offs.data(), 4, T.offs.size(), f) == T.offs.size() && (T.words.empty() || std::fread(T.words.data(), 4, T.words.size(), f) == T.words.size());
+    // every index the evaluator follows is checked here: program bounds, literal and input slots, the functions st_coeff_x calls
+    ok = ok && T.offs[0] == 0 && T.offs[(size_t)T.nreact] == (int32_t)T.words.size() && (i == 0 || (T.nreact == v[0].nreact && T.nenv == v[0].nenv));
+    for (int r = 0; ok && r < T.nreact; r++) ok = T.offs[(size_t)r] < T.offs[(size_t)r + 1];
+    for (size_t w = 0; ok && w < T.words.size(); w++) {
+      const int op = T.words[w] & 0xFF, arg = T.words[w] >> 8;
+      ok = op == 0 ? (arg >= 0 && arg < (int)T.consts.size()) : op == 1 ? (arg >= 0 && arg < T.nenv) : op <= 6 ? arg == 0 : (op == 7 && arg >= 26 && arg <= 28);
+    }
+  }
+  std::fclose(f);
+  if (!ok && err) *err = path + ": not a table of accommodation coefficients";
+  return ok;
+}
+
 bool mistra::PackTable::load(const std::string& path, std::string* err) {
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) { if (err) *err = "cannot open " + path; return false; }
@@ -272,6 +299,11 @@ struct MechState {
   LiqTable liq_tab;
   DevBuf<int32_t> lq_hkind, lq_eof, lq_foff, lq_boff, lq_fkind, lq_farg;
   DevBuf<double> lq_ha0, lq_hb0, lq_fa, lq_fb;
+  // st_coeff_x (aer, tot): one table per setting of the two namelist switches
+  bool stc_ready = false;
+  StcoeffTable stc_tab;
+  DevBuf<double> stc_consts[4];
+  DevBuf<int32_t> stc_offs[4], stc_words[4];
   // v_mean_x (aer, tot)
   bool vmean_ready = false;
   VmeanTable vmean_tab;
@@ -299,6 +331,8 @@ struct MechState {
     lq_hkind.release(); lq_eof.release(); lq_foff.release(); lq_boff.release(); lq_fkind.release(); lq_farg.release(); lq_ha0.release(); lq_hb0.release();
     lq_fa.release(); lq_fb.release(); liq_ready = false;
     vm_mass.release(); vmean_ready = false;
+    for (int i = 0; i < 4; i++) { stc_consts[i].release(); stc_offs[i].release(); stc_words[i].release(); }
+    stc_ready = false;
     dense_rows.release(); schur_cells.release(); rates_consts.release(); rates_offs.release(); rates_words.release(); rates_fslot.release(); s_env.release(); rates_ready = false;
     s_var.release(); s_fix.release(); s_rct.release(); s_out.release(); s_th.release(); s_ierr.release(); s_stats.release(); s_sing.release();
     sing_count = 0; sing_one = false;
@@ -452,6 +486,17 @@ int setup_mech(DeviceState& D, int mech) {
       HIP_TRY(S.lq_fkind.upload(T.fkind)); HIP_TRY(S.lq_farg.upload(T.farg)); HIP_TRY(S.lq_ha0.upload(T.h_a0)); HIP_TRY(S.lq_hb0.upload(T.h_b0));
       HIP_TRY(S.lq_fa.upload(T.fa)); HIP_TRY(S.lq_fb.upload(T.fb));
       S.liq_ready = true;
+    }
+  }
+  {   // accommodation coefficients (aer, tot)
+    std::string serr;
+    StcoeffTable& T = S.stc_tab;
+    if (T.load(mech_dir() + "/" + kMechName[mech] + ".stcoeff", &serr)) {
+      if (T.v[0].nreact != S.tab.nvar + S.tab.nfix) return fail(std::string(kMechName[mech]) + ".stcoeff does not belong to this mechanism");
+      for (int i = 0; i < 4; i++) {
+        HIP_TRY(S.stc_consts[i].upload(T.v[i].consts)); HIP_TRY(S.stc_offs[i].upload(T.v[i].offs)); HIP_TRY(S.stc_words[i].upload(T.v[i].words));
+      }
+      S.stc_ready = true;
     }
   }
   {   // mean molecular speeds (aer, tot)
@@ -1019,6 +1064,24 @@ int mistra_chem_henry_device(int mech, int nlayer, const double* d_tt, double* d
   return 0;
 }
 
+int mistra_chem_st_coeff_device(int mech, int nlayer, int lp_joyce14bc, int lp_buxmann15alph, const double* d_env, double* d_alpha, void* hip_stream) {
+  if (int rc = check_call(mech, 1)) return rc;
+  if (nlayer == 0) return 0;
+  if (nlayer < 0) return fail("nlayer < 0");
+  if (!d_env || !d_alpha) return fail("null pointer");
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, d_alpha) != hipSuccess) return fail("the output is not a device pointer");
+  DeviceState* D = device_slot(attr.device);
+  if (!D) return fail("the buffers live on a device mistra_chem_init(_devices) did not set up");
+  const MechState& S = D->mech[mech];
+  if (!S.stc_ready) return fail(std::string("the ") + kMechName[mech] + " mechanism has no st_coeff routine (st_coeff_a: aer, st_coeff_t: tot)");
+  HIP_TRY(hipSetDevice(D->id));
+  const int v = (lp_joyce14bc ? 1 : 0) + (lp_buxmann15alph ? 2 : 0);
+  const RatesDev R{S.stc_consts[v].p, S.stc_offs[v].p, S.stc_words[v].p, nullptr, S.stc_tab.v[v].nreact, S.stc_tab.v[v].nenv};
+  LAUNCH_TRY(launch_update_rconst(R, d_env, d_alpha, nlayer, static_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
 int mistra_chem_v_mean_device(int mech, int nlayer, const double* d_tt, double* d_vmean, void* hip_stream) {
   if (int rc = check_call(mech, 1)) return rc;
   if (nlayer == 0) return 0;
@@ -1120,6 +1183,27 @@ int mistra_chem_henry(int mech, int nlayer, const double* tt, double* henry) {
   if (int rc = mistra_chem_henry_device(mech, nlayer, B.dptr(i_t), B.dptr(i_h), nullptr)) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(B.down(i_h, henry));
+  return 0;
+}
+
+int mistra_chem_st_coeff(int mech, int nlayer, int lp_joyce14bc, int lp_buxmann15alph, const double* env, double* alpha) {
+  if (int rc = lazy_init()) return rc;
+  if (int rc = check_call(mech, nlayer)) return rc;
+  if (nlayer == 0) return 0;
+  if (!env || !alpha) return fail("null pointer");
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  const MechState& S = D.mech[mech];
+  if (!S.stc_ready) return fail(std::string("the ") + kMechName[mech] + " mechanism has no st_coeff routine (st_coeff_a: aer, st_coeff_t: tot)");
+  HIP_TRY(hipSetDevice(D.id));
+  const size_t nl = (size_t)nlayer, nspec = (size_t)S.stc_tab.v[0].nreact, nenv = (size_t)S.stc_tab.v[0].nenv;
+  DevBlock B;
+  const size_t i_e = B.add(nl * nenv * sizeof(double)), i_a = B.add(nl * nspec * sizeof(double));
+  HIP_TRY(B.alloc());
+  HIP_TRY(B.up(i_e, env));
+  if (int rc = mistra_chem_st_coeff_device(mech, nlayer, lp_joyce14bc, lp_buxmann15alph, B.dptr(i_e), B.dptr(i_a), nullptr)) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.down(i_a, alpha));
   return 0;
 }
 

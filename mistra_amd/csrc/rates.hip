@@ -141,6 +141,23 @@ __device__ double fhet_d(const Env& v, double xliq, double xhet, int a0, int b0,
   return r;
 }
 
+// ---- st_coeff_a / st_coeff_t (kpp.f90:857-1038 | 664-851) run through the same evaluator (tools/extract_stcoeff.py writes their assignments as
+//      postfix programs over env = [t, cw(1,k), cm(1,k), sion1(13,1,k), sion1(14,1,k)]); what they call beyond + - * /:
+__device__ __forceinline__ double fmin_fortran(double a, double b) { return (a < b || b != b) ? a : b; }
+// kpp.f90:8377  a_n2o5(k,kc), kc = 1: uptake coefficient of N2O5 on the sulfate aerosol from its water, nitrate and chloride content
+__device__ double a_n2o5(double cw1, double cm1, double s13, double s14) {
+  double xno3m = 0.0, xclm = 0.0, xh2o = 0.0;
+  if (cw1 > 0.0) {
+    xno3m = (s13 / cw1) * 1.0e-3;
+    xclm = (s14 / cw1) * 1.0e-3;
+  }
+  if (cm1 > 0.0 && cw1 > 0.0) xh2o = 55.55 * (cm1 / cw1);
+  const double xk2f = 1.15e6 - 1.15e6 * exp(-0.13 * xh2o);
+  double denom = 1.0;
+  if (xno3m > 0.0) denom = (1.0 + (6.0e-2 * xh2o) / xno3m) + (29.0 * xclm) / xno3m;
+  return (3.2e-8 * xk2f) * (1.0 - (1.0 / denom));
+}
+
 __global__ __launch_bounds__(256) void update_rconst_kernel(const RatesDev R, const double* __restrict__ env, double* __restrict__ rconst,
                                                             int ncell) {
   // lane = cell, wave = a contiguous run of reactions: the 64 lanes of a wave interpret the SAME program (no divergence in
@@ -242,6 +259,9 @@ __global__ __launch_bounds__(256) void update_rconst_kernel(const RatesDev R, co
             v = d > 0.0 ? (k / (1.0 + ((k / dclim) * c) * d)) * (d * d) : 0.0;
             break;
           }
+          case 26: sp -= 1; v = exp(st_at(sp)); break;                                                                      // the intrinsic, st_coeff_x
+          case 27: sp -= 4; v = a_n2o5(st_at(sp), st_at(sp + 1), st_at(sp + 2), st_at(sp + 3)); break;
+          case 28: sp -= 2; v = fmin_fortran(st_at(sp), st_at(sp + 1)); break;                                              // min(a, b)
         }
         st_at(sp++) = v;
       }

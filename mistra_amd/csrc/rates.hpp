@@ -23,6 +23,13 @@ struct RatesTable {
   bool load(const std::string& path, std::string* err);
 };
 
+// st_coeff_a / st_coeff_t (kpp.f90:857-1038 | 664-851) as four tables of the same format, one per setting of the namelist switches
+// lpJoyce14bc + 2*lpBuxmann15alph (mistra_amd/mech/<mech>.stcoeff, tools/extract_stcoeff.py); outputs = NSPEC, env = 5 doubles per layer
+struct StcoeffTable {
+  RatesTable v[4];
+  bool load(const std::string& path, std::string* err);
+};
+
 hipError_t launch_update_rconst(const RatesDev& R, const double* d_env, double* d_rconst, int ncell, hipStream_t stream);
 
 }  // namespace mistra

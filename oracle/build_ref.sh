@@ -78,7 +78,7 @@ if [ "$WHAT" = model ] || [ "$WHAT" = all ]; then
       -Wl,--wrap=integrate_g_ -Wl,--wrap=integrate_a_ -Wl,--wrap=integrate_t_ \
       -Wl,--wrap=update_rconst_g_ -Wl,--wrap=update_rconst_a_ -Wl,--wrap=update_rconst_t_ \
       -Wl,--wrap=gas_drive_ -Wl,--wrap=aer_drive_ -Wl,--wrap=tot_drive_ -Wl,--wrap=fast_k_mt_a_ -Wl,--wrap=fast_k_mt_t_ \
-      -Wl,--wrap=henry_a_ -Wl,--wrap=henry_t_ -Wl,--wrap=equil_co_a_ -Wl,--wrap=equil_co_t_ -Wl,--wrap=v_mean_a_ -Wl,--wrap=v_mean_t_ \
+      -Wl,--wrap=henry_a_ -Wl,--wrap=henry_t_ -Wl,--wrap=equil_co_a_ -Wl,--wrap=equil_co_t_ -Wl,--wrap=v_mean_a_ -Wl,--wrap=v_mean_t_ -Wl,--wrap=st_coeff_a_ -Wl,--wrap=st_coeff_t_ \
       -Wl,--unresolved-symbols=ignore-all
 fi
 

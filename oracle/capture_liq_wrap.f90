@@ -1,4 +1,5 @@
-! TEST INFRASTRUCTURE — fixture capture of henry_a / henry_t / equil_co_a / equil_co_t / v_mean_a / v_mean_t calls of the running reference model
+! TEST INFRASTRUCTURE — fixture capture of henry_a / henry_t / equil_co_a / equil_co_t / v_mean_a / v_mean_t / st_coeff_a / st_coeff_t calls of the running
+! reference model
 ! (oracle/build_ref.sh `model`), for those liq_parm kernels on the device (SURVEY.md §8 f3).
 !
 ! Linked with -Wl,--wrap=henry_a_ ... equil_co_t_, v_mean_a_, v_mean_t_: liq_parm's calls (kpp.f90:612-616, 632-636) land here.  For the calls selected by
@@ -6,17 +7,20 @@
 ! the column, it records what the routine READS for that layer and what it leaves behind, into MISTRA_CAPTURE_LIQ_FILE:
 !   henry_x     tt(k)                                      -> henry(:,k)
 !   v_mean_x    tt(k)                                      -> vmean(:,k)
+!   st_coeff_x  t(k), cw(1,k), cm(1,k), sion1(13:14,1,k), the switches lpJoyce14bc, lpBuxmann15alph    -> alpha(:,k)
 !   equil_co_x  tt(k), conv2(:,k), xgamma(:,:,k)           -> xkef(:,:,k), xkeb(:,:,k), both also BEFORE the call (entries of species the
 !                                                             routine does not set keep what they held)
 ! No reference source is modified.
-! record: int32 {magic 'LIQC', routine (1 henry_a | 2 henry_t | 3 equil_co_a | 4 equil_co_t | 5 v_mean_a | 6 v_mean_t), k, nspec, nkc, j6}, then doubles
+! record: int32 {magic 'LIQC', routine (1 henry_a | 2 henry_t | 3 equil_co_a | 4 equil_co_t | 5 v_mean_a | 6 v_mean_t | 7 st_coeff_a | 8 st_coeff_t), k, nspec, nkc, j6},
+!         then doubles
 !         routines 1, 2:  tt, henry(nspec)            routines 5, 6:  tt, vmean(nspec)
+!         routines 7, 8:  t, cw1, cm1, sion1_13, sion1_14, lpJoyce14bc (0 | 1), lpBuxmann15alph (0 | 1), alpha(nspec)
 !         routines 3, 4:  tt, conv2(nkc), xgamma(j6,nkc), xkef_before(nspec,nkc), xkeb_before(nspec,nkc), xkef(nspec,nkc), xkeb(nspec,nkc)
 module capture_liq_state
   implicit none
   integer :: unit_out = 0, nlayers = 6
   logical :: inited = .false., opened = .false.
-  integer :: ncall(6) = 0, nrec(6) = 0, nskip = 0, nevery = 1, nmax = 2
+  integer :: ncall(8) = 0, nrec(8) = 0, nskip = 0, nevery = 1, nmax = 2
 contains
   subroutine init()
     character(len=512) :: buf
@@ -250,3 +254,61 @@ subroutine wrap_v_mean_t(tt, nmaxf) bind(C, name="__wrap_v_mean_t_")
      end do
   end if
 end subroutine wrap_v_mean_t
+
+subroutine wrap_st_coeff_a() bind(C, name="__wrap_st_coeff_a_")
+  use capture_liq_state
+  use config, only: lpJoyce14bc, lpBuxmann15alph
+  use global_params, only: nf, n, nkc, j2, j6
+  implicit none
+  integer, parameter :: NSPEC = 262
+  double precision :: alpha, vmean, cw, cm, sl1, sion1, theta, thetl, t, talt, p, rho
+  common /kpp_2aer/ alpha(NSPEC, nf), vmean(NSPEC, nf)
+  common /blck12/ cw(nkc, n), cm(nkc, n)
+  common /blck17/ sl1(j2, nkc, n), sion1(j6, nkc, n)
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  interface
+     subroutine real_st_coeff_a() bind(C, name="__real_st_coeff_a_")
+     end subroutine real_st_coeff_a
+  end interface
+  integer :: klist(64), taken, i, k
+  logical :: keep
+  keep = want(7)
+  call real_st_coeff_a()
+  if (keep) then
+     call pick(nf, klist, taken)
+     do i = 1, taken
+        k = klist(i)
+        write (unit_out) int(z'4C495143'), 7, k, NSPEC, nkc, j6
+        write (unit_out) t(k), cw(1, k), cm(1, k), sion1(13, 1, k), sion1(14, 1, k), merge(1.d0, 0.d0, lpJoyce14bc), merge(1.d0, 0.d0, lpBuxmann15alph), alpha(:, k)
+     end do
+  end if
+end subroutine wrap_st_coeff_a
+
+subroutine wrap_st_coeff_t() bind(C, name="__wrap_st_coeff_t_")
+  use capture_liq_state
+  use config, only: lpJoyce14bc, lpBuxmann15alph
+  use global_params, only: nf, n, nkc, j2, j6
+  implicit none
+  integer, parameter :: NSPEC = 424
+  double precision :: alpha, vmean, cw, cm, sl1, sion1, theta, thetl, t, talt, p, rho
+  common /kpp_2tot/ alpha(NSPEC, nf), vmean(NSPEC, nf)
+  common /blck12/ cw(nkc, n), cm(nkc, n)
+  common /blck17/ sl1(j2, nkc, n), sion1(j6, nkc, n)
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  interface
+     subroutine real_st_coeff_t() bind(C, name="__real_st_coeff_t_")
+     end subroutine real_st_coeff_t
+  end interface
+  integer :: klist(64), taken, i, k
+  logical :: keep
+  keep = want(8)
+  call real_st_coeff_t()
+  if (keep) then
+     call pick(nf, klist, taken)
+     do i = 1, taken
+        k = klist(i)
+        write (unit_out) int(z'4C495143'), 8, k, NSPEC, nkc, j6
+        write (unit_out) t(k), cw(1, k), cm(1, k), sion1(13, 1, k), sion1(14, 1, k), merge(1.d0, 0.d0, lpJoyce14bc), merge(1.d0, 0.d0, lpBuxmann15alph), alpha(:, k)
+     end do
+  end if
+end subroutine wrap_st_coeff_t

@@ -166,6 +166,30 @@ FUNCS = {
 }
 
 
+def _a_n2o5(e, cw1, cm1, s13, s14):      # kpp.f90:8377 with kc = 1
+    xno3m = xclm = xh2o = 0.0
+    if cw1 > 0.0:
+        xno3m = (s13 / cw1) * 1.0e-3
+        xclm = (s14 / cw1) * 1.0e-3
+    if cm1 > 0.0 and cw1 > 0.0:
+        xh2o = 55.55 * (cm1 / cw1)
+    xk2f = 1.15e6 - 1.15e6 * math.exp(-0.13 * xh2o)
+    denom = 1.0
+    if xno3m > 0.0:
+        denom = (1.0 + (6.0e-2 * xh2o) / xno3m) + (29.0 * xclm) / xno3m
+    return (3.2e-8 * xk2f) * (1.0 - (1.0 / denom))
+
+
+# st_coeff_a / st_coeff_t (kpp.f90:857-1038 | 664-851) use the same program format (tools/extract_stcoeff.py)
+FUNCS.update({"exp": lambda e, x: math.exp(x), "a_n2o5": _a_n2o5, "min": lambda e, a, b: a if (a < b or b != b) else b})
+
+
+def st_coeff_layer(table, lp_joyce14bc, lp_buxmann15alph, env):
+    """alpha(:,k) of one layer [NSPEC] from env = [t(k), cw(1,k), cm(1,k), sion1(13,1,k), sion1(14,1,k)]; table = <mech>.stcoeff.json"""
+    var = table["variants"][int(bool(lp_joyce14bc)) + 2 * int(bool(lp_buxmann15alph))]
+    return evaluate({"nreact": table["nspec"], "programs": var["programs"]}, {n: i for i, n in enumerate(table["env"])}, env)
+
+
 def evaluate(table, slot, env, fslot=None):
     """rconst[nreact] for one env vector; table = the .rates.json dict, slot = {name: env index}, fslot = the slot list of the
     mechanism (both from mistra_amd/mech/<mech>.rates_env.json)"""

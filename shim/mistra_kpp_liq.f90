@@ -1,7 +1,8 @@
-! Fortran side of liq_parm's table-driven kernels on the GPU (SURVEY.md §8 f3; include/mistra_chem.h: mistra_chem_fast_k_mt, _henry, _v_mean, _equil_co):
+! Fortran side of liq_parm's table-driven kernels on the GPU (SURVEY.md §8 f3; include/mistra_chem.h: mistra_chem_fast_k_mt, _henry, _v_mean, _st_coeff, _equil_co):
 !   FAST_K_MT_BATCH   fast_k_mt_a (kpp.f90:2683-2947) | fast_k_mt_t (kpp.f90:2421-2676): xkmt AND the sedimentation velocity vt, every 120 s
 !   HENRY_BATCH       henry_a (kpp.f90:1914-2145)     | henry_t (kpp.f90:1676-1907): the inverse dimensionless Henry constants, every step
 !   V_MEAN_BATCH      v_mean_a (kpp.f90:1472-1670)    | v_mean_t (kpp.f90:1268-1465): the mean molecular speeds, every step
+!   ST_COEFF_BATCH    st_coeff_a (kpp.f90:857-1038)   | st_coeff_t (kpp.f90:664-851): the accommodation coefficients alpha, every step
 !   EQUIL_CO_BATCH    equil_co_a (kpp.f90:3162-3363)  | equil_co_t (kpp.f90:2954-3155): forward / backward equilibrium rate constants, every step
 ! for a run of consecutive layers.  Every array of the reference has the layer as its LAST dimension, so the caller hands over the model
 ! arrays in place, starting at the first layer of the run: ff(1,1,kmin), xkmt(1,1,kmin), cw(1,kmin), freep(kmin) ... (drop-ins with the
@@ -34,6 +35,13 @@ module mistra_kpp_liq
        real(c_double) :: vmean(*)
        integer(c_int) :: rc
      end function mistra_chem_v_mean
+     function mistra_chem_st_coeff(mech, nlayer, lp_joyce14bc, lp_buxmann15alph, env, alpha) bind(C, name="mistra_chem_st_coeff") result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: mech, nlayer, lp_joyce14bc, lp_buxmann15alph
+       real(c_double), intent(in) :: env(*)
+       real(c_double) :: alpha(*)
+       integer(c_int) :: rc
+     end function mistra_chem_st_coeff
      function mistra_chem_equil_co(mech, nlayer, nkc, j6, tt, conv2, xgamma, xkef, xkeb) bind(C, name="mistra_chem_equil_co") result(rc)
        import :: c_int, c_double
        integer(c_int), value :: mech, nlayer, nkc, j6
@@ -71,6 +79,17 @@ contains
     if (nlayer <= 0) return
     if (mistra_chem_v_mean(int(mech - 1, c_int), int(nlayer, c_int), tt, vmean) /= 0) call mistra_chem_fail('V_MEAN_BATCH')
   end subroutine V_MEAN_BATCH
+
+  ! env(5,nlayer) = t(k), cw(1,k), cm(1,k), sion1(13,1,k), sion1(14,1,k) -> alpha(NSPEC,nlayer), written whole; the two namelist switches of module config
+  subroutine ST_COEFF_BATCH(mech, nlayer, lpJoyce14bc, lpBuxmann15alph, env, alpha)
+    integer, intent(in) :: mech, nlayer
+    logical, intent(in) :: lpJoyce14bc, lpBuxmann15alph
+    real(c_double), intent(in) :: env(*)
+    real(c_double) :: alpha(*)
+    if (nlayer <= 0) return
+    if (mistra_chem_st_coeff(int(mech - 1, c_int), int(nlayer, c_int), merge(1_c_int, 0_c_int, lpJoyce14bc), merge(1_c_int, 0_c_int, lpBuxmann15alph), &
+                             env, alpha) /= 0) call mistra_chem_fail('ST_COEFF_BATCH')
+  end subroutine ST_COEFF_BATCH
 
   ! tt(nlayer), conv2(nkc,nlayer), xgamma(j6,nkc,nlayer) -> xkef, xkeb(NSPEC,nkc,nlayer) in/out
   subroutine EQUIL_CO_BATCH(mech, nlayer, nkc, j6, tt, conv2, xgamma, xkef, xkeb)

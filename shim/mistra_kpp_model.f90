@@ -108,6 +108,44 @@ subroutine HENRY_HIP_a(tt, nmaxf)                  ! henry_a (tt,nmaxf), kpp.f90
   call HENRY_BATCH(2, nmaxf, tt, henry)
 end subroutine HENRY_HIP_a
 
+subroutine ST_COEFF_HIP_t                          ! st_coeff_t, kpp.f90:664: layers 2..nf, layer 1 keeps the default
+  USE config, ONLY : lpBuxmann15alph, lpJoyce14bc
+  USE global_params, ONLY : j2, j6, nf, n, nkc
+  USE mistra_kpp_liq, ONLY : ST_COEFF_BATCH
+  implicit none
+  integer, parameter :: NSPEC = 424
+  double precision :: alpha, vmean, cw, cm, sl1, sion1, theta, thetl, t, talt, p, rho, env(5, nf)
+  integer :: k
+  common /kpp_2tot/ alpha(NSPEC,nf), vmean(NSPEC,nf)
+  common /blck12/ cw(nkc,n), cm(nkc,n)
+  common /blck17/ sl1(j2,nkc,n), sion1(j6,nkc,n)
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  alpha(:,1) = 0.1d0                               ! alpha(:,:) = 0.1_dp, kpp.f90:717
+  do k = 2, nf
+     env(:, k) = [t(k), cw(1,k), cm(1,k), sion1(13,1,k), sion1(14,1,k)]
+  end do
+  call ST_COEFF_BATCH(3, nf - 1, lpJoyce14bc, lpBuxmann15alph, env(1, 2), alpha(1, 2))
+end subroutine ST_COEFF_HIP_t
+
+subroutine ST_COEFF_HIP_a                          ! st_coeff_a, kpp.f90:857
+  USE config, ONLY : lpJoyce14bc
+  USE global_params, ONLY : j2, j6, nf, n, nkc
+  USE mistra_kpp_liq, ONLY : ST_COEFF_BATCH
+  implicit none
+  integer, parameter :: NSPEC = 262
+  double precision :: alpha, vmean, cw, cm, sl1, sion1, theta, thetl, t, talt, p, rho, env(5, nf)
+  integer :: k
+  common /kpp_2aer/ alpha(NSPEC,nf), vmean(NSPEC,nf)
+  common /blck12/ cw(nkc,n), cm(nkc,n)
+  common /blck17/ sl1(j2,nkc,n), sion1(j6,nkc,n)
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  alpha(:,1) = 0.1d0                               ! alpha(:,:) = 0.1_dp, kpp.f90:905
+  do k = 2, nf
+     env(:, k) = [t(k), cw(1,k), cm(1,k), sion1(13,1,k), sion1(14,1,k)]
+  end do
+  call ST_COEFF_BATCH(2, nf - 1, lpJoyce14bc, .false., env(1, 2), alpha(1, 2))      ! (st_coeff_a has no lpBuxmann15alph branch)
+end subroutine ST_COEFF_HIP_a
+
 subroutine V_MEAN_HIP_t(tt, nmaxf)                 ! v_mean_t (tt,nmaxf), kpp.f90:1268: layers 1..nmaxf, the layers above stay 0
   USE global_params, ONLY : nf, n
   USE mistra_kpp_liq, ONLY : V_MEAN_BATCH

@@ -19,8 +19,10 @@ def main():
         h = np.frombuffer(raw, np.int32, 6, off); off += 24
         assert h[0] == 0x4C495143
         routine, k, nspec, nkc, j6 = (int(x) for x in h[1:])
-        n = 1 + nspec if routine <= 2 or routine >= 5 else 1 + nkc + j6 * nkc + 4 * nspec * nkc
+        n = 7 + nspec if routine >= 7 else 1 + nspec if routine <= 2 or routine >= 5 else 1 + nkc + j6 * nkc + 4 * nspec * nkc
         d = np.frombuffer(raw, np.float64, n, off).copy(); off += 8 * n
+        if routine >= 7:
+            continue      # st_coeff_x: tests/golden/make_stcoeff_golden.py
         if routine <= 2 or routine >= 5:
             per[routine].append(dict(k=k, tt=d[0], henry=d[1:]))
         else:

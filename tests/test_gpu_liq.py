@@ -90,3 +90,35 @@ def test_mean_molecular_speeds_on_the_device(mech):
     assert (want != 0).sum(axis=1).min() >= 90 and (want == 0).any()
     with pytest.raises(chem.MistraChemError):
         chem.v_mean("gas", torch.tensor(np.ascontiguousarray(g["vmean_tt"]), device=dev), out)
+
+
+@pytest.mark.parametrize("mech", ["aer", "tot"])
+def test_accommodation_coefficients_on_the_device(mech):
+    """st_coeff_a / st_coeff_t (kpp.f90:857-1038 | 664-851) from mistra_chem_st_coeff_device — the postfix programs of <mech>.stcoeff run by the
+    evaluator of the rate constants — against the layers captured from the running reference model, both settings of lpJoyce14bc for aer: the
+    species whose coefficient is a literal (or the default 0.1) bit for bit, the temperature laws and a_n2o5 to the last place of the device
+    exp (asserted: 1e-14), the whole array written."""
+    import json
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from mistra_amd import chem
+    chem.init(0)
+    dev = torch.device("cuda", 0)
+    g = np.load(os.path.join(REPO, "tests", "golden", "stcoeff_%s.npz" % mech))
+    tab = json.load(open(os.path.join(REPO, "mistra_amd", "mech", mech + ".stcoeff.json")))
+    for jo in sorted(set(g["lp_joyce14bc"].tolist())):
+        for bu in sorted(set(g["lp_buxmann15alph"].tolist())):
+            pick = (g["lp_joyce14bc"] == jo) & (g["lp_buxmann15alph"] == bu)
+            if not pick.any():
+                continue
+            want = g["alpha"][pick]
+            out = torch.full(want.shape, float("nan"), dtype=torch.float64, device=dev)
+            chem.st_coeff(mech, torch.tensor(np.ascontiguousarray(g["env"][pick]), device=dev), out, bool(jo), bool(bu))
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            assert np.isfinite(got).all() and np.array_equal(got == 0.0, want == 0.0) and _rel(got, want) <= TOL, _rel(got, want)
+            progs = tab["variants"][jo + 2 * bu]["programs"]
+            plain = np.array([j for j, p in enumerate(progs) if not any(t[0] == "call" and t[1] != "min" for t in p)])
+            assert len(plain) > 300 and np.array_equal(got[:, plain], want[:, plain])
+    with pytest.raises(chem.MistraChemError):
+        chem.st_coeff("gas", torch.zeros((1, 5), dtype=torch.float64, device=dev), torch.zeros((1, 105), dtype=torch.float64, device=dev))

@@ -173,7 +173,7 @@ def test_fortran_batched_column_step(name, tmp_path, capsys):
 @needs_flang
 @pytest.mark.parametrize("mech", ["aer", "tot"])
 def test_fortran_liq_parm_kernels(mech, tmp_path):
-    """SURVEY §8 f3 from Fortran: FAST_K_MT_BATCH (xkmt and the sedimentation velocity vt), HENRY_BATCH, V_MEAN_BATCH, EQUIL_CO_BATCH of
+    """SURVEY §8 f3 from Fortran: FAST_K_MT_BATCH (xkmt and the sedimentation velocity vt), HENRY_BATCH, V_MEAN_BATCH, ST_COEFF_BATCH, EQUIL_CO_BATCH of
     shim/mistra_kpp_liq.f90 — the host-buffer calls the drop-ins of shim/mistra_kpp_model.f90 make with the model's arrays in place — on the
     layers captured from the running reference model.  The results must be the device-pointer entry points' bit for bit (same kernels), i.e.
     what tests/test_gpu_kmt.py and test_gpu_liq.py pin against the captures."""
@@ -226,6 +226,21 @@ def test_fortran_liq_parm_kernels(mech, tmp_path):
         np.ascontiguousarray(g["vmean_tt"], np.float64).tofile(f)
     subprocess.run([DRIVER, "V" + mech[0], str(fin), str(fout)], check=True, timeout=300)
     assert np.array_equal(np.fromfile(fout, np.float64).reshape(nl, nspec), g["vmean"])
+    # ---- st_coeff_x: what the device-pointer entry returns, bit for bit; against the running model to the last place of exp
+    gs = np.load(os.path.join(REPO, "tests", "golden", "stcoeff_%s.npz" % mech))
+    for jo in sorted(set(gs["lp_joyce14bc"].tolist())):
+        pick = gs["lp_joyce14bc"] == jo
+        env, want = gs["env"][pick], gs["alpha"][pick]
+        with open(fin, "wb") as f:
+            f8(env.shape[0], want.shape[1], jo, 0).tofile(f)
+            np.ascontiguousarray(env, np.float64).tofile(f)
+        subprocess.run([DRIVER, "S" + mech[0], str(fin), str(fout)], check=True, timeout=300)
+        al = np.fromfile(fout, np.float64).reshape(want.shape)
+        da = torch.full(want.shape, float("nan"), dtype=torch.float64, device=dev)
+        chem.st_coeff(mech, T(env), da, bool(jo), False)
+        torch.cuda.synchronize()
+        nz = want != 0
+        assert np.array_equal(al, da.cpu().numpy()) and np.array_equal(al == 0, ~nz) and (np.abs(al[nz] - want[nz]) / np.abs(want[nz])).max() <= 1e-14
     nl, nkc, j6 = g["xgamma"].shape
     with open(fin, "wb") as f:
         f8(nl, nkc, j6, nspec).tofile(f)

@@ -91,3 +91,32 @@ def test_binary_table_matches_json(mech):
                 assert op == OP["env"] and 0 <= arg < len(names)
             else:
                 assert op == OP[t[0]]
+
+
+@pytest.mark.parametrize("mech", ["aer", "tot"])
+def test_accommodation_coefficients_of_captured_layers(mech):
+    """st_coeff_a / st_coeff_t (kpp.f90:857-1038 | 664-851) as postfix programs (tools/extract_stcoeff.py) evaluated by the
+    restated evaluator, on layers captured from the RUNNING reference model (tests/golden/stcoeff_<mech>.npz: BTZ96 with both switches off and,
+    Joyce2014 and BTZ96 with lpJoyce14bc = T, i.e. alpha(N2O5) = a_n2o5(k,1) on dry and on wet aerosol): alpha(:,k) bit for bit — the defaults, the literals, the
+    temperature laws, the copies and min(1, .) — with the host libm's exp."""
+    import json
+    from oracle import rates_py
+    tab = json.load(open(os.path.join(REPO, "mistra_amd", "mech", mech + ".stcoeff.json")))
+    g = np.load(os.path.join(REPO, "tests", "golden", "stcoeff_%s.npz" % mech))
+    assert len(g["k"]) >= 16 and g["alpha"].shape[1] == tab["nspec"]
+    for i in range(len(g["k"])):
+        got = rates_py.st_coeff_layer(tab, g["lp_joyce14bc"][i], g["lp_buxmann15alph"][i], g["env"][i])
+        assert np.array_equal(got, g["alpha"][i]), (mech, i)
+    if mech == "aer":      # the a_n2o5 branch is in the fixture, and it is not the default
+        jo = g["lp_joyce14bc"] == 1
+        n2o5 = [j for j in tab["variants"][1]["set"] if j not in tab["variants"][0]["set"]]
+        a = g["alpha"][jo][:, n2o5[0] - 1]
+        assert jo.any() and len(n2o5) == 1 and np.all(a != 0.1) and (a > 0).any() and (a == 0).any()      # wet nitrate-bearing aerosol, and dry
+
+
+def test_stcoeff_tables_in_the_repo_are_what_the_extractor_writes():
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("the reference tree is not here")
+    import subprocess
+    import sys
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "extract_stcoeff.py"), "--check"], check=True, stdout=subprocess.DEVNULL)
