@@ -119,6 +119,6 @@ def test_accommodation_coefficients_on_the_device(mech):
             assert np.isfinite(got).all() and np.array_equal(got == 0.0, want == 0.0) and _rel(got, want) <= TOL, _rel(got, want)
             progs = tab["variants"][jo + 2 * bu]["programs"]
             plain = np.array([j for j, p in enumerate(progs) if not any(t[0] == "call" and t[1] != "min" for t in p)])
-            assert len(plain) > 300 and np.array_equal(got[:, plain], want[:, plain])
+            assert len(plain) > 200 and np.array_equal(got[:, plain], want[:, plain])
     with pytest.raises(chem.MistraChemError):
         chem.st_coeff("gas", torch.zeros((1, 5), dtype=torch.float64, device=dev), torch.zeros((1, 105), dtype=torch.float64, device=dev))
