@@ -235,7 +235,7 @@ struct VmBufs {
   DevBuf<uint16_t> blk_n;
   int nrounds = 0;
   hipError_t upload(const VmProgram& P) {
-    nrounds = P.nrounds;
+    nrounds = P.nbarriers;      // what the executor counts down: the rounds that end in a barrier
     hipError_t e;
     if ((e = wave_base.upload(P.wave_base)) != hipSuccess) return e;
     if ((e = blk_n.upload(P.blk_n)) != hipSuccess) return e;

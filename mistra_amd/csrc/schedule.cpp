@@ -77,7 +77,7 @@ int lds_pass_cycles(const int* cell64) {
 // Small sets are packed into few waves.  Which lane walks an item changes no arithmetic: every entry keeps its update order.
 // (Tried on top, dropped: sweeps of pairwise swaps between half-waves of one-record items that share a row, accepted where the modelled
 // cycles of both half-waves' seven gathers drop — 1.7 % fewer modelled cycles for 1.6 s of start-up time per sweep.)
-std::vector<int> deal(const std::vector<Item>& items, const std::vector<VmEntry>& entries, int nt, int upr, std::vector<int>& row0) {
+std::vector<int> deal(const std::vector<Item>& items, const std::vector<VmEntry>& entries, int nt, int upr, std::vector<int>& row0, int max_waves = 0) {
   const int n = (int)items.size();
   std::vector<int> lane((size_t)n);
   row0.assign((size_t)n, 0);
@@ -96,12 +96,12 @@ std::vector<int> deal(const std::vector<Item>& items, const std::vector<VmEntry>
   int waves_used = 1;
   {
     long best_t = -1, best_rows = 0;
-    for (int w = 1; w <= nt / 64 && !plain_deal; w++) {
+    for (int w = 1; w <= (max_waves > 0 ? max_waves : nt / 64) && !plain_deal; w++) {
       const long r = std::max<long>(longest, (total + 64L * std::min(rcp_waves, w) + 64L * w - 1) / (64L * w));
       const long t = std::max<long>((long)c_lds * w * r, (long)c_row * r);
       if (best_t < 0 || t < best_t || (t == best_t && w * r <= best_rows)) { best_t = t; best_rows = w * r; waves_used = w; }
     }
-    if (plain_deal) waves_used = std::max(1, std::min(nt / 64, (n + 63) / 64));
+    if (plain_deal) waves_used = std::max(1, std::min(max_waves > 0 ? max_waves : nt / 64, (n + 63) / 64));
   }
   const int lanes = waves_used * 64, groups = lanes / 32;
   if (plain_deal) {
@@ -226,7 +226,7 @@ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
-VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget, int upr) {
+VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget, int upr, int local_max) {
   if (upr != 2 && upr != 3) throw std::invalid_argument("records hold two (a, r, u) or three (a, u) updates");
   if (nt % 64 != 0 || nt <= 0) throw std::invalid_argument("nt must be a positive multiple of 64");
   const int msize = lay.size(), zero_slot = lay.zero();
@@ -345,6 +345,21 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
 
   P.nrounds = (int)rounds.size();
   P.blk_n.assign((size_t)P.nrounds * P.nw, 0);
+  // Local rounds.  A round of a few dozen records costs a workgroup what every round costs it — all waves through a barrier and its LDS
+  // round trips, ~650 cycles — for one or two rows of work.  Rounds of at most local_max records are walked by wave 0 ALONE, and a run of
+  // consecutive ones without any barrier in between: the LDS operations of one wave complete in order, so a round sees what the round
+  // before it stored.  Only the run's last round ends in the barrier, which the other waves meet with a null row (they have no rows at
+  // all in the rounds before it).  Same records, same order per entry: the arithmetic does not know who walks it.
+  std::vector<char> local((size_t)P.nrounds, 0), local_open((size_t)P.nrounds, 0);      // local_open: local AND followed by another local round
+  if (local_max > 0) {      // (a workgroup of ONE wave — gas — has nobody to wait for: all of its rounds are local, whatever they hold)
+    int r = 0;
+    for (auto& kv : rounds) {
+      long recs = 0;
+      for (const Item& it : kv.second) recs += std::max(1, (it.count + upr - 1) / upr);
+      local[(size_t)r++] = P.nw == 1 || recs <= local_max;
+    }
+    for (int q = 0; q + 1 < P.nrounds; q++) local_open[(size_t)q] = local[(size_t)q] && local[(size_t)q + 1];
+  }
   // per-wave linear record streams: stream[w] = rows of 64 records of VM_REC_WORDS words
   std::vector<std::vector<uint32_t>> stream((size_t)P.nw);
   const uint32_t zoff = vm_off(zero_slot, 0);
@@ -362,7 +377,7 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
     auto nrec = [upr](const Item& it) { return std::max(1, (it.count + upr - 1) / upr); };
     std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return nrec(a) > nrec(b); });
     std::vector<int> row0;      // first record row of every item within its lane
-    std::vector<int> lane = deal(items, entries, nt, upr, row0);
+    std::vector<int> lane = deal(items, entries, nt, upr, row0, local[(size_t)ridx] ? 1 : 0);
     // The record that publishes a pivot's reciprocal carries an IEEE division (~150 cycles of dependent work) on top of its
     // row; every other wave then waits for it at the barrier.  Where the waves of a round do not all have the same number
     // of rows, that record goes to a wave with fewer: it swaps lanes with an equally long item there (no lane's row count
@@ -436,10 +451,14 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
       size_t n = 0;
       for (int l = 0; l < 64; l++) n = std::max(n, prog[(size_t)wv * 64 + l].size() / VM_REC_WORDS);
       if (n > 0xFFFF) throw std::logic_error("VM block too long");
+      if (local_open[(size_t)ridx] && wv > 0) {          // wave 0's own round, and its next one too: the others are not here
+        if (n != 0) throw std::logic_error("a local round has records outside wave 0");
+        continue;
+      }
       const size_t rows = std::max<size_t>(n, 1);       // a wave with no work still gets a null row carrying the round mark
       P.blk_n[(size_t)ridx * P.nw + wv] = (uint16_t)rows;
       for (size_t r = 0; r < rows; r++) {
-        uint32_t row_flags = (r == rows - 1 ? VM_ROW_EOR : 0u) | (n == 0 ? VM_ROW_NULL : 0u);
+        uint32_t row_flags = (r == rows - 1 ? VM_ROW_EOR | (local_open[(size_t)ridx] ? VM_ROW_LOCAL : 0u) : 0u) | (n == 0 ? VM_ROW_NULL : 0u);
         for (int l = 0; l < 64; l++) {
           const auto& w = prog[(size_t)wv * 64 + l];
           if (r * VM_REC_WORDS < w.size() &&
@@ -459,7 +478,19 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
       crit = std::max(crit, (int)rows);
     }
     P.crit_rows += crit;
+    P.nbarriers += local_open[(size_t)ridx] ? 0 : 1;
     ridx++;
+  }
+  // every wave must meet exactly nbarriers barriers (a mismatch would hang the workgroup): counted on the streams as built
+  for (int wv = 0; wv < P.nw; wv++) {
+    int eor = 0;
+    const std::vector<uint32_t>& st = stream[(size_t)wv];
+    for (size_t row = 0; row < st.size() / (64 * VM_REC_WORDS); row++) {
+      const uint32_t d1 = st[row * 64 * VM_REC_WORDS + 1];
+      if ((d1 & VM_ROW_LOCAL) && (!(d1 & VM_ROW_EOR) || wv != 0)) throw std::logic_error("local mark outside the end of a round of wave 0");
+      eor += (d1 & VM_ROW_EOR) && !(d1 & VM_ROW_LOCAL);
+    }
+    if (eor != P.nbarriers) throw std::logic_error("the waves of a VM program do not meet the same number of barriers");
   }
   // census: LDS-array cycles of the gathers as placed (per wave row: target read + write, six operand reads)
   for (int wv = 0; wv < P.nw; wv++) {
@@ -955,17 +986,23 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
   // the Schur steps multiply UNSCALED L slots with ROW-SCALED U slots: their pivots must be rows of the solves' tail chain
   if (dense_nd > 0 && S.tail.h > S.dense.jm) throw std::logic_error("the solves' tail chain must cover the dense block and its Schur pivots");
   const int dh = dense_nd > 0 ? S.dense.h : -1, djm = dense_nd > 0 ? S.dense.jm : -1;
+  // rounds small enough for wave 0 alone (build_vm_program: local rounds), in records
+  // (measured, same box, tools/ab_envs.sh: tot sweeps 0 / 128 / 192 / 512 records: 25 500 / 25 720 / 25 670 / 25 420 timesteps/s, tot LU 0 / 128 / 320:
+  //  25 700 / 25 670 / 25 410; aer LU 0 / 64 / 128 / 256: 61 790 / 62 040 / 61 700 / 60 730, aer sweeps 0 / 192: 61 500 / 61 700 — a round walked by one
+  //  wave is hardly cheaper than one walked by all: what a round costs is its chain of LDS round trips, not its barrier)
+  static const int local_lu = diag_env("MISTRA_DIAG_LOCAL_LU") ? std::atoi(diag_env("MISTRA_DIAG_LOCAL_LU")) : 64;
+  static const int local_sweep = diag_env("MISTRA_DIAG_LOCAL_SWEEP") ? std::atoi(diag_env("MISTRA_DIAG_LOCAL_SWEEP")) : 128;
   {
     // the scaling gets its own pass where there is enough of it (tot: 22 cells per thread, +2.7 %); for the small
     // mechanisms the extra pass's start-up costs more than the VM rows it replaces (gas -1.8 %, aer -0.6 %, measured)
     std::vector<std::pair<int, int>> pairs;
     (void)lu_entries(m, lay, true, S.tail.h, &pairs, dh, djm);
     if ((int)pairs.size() >= 16 * nt || dense_nd > 0) {     // (dense_lu reads scaled multipliers: always after a scaling pass)
-      S.lu = build_vm_program(lu_entries(m, lay, true, S.tail.h, &pairs, dh, djm), lay, nt);
+      S.lu = build_vm_program(lu_entries(m, lay, true, S.tail.h, &pairs, dh, djm), lay, nt, 2, VM_UPD_PER_REC, local_lu);
       pairs.resize(pairs.size() / 2);         // lu_entries appended the same list a second time
       S.lu_scale = build_scale_program(pairs, lay, nt);
     } else {
-      S.lu = build_vm_program(lu_entries(m, lay, true, S.tail.h, nullptr), lay, nt);
+      S.lu = build_vm_program(lu_entries(m, lay, true, S.tail.h, nullptr), lay, nt, 2, VM_UPD_PER_REC, local_lu);
     }
   }
   S.solve = build_vm_program(solve_entries(m, lay), lay, nt);
@@ -979,8 +1016,8 @@ KernelSchedule build_kernel_schedule(const MechTables& m, int nt, uint32_t ab_ba
     std::vector<VmEntry> bwd = solve_head_bwd_entries(m, lay, S.tail.h, bwd_split, S.n_temps, &bwd_temps);
     S.n_temps += bwd_temps;
     // the sweeps' updates are (L(i,j), 1.0, X(j)): the middle operand is dropped and a record holds three of them
-    S.solve_head_fwd = build_vm_program(std::move(fwd), lay, nt, 2, VM_SWEEP_UPD_PER_REC);
-    S.solve_head_bwd = build_vm_program(std::move(bwd), lay, nt, 2, VM_SWEEP_UPD_PER_REC);
+    S.solve_head_fwd = build_vm_program(std::move(fwd), lay, nt, 2, VM_SWEEP_UPD_PER_REC, local_sweep);
+    S.solve_head_bwd = build_vm_program(std::move(bwd), lay, nt, 2, VM_SWEEP_UPD_PER_REC, local_sweep);
   }
   return S;
 }

@@ -70,7 +70,9 @@ constexpr uint32_t VM_ROW_EOR = 1u << 24;    // every lane of a row: last row of
 constexpr uint32_t VM_ROW_NULL = 1u << 25;   // every lane of a row: the row carries no work (a wave with nothing to do in a round)
 constexpr uint32_t VM_ROW_AUX = 1u << 26;    // every lane of a row: some lane publishes a reciprocal OR scales by M[aux] != 1.0
                                              // cell; rows without the mark skip the aux read and the final multiply
-constexpr int VM_ROW_EOR_BIT = 24, VM_ROW_NULL_BIT = 25, VM_ROW_AUX_BIT = 26;
+constexpr uint32_t VM_ROW_LOCAL = 1u << 27;  // with VM_ROW_EOR, wave 0 only: the NEXT round is this wave's own too (a small round the other waves have no
+                                             // rows in): no barrier between them — the LDS operations of a wave complete in order
+constexpr int VM_ROW_EOR_BIT = 24, VM_ROW_NULL_BIT = 25, VM_ROW_AUX_BIT = 26, VM_ROW_LOCAL_BIT = 27;
 constexpr uint32_t VM_AUX_MASK = 0x00FFFFF8u;   // byte address part of d1
 constexpr int VM_REC_WORDS = 8;
 inline size_t vm_rec_index(size_t row, int lane, int k) { return row * 512 + (k < 4 ? 0 : 256) + (size_t)lane * 4 + (size_t)(k & 3); }
@@ -110,9 +112,11 @@ struct VmEntry {
 
 struct VmProgram {
   int nt = 0, nw = 0, nrounds = 0, zero_slot = 0;
+  int nbarriers = 0;                            // rounds that end in a workgroup barrier: what the executor counts (nrounds minus the local ones)
   int upd_per_rec = VM_UPD_PER_REC;             // 2: d2..d7 = (a1,r1,u1),(a2,r2,u2);  3: d2..d7 = (a1,u1),(a2,u2),(a3,u3), acc -= M[a]*M[u]
   std::vector<uint32_t> wave_base;              // [nw]  first record row of each wave's linear stream
-  std::vector<uint16_t> blk_n;                  // [nrounds*nw] record rows of (round, wave), null rows included (census / emulator)
+  std::vector<uint16_t> blk_n;                  // [nrounds*nw] record rows of (round, wave), null rows included (census / emulator); 0 = the wave skips
+                                                // the round (a local round of wave 0)
   std::vector<uint32_t> recs;                   // per row 512 words, PLANAR: words 0-3 of all 64 lanes, then words 4-7 of all
                                                 // lanes (vm_rec_index): each of the executor's two 16-byte loads per record then
                                                 // covers 16 whole cache lines instead of half of 32
@@ -231,7 +235,9 @@ struct KernelSchedule {
   DenseTail dense;                              // nd = 0: the mechanism runs without the dense tail block
 };
 
-VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 2, int upd_per_rec = VM_UPD_PER_REC);
+// local_max: rounds of at most this many records are walked by wave 0 alone, runs of them without a barrier in between (0: every round by all waves)
+VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, int nt, int merge_budget = 2, int upd_per_rec = VM_UPD_PER_REC,
+                           int local_max = 0);
 // with_rhs: also forward-sweep the vector held in XS while factorising (rows of an appended right-hand-side column)
 // scale_pairs: where to put the (tgt, aux) pairs of the final scaling; nullptr = keep them as a last phase of VM entries
 // dense_h >= 0: rows/columns [dense_h, n) are the dense tail block (DenseTail): the program leaves out the updates of

@@ -39,8 +39,15 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
     std::fill(writer.begin(), writer.end(), -1);
     std::vector<std::pair<int, int>> reads;   // (slot, lane)
     std::vector<double> snapshot = M;         // every lane of a round sees the pre-round memory of OTHER lanes
+    // a local round (wave 0 ends it with VM_ROW_LOCAL: no barrier) has no rows in the other waves
+    bool local_round = false;
+    if (P.blk_n[(size_t)r * P.nw] > 0) {
+      const size_t last = (size_t)P.wave_base[0] + row_of_wave[0] + P.blk_n[(size_t)r * P.nw] - 1;
+      local_round = (P.recs[vm_rec_index(last, 0, 1)] & VM_ROW_LOCAL) != 0;
+    }
     for (int w = 0; w < P.nw; w++) {
       const int n = P.blk_n[(size_t)r * P.nw + w];
+      if (local_round ? (w > 0 && n != 0) : n == 0) return -12;      // every wave meets every barrier, and only those
       const size_t base = (size_t)P.wave_base[(size_t)w] + row_of_wave[(size_t)w];
       row_of_wave[(size_t)w] += (uint32_t)n;
       for (int l = 0; l < 64; l++) {
@@ -52,6 +59,7 @@ static int run_vm(const VmProgram& P, std::vector<double>& M, int trash) {
           uint32_t rec[VM_REC_WORDS];
           for (int k = 0; k < VM_REC_WORDS; k++) rec[k] = P.recs[vm_rec_index(base + (size_t)ridx, l, k)];
           if ((rec[1] & VM_ROW_EOR) ? (ridx != n - 1) : (ridx == n - 1)) return -5;   // round mark on the wrong row
+          if ((rec[1] & VM_ROW_LOCAL) && (w != 0 || !(rec[1] & VM_ROW_EOR))) return -11;    // a local round is wave 0's
           if (rec[1] & VM_ROW_NULL) continue;
           auto rd = [&](uint32_t off) {
             const int i = (int)((off & VM_AUX_MASK) >> 3);

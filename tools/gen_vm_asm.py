@@ -179,11 +179,14 @@ def variant(n, upr=2):
         emit("ds_write_b64 %s, %%[acc]" % d(s, 0))
         emit("Lvm_eorb%d_%%=:" % s)
         refill(s)
+        emit("s_bitcmp1_b32 %%[fl%s], 27" % p)                    # VM_ROW_LOCAL: the next round is this wave's own (wave 0, a run of small rounds) -
+        emit("s_cbranch_scc1 Lvm_loc%d_%%=" % s)                  # no barrier: what it reads next, it has stored itself, and LDS is in-order within a wave
         emit("s_waitcnt lgkmcnt(0)")
         emit("s_barrier")
         emit("s_sub_u32 %[rounds], %[rounds], 1")
         emit("s_cmp_eq_u32 %[rounds], 0")
         emit("s_cbranch_scc1 Lvm_exit_%=")
+        emit("Lvm_loc%d_%%=:" % s)
         emit("s_waitcnt vmcnt(%d)" % vm_after)
         prefetch(t, q)
         emit("s_branch " + nxt)
