@@ -257,7 +257,7 @@ int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const dou
 
 /* The liq_parm kernels above on HOST buffers (same layouts, layer-major as the model holds them: every array of the reference has the
  * layer as its last dimension, so a run of layers kmin..kmax is handed over in place — ff(1,1,kmin), xkmt(1,1,kmin) ...): what the Fortran
- * shim calls (shim/mistra_kpp_liq.f90: FAST_K_MT_BATCH, HENRY_BATCH, V_MEAN_BATCH, ST_COEFF_BATCH, EQUIL_CO_BATCH; drop-ins with the reference's own signatures in
+ * shim calls (shim/mistra_kpp_liq.f90: FAST_K_MT_BATCH, HENRY_BATCH, V_MEAN_BATCH, ST_COEFF_BATCH, EQUIL_CO_BATCH, CW_RC_BATCH; drop-ins with the reference's own signatures in
  * shim/mistra_kpp_model.f90).  Synchronous; primary device. */
 int mistra_chem_fast_k_mt(int mech, int nlayer, const double* ff, const double* rq, const int32_t* kw, int nkw, int ka, int ifeed, int nkc_l,
                           const double* cw, const double* cm, const double* freep, const double* alpha, const double* vmean, double* xkmt,
@@ -265,6 +265,20 @@ int mistra_chem_fast_k_mt(int mech, int nlayer, const double* ff, const double* 
 int mistra_chem_henry(int mech, int nlayer, const double* tt, double* henry);
 int mistra_chem_v_mean(int mech, int nlayer, const double* tt, double* vmean);
 int mistra_chem_st_coeff(int mech, int nlayer, int lp_joyce14bc, int lp_buxmann15alph, const double* env, double* alpha);
+/* cw_rc (nmaxf) (kpp.f90:2152-2414; liq_parm calls it every time step, kpp.f90:609) and, with dry != 0, dry_cw_rc (nmax) (kpp.f90:4580-4690): liquid water
+ * content, mean radius, and — cw_rc — the water mass and the chemistry switch conv2 of the particle bins of nlayer layers, as moments of the
+ * two-dimensional particle spectrum summed in the reference's own order (bit-identical: tests/test_gpu_liq.py).  Mechanism-independent.  Host buffers,
+ * layer-major as the model holds them:
+ *   ff [nlayer][nka][nkt]     ff(1:nkt,1:nka,k) of /cb52/;  rq [nka][nkt], e [nkt]: /cb50/;  kw [nka], ka: /blck06/;  ifeed: module config
+ *   feu [nlayer]              relative humidity feu(k) of /cb54/;  cloud [nlayer][4]: cloud(1:nkc,k) of /kpp_l1/ as 0 | 1 (the hysteresis of bins 1, 2)
+ *   crys4 [4]                 xcryssulf, xcrysss, xdelisulf, xdeliss of /kpp_crys/
+ *   rc, cw, cm, conv2 [nlayer][4]   rc(:,k) of /blck11/, cw(:,k), cm(:,k) of /blck12/, conv2(:,k) of /blck13/;  with dry: rc, cw [nlayer][2] = rcd(:,k),
+ *                             cwd(:,k) of the dry-aerosol common blocks, and e, feu, cloud, crys4, cm, conv2, below are not touched (may be NULL)
+ *   below [nlayer]            1 where feu(k) < min(xcryssulf, xcrysss): the reference prints `k, feu(k), ' below both crystal. points'` for those
+ *                             layers up to kinv (the Fortran drop-in does, shim/mistra_kpp_model.f90); may be NULL
+ * cw_rc computes layers 2..nmaxf, dry_cw_rc nf+1..nmax: the caller hands over that run of layers. */
+int mistra_chem_cw_rc(int nlayer, int nkt, int nka, int dry, const double* ff, const double* rq, const double* e, const int32_t* kw, int ka, int ifeed,
+                      const double* feu, const int32_t* cloud, const double* crys4, double* rc, double* cw, double* cm, double* conv2, int32_t* below);
 int mistra_chem_equil_co(int mech, int nlayer, int nkc, int j6, const double* tt, const double* conv2, const double* xgamma, double* xkef,
                          double* xkeb);
 

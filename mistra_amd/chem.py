@@ -371,6 +371,28 @@ def v_mean(mech, tt, out):
     _check(lib().mistra_chem_v_mean_device(mid, out.shape[0], _p(tt), _p(out), _stream(out)))
 
 
+def cw_rc(ff, rq, e, kw, ka, ifeed, feu=None, cloud=None, crys4=None, dry=False):
+    """cw_rc (dry=False: -> rc, cw, cm, conv2 [nlayer, 4], below [nlayer]) or dry_cw_rc (dry=True: -> rcd, cwd [nlayer, 2]) for a batch of layers;
+    numpy arrays in and out (host-buffer entry, include/mistra_chem.h)."""
+    L = lib()
+    if not hasattr(L, "_cw_rc_typed"):
+        L.mistra_chem_cw_rc.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _ip, C.c_int, C.c_int, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _ip]
+        L._cw_rc_typed = True
+    ff = np.ascontiguousarray(ff, np.float64)
+    nl, nka, nkt = ff.shape
+    nb = 2 if dry else 4
+    f8 = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)
+    rq, e, feu, crys4 = f8(rq), f8(e), f8(feu), f8(crys4)
+    kw = np.ascontiguousarray(kw, np.int32)
+    cl = None if cloud is None else np.ascontiguousarray(cloud, np.int32)
+    rc, cw, cm, cv = (np.full((nl, nb), np.nan) for _ in range(4))
+    below = np.full(nl, -1, np.int32)
+    P = lambda a, t=_dp: None if a is None else a.ctypes.data_as(t)
+    _check(L.mistra_chem_cw_rc(nl, nkt, nka, int(bool(dry)), P(ff), P(rq), P(e), P(kw, _ip), int(ka), int(ifeed), P(feu), P(cl, _ip), P(crys4), P(rc), P(cw),
+                               P(cm), P(cv), P(below, _ip)))
+    return (rc, cw) if dry else (rc, cw, cm, cv, below)
+
+
 def st_coeff(mech, env, out, lp_joyce14bc=False, lp_buxmann15alph=False):
     """st_coeff_a (aer) / st_coeff_t (tot) for a batch of layers: out [nlayer, NSPEC] <- env [nlayer, 5] = t, cw(1), cm(1), sion1(13,1), sion1(14,1)
     (include/mistra_chem.h)."""

@@ -1186,6 +1186,38 @@ int mistra_chem_henry(int mech, int nlayer, const double* tt, double* henry) {
   return 0;
 }
 
+int mistra_chem_cw_rc(int nlayer, int nkt, int nka, int dry, const double* ff, const double* rq, const double* e, const int32_t* kw, int ka, int ifeed,
+                      const double* feu, const int32_t* cloud, const double* crys4, double* rc, double* cw, double* cm, double* conv2, int32_t* below) {
+  if (int rc0 = lazy_init()) return rc0;
+  if (nlayer == 0) return 0;
+  if (nlayer < 0 || nkt < 1 || nka < 1 || nkt > 4096 || nka > 4096 || ka < 0 || ka > nka) return fail("cw_rc: bad dimensions");
+  if (!ff || !rq || !kw || !rc || !cw || (!dry && (!e || !feu || !cloud || !crys4 || !cm || !conv2))) return fail("null pointer");
+  for (int i = 0; i < nka; i++)
+    if (kw[i] < 0 || kw[i] > nkt) return fail("kw out of range");      // the kernel's loop limits: checked here, on the host
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  HIP_TRY(hipSetDevice(D.id));
+  const size_t nl = (size_t)nlayer, grid = (size_t)nka * nkt, nb = dry ? 2 : 4, d8 = sizeof(double);
+  DevBlock B;
+  const size_t i_ff = B.add(nl * grid * d8), i_rq = B.add(grid * d8), i_e = B.add((size_t)nkt * d8), i_kw = B.add((size_t)nka * 4), i_feu = B.add(nl * d8),
+               i_cl = B.add(nl * 4 * 4), i_rc = B.add(nl * nb * d8), i_cw = B.add(nl * nb * d8), i_cm = B.add(nl * nb * d8), i_cv = B.add(nl * nb * d8),
+               i_bl = B.add(nl * 4);
+  HIP_TRY(B.alloc());
+  HIP_TRY(B.up(i_ff, ff)); HIP_TRY(B.up(i_rq, rq)); HIP_TRY(B.up(i_kw, kw));
+  if (!dry) { HIP_TRY(B.up(i_e, e)); HIP_TRY(B.up(i_feu, feu)); HIP_TRY(B.up(i_cl, cloud)); }
+  CwRcArgs A{};
+  A.nlayer = nlayer; A.nkt = nkt; A.nka = nka; A.ka = ka; A.ial = ifeed == 2 ? 2 : 1; A.dry = dry ? 1 : 0;
+  if (!dry) { A.xcryssulf = crys4[0]; A.xcrysss = crys4[1]; A.xdelisulf = crys4[2]; A.xdeliss = crys4[3]; }
+  A.kw = reinterpret_cast<const int32_t*>(B.dptr(i_kw)); A.ff = B.dptr(i_ff); A.rq = B.dptr(i_rq); A.e = B.dptr(i_e); A.feu = B.dptr(i_feu);
+  A.cloud = reinterpret_cast<const int32_t*>(B.dptr(i_cl)); A.rc = B.dptr(i_rc); A.cw = B.dptr(i_cw); A.cm = B.dptr(i_cm); A.conv2 = B.dptr(i_cv);
+  A.below = reinterpret_cast<int32_t*>(B.dptr(i_bl));
+  LAUNCH_TRY(launch_cw_rc(A, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.down(i_rc, rc)); HIP_TRY(B.down(i_cw, cw));
+  if (!dry) { HIP_TRY(B.down(i_cm, cm)); HIP_TRY(B.down(i_cv, conv2)); if (below) HIP_TRY(B.down(i_bl, below)); }
+  return 0;
+}
+
 int mistra_chem_st_coeff(int mech, int nlayer, int lp_joyce14bc, int lp_buxmann15alph, const double* env, double* alpha) {
   if (int rc = lazy_init()) return rc;
   if (int rc = check_call(mech, nlayer)) return rc;

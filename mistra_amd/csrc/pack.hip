@@ -256,6 +256,59 @@ __global__ __launch_bounds__(256) void equil_co_kernel(const LiqDev L, int nlaye
   xkeb[at] = liq_product(L, L.boff[e], L.foff[e + 1], T, cv2, xg);
 }
 
+// cw_rc (kpp.f90:2152-2414) | dry_cw_rc (kpp.f90:4580-4690): one thread per (layer, bin) walks the bin's part of the particle grid in the reference's
+// order — dry-aerosol classes ia ascending, droplet classes jt ascending inside — with the reference's three running sums: every sum is a serial chain
+// of ~1 200 additions whose order is its value, and a column of layers times four bins is parallel enough for what is a few microseconds of work.
+//   bin 1: ia <= ka, jt <= kw(ia)    bin 3: ia <= ka, jt > kw(ia)    bin 2: ia > ka, jt <= kw(ia)    bin 4: ia > ka, jt > kw(ia)
+//   x0 = ff*xpi*rq**3 (rq**3 as the compiler expands it: rq*rq*rq); cw += x0; rc += x0*rq; cm += ff*e(jt)
+// xpi = 4._dp/3._dp*pi in cw_rc and 4./3.*pi — a single-precision 4/3 — in dry_cw_rc.  One rounding per operation (-ffp-contract=off).
+__global__ __launch_bounds__(64) void cw_rc_kernel(const CwRcArgs A) {
+  constexpr double pi = 3.1415926535897932;                              // constants.f90:54
+  constexpr double cwm = 1.0e-1, cwmd = 1.0e2;                           // kpp.f90:2195-2196
+  const int nbin = A.dry ? 2 : 4;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, k = tid / 4, kc = tid % 4;
+  if (k >= A.nlayer || kc >= nbin) return;
+  const double xpi = A.dry ? (double)(4.0f / 3.0f) * pi : 4.0 / 3.0 * pi;
+  const bool small_ia = (kc == 0 || kc == 2);
+  const int ia0 = small_ia ? A.ial : A.ka + 1, ia1 = small_ia ? A.ka : A.nka;      // 1-based, inclusive
+  const double* ffk = A.ff + (size_t)k * A.nka * A.nkt;
+  double cws = 0.0, rcs = 0.0, cms = 0.0;
+  for (int ia = ia0; ia <= ia1; ia++) {
+    const int kwa = A.kw[ia - 1];
+    const int jt0 = kc < 2 ? 1 : kwa + 1, jt1 = kc < 2 ? kwa : A.nkt;
+    for (int jt = jt0; jt <= jt1; jt++) {
+      const double f = ffk[(size_t)(ia - 1) * A.nkt + (jt - 1)], r = A.rq[(size_t)(ia - 1) * A.nkt + (jt - 1)];
+      const double x0 = (f * xpi) * ((r * r) * r);
+      cws = cws + x0;
+      rcs = rcs + x0 * r;
+      if (!A.dry) cms = cms + f * A.e[jt - 1];
+    }
+  }
+  const size_t at = (size_t)k * nbin + kc;
+  A.rc[at] = cws > 0.0 ? (rcs / cws) * 1.0e-6 : 0.0;
+  A.cw[at] = cws * 1.0e-12;
+  if (A.dry) return;
+  const double feu = A.feu[k];
+  const double xmin = A.xcryssulf < A.xcrysss ? A.xcryssulf : A.xcrysss;      // min(xcryssulf,xcrysss)
+  bool on;
+  if (feu < xmin) {
+    on = false;
+    if (kc == 0) A.below[k] = 1;
+  } else {
+    if (kc == 0) A.below[k] = 0;
+    if (kc == 0) on = cws >= cwm && ((A.cloud[(size_t)k * 4 + 0] != 0 && feu >= A.xcryssulf) || feu >= A.xdelisulf);
+    else if (kc == 1) on = cws >= cwm && ((A.cloud[(size_t)k * 4 + 1] != 0 && feu >= A.xcrysss) || feu >= A.xdeliss);
+    else on = cws >= cwmd;
+  }
+  A.cm[at] = on ? cms * 1.0e-3 : 0.0;
+  A.conv2[at] = on ? 1.0e9 / cws : 0.0;
+}
+hipError_t launch_cw_rc(const CwRcArgs& A, hipStream_t stream) {
+  if (A.nlayer <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cw_rc_kernel, dim3((unsigned)((A.nlayer * 4 + 63) / 64)), dim3(64), 0, stream, A);
+  return hipGetLastError();
+}
+
 // v_mean_a | v_mean_t (kpp.f90:1472-1670 | 1268-1465): the mean molecular speed sqrt(8 R T / (pi M)) as the reference writes it,
 // func(a,k) = sqrt(tt(k)/a)*4.60138 (the factor a default-real literal), one thread per (layer, species); a species the routine does not
 // set stays 0 (`vmean(:,:) = 0._dp`).  Quotient, square root and product each round once, as compiled Fortran does: bit-identical.

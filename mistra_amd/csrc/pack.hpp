@@ -81,6 +81,19 @@ struct LiqDev {
   double henry_tref, henry_fct, equil_tref;
 };
 hipError_t launch_henry(const LiqDev& L, int nlayer, const double* tt, double* henry, hipStream_t stream);
+// ---- liquid water content, mean radius and the chemistry switches of the four particle bins (kpp.f90: cw_rc 2152-2414; dry_cw_rc 4580-4690 for the
+//      layers above the chemistry levels): moments of the two-dimensional particle spectrum ff, summed in the reference's own order
+struct CwRcArgs {
+  int nlayer, nkt, nka, ka, ial;      // ial: first dry-aerosol class that counts (2 where ifeed = 2, else 1)
+  int dry;                            // 0: cw_rc (four bins, cm and conv2 with the crystallisation / deliquescence switches); 1: dry_cw_rc (rcd, cwd of bins 1, 2)
+  double xcryssulf, xcrysss, xdelisulf, xdeliss;
+  const int32_t* kw;                  // [nka]
+  const double *ff, *rq, *e, *feu;    // ff [nlayer][nka][nkt], rq [nka][nkt], e [nkt], feu [nlayer]
+  const int32_t* cloud;               // [nlayer][nkc]: cloud(kc,k) of /kpp_l1/ as 0 | 1 (bins 1, 2 are read)
+  double *rc, *cw, *cm, *conv2;       // [nlayer][nkc] each (dry: rc, cw are [nlayer][2] = rcd, cwd; cm, conv2 unused)
+  int32_t* below;                     // [nlayer]: 1 where feu < min(xcryssulf, xcrysss) (the reference prints a line for those below the inversion)
+};
+hipError_t launch_cw_rc(const CwRcArgs& A, hipStream_t stream);
 // ---- mean molecular speeds (kpp.f90: v_mean_a 1472-1670, v_mean_t 1268-1465).  Table: mistra_amd/mech/<mech>.vmean (tools/extract_vmean.py).
 struct VmeanTable {
   int nspec = 0;

@@ -60,6 +60,103 @@ int lds_pass_cycles(const int* cell64) {
   return total;
 }
 
+// The deal of rounds 1-3, kept for the eight-wave workgroups (tot), where it measured 0.4 % faster than the longest-first deal below although
+// its rounds are a quarter longer in rows (same box, round 4; for four waves and one the longest-first deal wins: aer +0.3 %, gas +3.7 %).
+// Deal the items of one round (sorted by decreasing record count) over lanes.  Lane LOADS follow the snake deal (pass p
+// gives every lane its p-th item, alternate passes run backwards); small sets are packed into few waves.  WHICH item of a
+// run of equally long items goes to which lane of the pass is chosen against LDS bank conflicts: the dense LU rounds are
+// bound by the LDS pipe, whose gathers cost ~4 array cycles per wave instruction when the 32 lanes of a pass are
+// thrown at the banks at random and 1 when they are spread.  Records of one pass sit in (nearly) the same rows of
+// their lanes, i.e. are issued together; an item goes to the half-wave in which its operand cells meet the fewest
+// distinct cells of their bank classes already placed there.
+std::vector<int> deal_snake(const std::vector<Item>& items, const std::vector<VmEntry>& entries, int nt, int upr, std::vector<int>& row0) {
+  const int n = (int)items.size();
+  std::vector<int> lane((size_t)n);
+  static const bool plain_deal = diag_env("MISTRA_DIAG_PLAIN_DEAL") != nullptr;   // A/B diagnostic: positions as sorted
+  const int waves_used = std::max(1, std::min(nt / 64, (n + 63) / 64));
+  const int lanes = waves_used * 64, groups = lanes / 32;
+  auto nrec = [upr](const Item& it) { return std::max(1, (it.count + upr - 1) / upr); };
+  struct Slot { std::vector<uint16_t> cells; int cnt[32]; };
+  for (int p0 = 0; p0 < n; p0 += lanes) {                 // one pass
+    const int pn = std::min(lanes, n - p0), pass = p0 / lanes;
+    std::vector<int> pos_lane((size_t)pn);
+    for (int j = 0; j < pn; j++) pos_lane[(size_t)j] = (pass & 1) ? (lanes - 1 - j) : j;
+    const int rmax = nrec(items[(size_t)p0]);
+    std::vector<Slot> slot((size_t)groups * rmax * 7);      // [group][record][operand]: cells present, per bank class
+    for (Slot& sl : slot) std::fill(sl.cnt, sl.cnt + 32, 0);
+    auto operands = [&](const Item& it, int r, int* cell /*7*/) {
+      const VmEntry& E = entries[(size_t)it.entry];
+      cell[0] = E.tgt;
+      const int per = upr == 2 ? 3 : 2;      // operand cells per update: (a, r, u), or (a, u) in records of three updates
+      for (int u = 0; u < upr; u++) {
+        const int i = r * upr + u;
+        if (i < it.count) {
+          const VmUpd& up = E.upd[(size_t)(it.first + i)];
+          cell[1 + per * u] = up.a;
+          if (upr == 2) { cell[2 + 3 * u] = up.r; cell[3 + 3 * u] = up.u; }
+          else cell[2 + 2 * u] = up.u;
+        } else {
+          for (int o = 0; o < per; o++) cell[1 + per * u + o] = -1;      // the 0.0 cell in every lane: broadcast
+        }
+      }
+    };
+    for (int j0 = 0; j0 < pn;) {                          // one run of equally long items
+      int j1 = j0;
+      while (j1 < pn && nrec(items[(size_t)(p0 + j1)]) == nrec(items[(size_t)(p0 + j0)])) j1++;
+      const int nr = nrec(items[(size_t)(p0 + j0)]);
+      std::vector<std::vector<int>> free_lanes((size_t)groups);      // lanes of this run, by half-wave
+      for (int j = j0; j < j1; j++) free_lanes[(size_t)(pos_lane[(size_t)j] / 32)].push_back(pos_lane[(size_t)j]);
+      for (int j = j0; j < j1; j++) {
+        const Item& it = items[(size_t)(p0 + j)];
+        int best = -1, best_cost = 0;
+        for (int g = 0; g < groups; g++) {
+          if (free_lanes[(size_t)g].empty()) continue;
+          int cost = 0;
+          for (int r = 0; r < nr; r++) {
+            int cell[7];
+            operands(it, r, cell);
+            for (int o = 0; o < 7; o++) {
+              if (cell[o] < 0) continue;
+              const Slot& sl = slot[((size_t)g * rmax + r) * 7 + o];
+              if (std::find(sl.cells.begin(), sl.cells.end(), (uint16_t)cell[o]) != sl.cells.end()) continue;   // broadcast
+              cost += (o == 0 ? 2 : 1) * sl.cnt[bank_class(cell[o])];      // the target is read and written
+            }
+          }
+          if (best < 0 || cost < best_cost) { best = g; best_cost = cost; }
+        }
+        if (plain_deal) best = pos_lane[(size_t)j] / 32;
+        if (plain_deal) {
+          std::vector<int>& fl = free_lanes[(size_t)best];
+          fl.erase(std::find(fl.begin(), fl.end(), pos_lane[(size_t)j]));
+          lane[(size_t)(p0 + j)] = pos_lane[(size_t)j];
+        } else {
+          lane[(size_t)(p0 + j)] = free_lanes[(size_t)best].back();
+          free_lanes[(size_t)best].pop_back();
+        }
+        for (int r = 0; r < nr; r++) {
+          int cell[7];
+          operands(it, r, cell);
+          for (int o = 0; o < 7; o++) {
+            if (cell[o] < 0) continue;
+            Slot& sl = slot[((size_t)best * rmax + r) * 7 + o];
+            if (std::find(sl.cells.begin(), sl.cells.end(), (uint16_t)cell[o]) != sl.cells.end()) continue;
+            sl.cells.push_back((uint16_t)cell[o]);
+            sl.cnt[bank_class(cell[o])]++;
+          }
+        }
+      }
+      j0 = j1;
+    }
+  }
+  // first rows: a lane walks its items in the order dealt
+  row0.assign((size_t)n, 0);
+  {
+    std::vector<int> ld((size_t)lanes, 0);
+    for (int k = 0; k < n; k++) { row0[(size_t)k] = ld[(size_t)lane[(size_t)k]]; ld[(size_t)lane[(size_t)k]] += nrec(items[(size_t)k]); }
+  }
+  return lane;
+}
+
 // Deal the items of one round (sorted by decreasing record count) over lanes.  row0: the items' first record rows within their lanes
 // (a lane walks its items in the order of their rows).
 //   * Rows: longest-first into lanes that still have room under the bound R = max(longest item, records / lanes) keeps every lane at
@@ -377,13 +474,15 @@ VmProgram build_vm_program(std::vector<VmEntry> entries, const VmLayout& lay, in
     auto nrec = [upr](const Item& it) { return std::max(1, (it.count + upr - 1) / upr); };
     std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) { return nrec(a) > nrec(b); });
     std::vector<int> row0;      // first record row of every item within its lane
-    std::vector<int> lane = deal(items, entries, nt, upr, row0, local[(size_t)ridx] ? 1 : 0);
+    static const bool lpt_everywhere = diag_env("MISTRA_DIAG_LPT_DEAL") != nullptr;      // A/B diagnostic
+    const bool snake = nt / 64 >= 8 && !local[(size_t)ridx] && !lpt_everywhere;
+    std::vector<int> lane = snake ? deal_snake(items, entries, nt, upr, row0) : deal(items, entries, nt, upr, row0, local[(size_t)ridx] ? 1 : 0);
     // The record that publishes a pivot's reciprocal carries an IEEE division (~150 cycles of dependent work) on top of its
     // row; every other wave then waits for it at the barrier.  Where the waves of a round do not all have the same number
     // of rows, that record goes to a wave with fewer: it swaps lanes with an equally long item there (no lane's row count
     // changes), and the division runs while the fuller waves walk their extra row.
     {
-      static const bool no_rcp_move = diag_env("MISTRA_DIAG_PLAIN_DEAL") == nullptr || diag_env("MISTRA_DIAG_NO_RCP_MOVE") != nullptr;     // (the deal places these items itself; the move belongs to the snake deal kept for A/B runs)
+      const bool no_rcp_move = !(snake || diag_env("MISTRA_DIAG_PLAIN_DEAL") != nullptr) || diag_env("MISTRA_DIAG_NO_RCP_MOVE") != nullptr;     // (the longest-first deal places these items itself; the move belongs to the snake deal)
       std::vector<int> lane_rows((size_t)nt, 0);
       for (size_t k = 0; k < items.size(); k++) lane_rows[(size_t)lane[k]] += nrec(items[k]);
       const int nw = nt / 64;

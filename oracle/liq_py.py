@@ -71,3 +71,42 @@ def equil_co_layer(tab, tt, conv2, xgamma, xkef, xkeb):
             ef[kc, :] = 0.0
             eb[kc, :] = 0.0
     return ef, eb
+
+
+def cw_rc_layer(ff, rq, e, kw, ka, ifeed, feu=None, cloud=None, crys4=None, dry=False):
+    """cw_rc (kpp.f90:2152-2414) | dry_cw_rc (kpp.f90:4580-4690) for ONE layer: ff [nka][nkt] = ff(1:nkt,1:nka,k) transposed as the model holds it,
+    rq [nka][nkt], e [nkt], kw [nka] (1-based jt limits), ka.  -> rc, cw, cm, conv2 [4] and the 'below both crystallisation points' flag; dry: rcd, cwd [2].
+    The reference's loops and running sums, one rounding per operation."""
+    nka, nkt = ff.shape
+    pi = 3.1415926535897932
+    xpi = float(np.float32(4.0) / np.float32(3.0)) * pi if dry else 4.0 / 3.0 * pi       # dry_cw_rc: 4./3.*pi, a single-precision quotient
+    ial = 2 if ifeed == 2 else 1
+    nb = 2 if dry else 4
+    cws, rcs, cms = [0.0] * 4, [0.0] * 4, [0.0] * 4
+    for kc in range(nb):
+        small = kc in (0, 2)
+        for ia in range(ial if small else ka + 1, (ka if small else nka) + 1):
+            kwa = int(kw[ia - 1])
+            for jt in (range(1, kwa + 1) if kc < 2 else range(kwa + 1, nkt + 1)):
+                f, r = float(ff[ia - 1, jt - 1]), float(rq[ia - 1, jt - 1])
+                x0 = (f * xpi) * ((r * r) * r)
+                cws[kc] = cws[kc] + x0
+                rcs[kc] = rcs[kc] + x0 * r
+                if not dry:
+                    cms[kc] = cms[kc] + f * float(e[jt - 1])
+    rc = np.array([(rcs[kc] / cws[kc]) * 1.0e-6 if cws[kc] > 0.0 else 0.0 for kc in range(nb)])
+    cw = np.array([cws[kc] * 1.0e-12 for kc in range(nb)])
+    if dry:
+        return rc, cw
+    cwm, cwmd = 1.0e-1, 1.0e2
+    xcryssulf, xcrysss, xdelisulf, xdeliss = (float(x) for x in crys4)
+    cm, conv2 = np.zeros(4), np.zeros(4)
+    below = feu < min(xcryssulf, xcrysss)
+    if not below:
+        on = [cws[0] >= cwm and ((bool(cloud[0]) and feu >= xcryssulf) or feu >= xdelisulf),
+              cws[1] >= cwm and ((bool(cloud[1]) and feu >= xcrysss) or feu >= xdeliss), cws[2] >= cwmd, cws[3] >= cwmd]
+        for kc in range(4):
+            if on[kc]:
+                cm[kc] = cms[kc] * 1.0e-3
+                conv2[kc] = 1.0e9 / cws[kc]
+    return rc, cw, cm, conv2, int(below)

@@ -1,8 +1,9 @@
-! Fortran side of liq_parm's table-driven kernels on the GPU (SURVEY.md §8 f3; include/mistra_chem.h: mistra_chem_fast_k_mt, _henry, _v_mean, _st_coeff, _equil_co):
+! Fortran side of liq_parm's table-driven kernels on the GPU (SURVEY.md §8 f3; include/mistra_chem.h: mistra_chem_fast_k_mt, _henry, _v_mean, _st_coeff, _equil_co, _cw_rc):
 !   FAST_K_MT_BATCH   fast_k_mt_a (kpp.f90:2683-2947) | fast_k_mt_t (kpp.f90:2421-2676): xkmt AND the sedimentation velocity vt, every 120 s
 !   HENRY_BATCH       henry_a (kpp.f90:1914-2145)     | henry_t (kpp.f90:1676-1907): the inverse dimensionless Henry constants, every step
 !   V_MEAN_BATCH      v_mean_a (kpp.f90:1472-1670)    | v_mean_t (kpp.f90:1268-1465): the mean molecular speeds, every step
 !   ST_COEFF_BATCH    st_coeff_a (kpp.f90:857-1038)   | st_coeff_t (kpp.f90:664-851): the accommodation coefficients alpha, every step
+!   CW_RC_BATCH       cw_rc (kpp.f90:2152-2414) | dry_cw_rc (kpp.f90:4580-4690): liquid water, mean radius, water mass and chemistry switch of the particle bins
 !   EQUIL_CO_BATCH    equil_co_a (kpp.f90:3162-3363)  | equil_co_t (kpp.f90:2954-3155): forward / backward equilibrium rate constants, every step
 ! for a run of consecutive layers.  Every array of the reference has the layer as its LAST dimension, so the caller hands over the model
 ! arrays in place, starting at the first layer of the run: ff(1,1,kmin), xkmt(1,1,kmin), cw(1,kmin), freep(kmin) ... (drop-ins with the
@@ -42,6 +43,16 @@ module mistra_kpp_liq
        real(c_double) :: alpha(*)
        integer(c_int) :: rc
      end function mistra_chem_st_coeff
+     function mistra_chem_cw_rc(nlayer, nkt, nka, dry, ff, rq, e, kw, ka, ifeed, feu, cloud, crys4, rc, cw, cm, conv2, below) &
+          bind(C, name="mistra_chem_cw_rc") result(ret)
+       import :: c_int, c_int32_t, c_double
+       integer(c_int), value :: nlayer, nkt, nka, dry, ka, ifeed
+       real(c_double), intent(in) :: ff(*), rq(*), e(*), feu(*), crys4(4)
+       integer(c_int32_t), intent(in) :: kw(*), cloud(*)
+       real(c_double) :: rc(*), cw(*), cm(*), conv2(*)
+       integer(c_int32_t) :: below(*)
+       integer(c_int) :: ret
+     end function mistra_chem_cw_rc
      function mistra_chem_equil_co(mech, nlayer, nkc, j6, tt, conv2, xgamma, xkef, xkeb) bind(C, name="mistra_chem_equil_co") result(rc)
        import :: c_int, c_double
        integer(c_int), value :: mech, nlayer, nkc, j6
@@ -90,6 +101,23 @@ contains
     if (mistra_chem_st_coeff(int(mech - 1, c_int), int(nlayer, c_int), merge(1_c_int, 0_c_int, lpJoyce14bc), merge(1_c_int, 0_c_int, lpBuxmann15alph), &
                              env, alpha) /= 0) call mistra_chem_fail('ST_COEFF_BATCH')
   end subroutine ST_COEFF_BATCH
+
+  ! ff(nkt,nka,nlayer), rq(nkt,nka), e(nkt), kw(nka), feu(nlayer), cloud(4,nlayer) (0 | 1), crys4 = xcryssulf, xcrysss, xdelisulf, xdeliss
+  ! -> rc, cw, cm, conv2 (4,nlayer), below(nlayer); dry: rc, cw (2,nlayer) = rcd, cwd, the rest untouched
+  subroutine CW_RC_BATCH(nlayer, nkt, nka, dry, ff, rq, e, kw, ka, ifeed, feu, cloud, crys4, rc, cw, cm, conv2, below)
+    integer, intent(in) :: nlayer, nkt, nka, kw(nka), ka, ifeed, cloud(*)
+    logical, intent(in) :: dry
+    real(c_double), intent(in) :: ff(*), rq(*), e(*), feu(*), crys4(4)
+    real(c_double) :: rc(*), cw(*), cm(*), conv2(*)
+    integer :: below(*)
+    integer(c_int32_t), allocatable :: cl(:), bl(:)
+    if (nlayer <= 0) return
+    allocate (cl(4 * nlayer), bl(nlayer))
+    if (.not. dry) cl = int(cloud(1:4 * nlayer), c_int32_t)
+    if (mistra_chem_cw_rc(int(nlayer, c_int), int(nkt, c_int), int(nka, c_int), merge(1_c_int, 0_c_int, dry), ff, rq, e, int(kw, c_int32_t), int(ka, c_int), &
+                          int(ifeed, c_int), feu, cl, crys4, rc, cw, cm, conv2, bl) /= 0) call mistra_chem_fail('CW_RC_BATCH')
+    if (.not. dry) below(1:nlayer) = bl
+  end subroutine CW_RC_BATCH
 
   ! tt(nlayer), conv2(nkc,nlayer), xgamma(j6,nkc,nlayer) -> xkef, xkeb(NSPEC,nkc,nlayer) in/out
   subroutine EQUIL_CO_BATCH(mech, nlayer, nkc, j6, tt, conv2, xgamma, xkef, xkeb)

@@ -108,6 +108,55 @@ subroutine HENRY_HIP_a(tt, nmaxf)                  ! henry_a (tt,nmaxf), kpp.f90
   call HENRY_BATCH(2, nmaxf, tt, henry)
 end subroutine HENRY_HIP_a
 
+subroutine CW_RC_HIP(nmaxf)                        ! cw_rc (nmaxf), kpp.f90:2152: layers 2..nmaxf
+  USE config, ONLY : ifeed
+  USE global_params, ONLY : n, nka, nkt, nkc
+  USE mistra_kpp_liq, ONLY : CW_RC_BATCH
+  implicit none
+  integer, intent(in) :: nmaxf
+  integer :: kw, ka, nar, kinv, k, cl(nkc, n), below(n)
+  double precision :: rc, cw, cm, conv2, enw, ew, rn, rw, en, e, dew, rq, ff, fsum, xm1, xm2, feu, dfddt, xm1a, xcryssulf, xcrysss, xdelisulf, xdeliss
+  logical :: cloud
+  common /blck06/ kw(nka), ka
+  common /blck11/ rc(nkc,n)
+  common /blck12/ cw(nkc,n), cm(nkc,n)
+  common /blck13/ conv2(nkc,n)
+  common /cb50/ enw(nka), ew(nkt), rn(nka), rw(nkt,nka), en(nka), e(nkt), dew(nkt), rq(nkt,nka)
+  common /cb52/ ff(nkt,nka,n), fsum(n), nar(n)
+  common /cb54/ xm1(n), xm2(n), feu(n), dfddt(n), xm1a(n)
+  common /kpp_l1/ cloud(nkc,n)
+  common /kpp_crys/ xcryssulf, xcrysss, xdelisulf, xdeliss
+  common /kinv_i/ kinv
+  if (nmaxf < 2) return
+  cl = merge(1, 0, cloud)
+  call CW_RC_BATCH(nmaxf - 1, nkt, nka, .false., ff(1,1,2), rq, e, kw, ka, ifeed, feu(2), cl(1,2), [xcryssulf, xcrysss, xdelisulf, xdeliss], &
+                   rc(1,2), cw(1,2), cm(1,2), conv2(1,2), below(2))
+  do k = 2, nmaxf                                 ! kpp.f90:2335
+     if (below(k) /= 0 .and. k <= kinv) print *, k, feu(k), ' below both crystal. points'
+  end do
+end subroutine CW_RC_HIP
+
+subroutine DRY_CW_RC_HIP(nmax)                     ! dry_cw_rc (nmax), kpp.f90:4580: layers nf+1..nmax, bins 1 and 2 of rc / cw
+  USE config, ONLY : ifeed
+  USE global_params, ONLY : nf, n, nka, nkt, nkc
+  USE mistra_kpp_liq, ONLY : CW_RC_BATCH
+  implicit none
+  integer, intent(in) :: nmax
+  integer :: kw, ka, nar, k, idum(1)
+  double precision :: rc, cw, cm, enw, ew, rn, rw, en, e, dew, rq, ff, fsum, rcd(2, n), cwd(2, n), ddum(4)
+  common /blck06/ kw(nka), ka
+  common /blck11/ rc(nkc,n)
+  common /blck12/ cw(nkc,n), cm(nkc,n)
+  common /cb50/ enw(nka), ew(nkt), rn(nka), rw(nkt,nka), en(nka), e(nkt), dew(nkt), rq(nkt,nka)
+  common /cb52/ ff(nkt,nka,n), fsum(n), nar(n)
+  if (nmax <= nf) return
+  call CW_RC_BATCH(nmax - nf, nkt, nka, .true., ff(1,1,nf+1), rq, e, kw, ka, ifeed, ddum, idum, ddum, rcd(1,nf+1), cwd(1,nf+1), ddum, ddum, idum)
+  do k = nf + 1, nmax
+     rc(1:2,k) = rcd(:,k)
+     cw(1:2,k) = cwd(:,k)
+  end do
+end subroutine DRY_CW_RC_HIP
+
 subroutine ST_COEFF_HIP_t                          ! st_coeff_t, kpp.f90:664: layers 2..nf, layer 1 keeps the default
   USE config, ONLY : lpBuxmann15alph, lpJoyce14bc
   USE global_params, ONLY : j2, j6, nf, n, nkc

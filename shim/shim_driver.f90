@@ -17,9 +17,9 @@
 !                                                      sl1(121,4,n) sion1(55,4,n) bg(2,nrxn,nlev) bgs(2,122,n) | per layer: mech, k, air, h2o, env(nenv).
 !                                                      out.bin: the arrays after the step | per layer ierr, 8 statistics, texit, hexit | per repetition
 !                                                      the wall times (ms) of the staging loop and of the device call(s)
-!          shim_driver <Ka|Kt|Ha|Ht|Va|Vt|Sa|St|Qa|Qt> <in.bin> <out.bin>   liq_parm's kernels through shim/mistra_kpp_liq.f90 (SURVEY §8 f3): K = FAST_K_MT_BATCH
+!          shim_driver <Ka|Kt|Ha|Ht|Va|Vt|Sa|St|Qa|Qt|Ca> <in.bin> <out.bin>   liq_parm's kernels through shim/mistra_kpp_liq.f90 (SURVEY §8 f3): K = FAST_K_MT_BATCH
 !                                                      (in: nlayer, nka, nkt, nkc, nspec, ka, ifeed, nkc_l | kw | rq | ff cw cm freep alpha vmean xkmt t p vt;
-!                                                      out: xkmt, vt), H = HENRY_BATCH (in: nlayer, nspec | tt; out: henry), V = V_MEAN_BATCH (the same shapes; out: vmean), S = ST_COEFF_BATCH (in: nlayer, nspec, lpJoyce14bc, lpBuxmann15alph | env(5,nlayer); out: alpha), Q = EQUIL_CO_BATCH (in: nlayer,
+!                                                      out: xkmt, vt), H = HENRY_BATCH (in: nlayer, nspec | tt; out: henry), V = V_MEAN_BATCH (the same shapes; out: vmean), S = ST_COEFF_BATCH (in: nlayer, nspec, lpJoyce14bc, lpBuxmann15alph | env(5,nlayer); out: alpha), C = CW_RC_BATCH (in: nlayer, nkt, nka, dry, ka, ifeed | kw, rq, e, crys4, ff, feu, cloud; out: rc, cw, cm, conv2, below), Q = EQUIL_CO_BATCH (in: nlayer,
 !                                                      nkc, j6, nspec | tt conv2 xgamma xkef xkeb; out: xkef, xkeb)
 ! After the call the one-cell mode also writes ATOL(1), RTOL(1) (INTEGRATE_x resets them, gas.f:745-746).
 program shim_driver
@@ -37,7 +37,7 @@ program shim_driver
   case ('A'); call run_batch(1, 257, 5, 979, trim(fin), trim(fout))
   case ('T'); call run_batch(2, 417, 7, 1627, trim(fin), trim(fout))
   case ('D'); call run_drive(trim(fin), trim(fout))
-  case ('K', 'H', 'Q', 'V', 'S')
+  case ('K', 'H', 'Q', 'V', 'S', 'C')
      select case (a1(2:2))
      case ('a'); call run_liq(a1(1:1), 2, trim(fin), trim(fout))
      case ('t'); call run_liq(a1(1:1), 3, trim(fin), trim(fout))
@@ -241,6 +241,8 @@ contains
        alpha = -7.d0
        call ST_COEFF_BATCH(mech, nl, h(3) /= 0.d0, h(4) /= 0.d0, t, alpha)
        write (12) alpha
+    case ('C')
+       call run_cw_rc()
     case ('Q')
        read (11) h(1:4)
        nl = int(h(1)); nkc = int(h(2)); j6 = int(h(3)); nspec = int(h(4))
@@ -251,6 +253,25 @@ contains
     end select
     close (11); close (12)
   end subroutine run_liq
+  subroutine run_cw_rc()      ! (units 11 and 12 are open)
+    use mistra_kpp_liq
+    double precision :: h(6), crys4(4)
+    integer :: nl, nkt, nka, ka, ifeed, nb
+    logical :: dry
+    integer, allocatable :: kw(:), cloud(:), below(:)
+    double precision, allocatable :: tmp(:), rq(:), e(:), ff(:), feu(:), rc(:), cw(:), cm(:), conv2(:)
+    read (11) h
+    nl = int(h(1)); nkt = int(h(2)); nka = int(h(3)); dry = h(4) /= 0.d0; ka = int(h(5)); ifeed = int(h(6))
+    nb = merge(2, 4, dry)
+    allocate (tmp(nka), kw(nka), rq(nkt * nka), e(nkt), ff(nkt * nka * nl), feu(nl), cloud(4 * nl), below(nl), rc(nb * nl), cw(nb * nl), cm(nb * nl), conv2(nb * nl))
+    read (11) tmp; kw = int(tmp)
+    read (11) rq, e, crys4, ff, feu
+    deallocate (tmp); allocate (tmp(4 * nl))
+    read (11) tmp; cloud = int(tmp)
+    rc = -7.d0; cw = -7.d0; cm = -7.d0; conv2 = -7.d0; below = -7
+    call CW_RC_BATCH(nl, nkt, nka, dry, ff, rq, e, kw, ka, ifeed, feu, cloud, crys4, rc, cw, cm, conv2, below)
+    write (12) rc, cw, cm, conv2, dble(below)
+  end subroutine run_cw_rc
   subroutine run_drive(fin, fout)
     use mistra_kpp_drive
     character(len=*), intent(in) :: fin, fout

@@ -122,3 +122,19 @@ def test_accommodation_coefficients_on_the_device(mech):
             assert len(plain) > 200 and np.array_equal(got[:, plain], want[:, plain])
     with pytest.raises(chem.MistraChemError):
         chem.st_coeff("gas", torch.zeros((1, 5), dtype=torch.float64, device=dev), torch.zeros((1, 105), dtype=torch.float64, device=dev))
+
+
+def test_particle_bin_moments_on_the_device():
+    """cw_rc (kpp.f90:2152-2414) and dry_cw_rc (kpp.f90:4580-4690) from mistra_chem_cw_rc against the layers captured from the running reference model
+    (tests/golden/cwrc.npz): every output bit for bit (serial sums in the reference's order, no library function), the whole arrays written."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from mistra_amd import chem
+    chem.init(0)
+    g = np.load(os.path.join(REPO, "tests", "golden", "cwrc.npz"))
+    rc, cw, cm, cv, below = chem.cw_rc(g["wet_ff"], g["rq"], g["e"], g["kw"], int(g["ka"]), int(g["ifeed"]), g["wet_feu"], g["wet_cloud"], g["crys4"])
+    for got, key in ((rc, "rc"), (cw, "cw"), (cm, "cm"), (cv, "conv2")):
+        assert np.array_equal(got, g["wet_" + key]), key
+    assert np.array_equal(below, (g["wet_feu"] < g["crys4"][:2].min()).astype(np.int32))
+    rcd, cwd = chem.cw_rc(g["dry_ff"], g["rq"], g["e"], g["kw"], int(g["ka"]), int(g["ifeed"]), dry=True)
+    assert np.array_equal(rcd, g["dry_rc"][:, :2]) and np.array_equal(cwd, g["dry_cw"][:, :2])

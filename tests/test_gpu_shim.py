@@ -256,3 +256,27 @@ def test_fortran_liq_parm_kernels(mech, tmp_path):
     for got, want in ((ef, g["xkef"]), (eb, g["xkeb"])):
         nz = want != 0
         assert np.array_equal(got == 0, ~nz) and (np.abs(got[nz] - want[nz]) / np.abs(want[nz])).max() <= 1e-14
+
+
+@needs_flang
+def test_fortran_particle_bin_moments(tmp_path):
+    """cw_rc and dry_cw_rc from Fortran (CW_RC_BATCH of shim/mistra_kpp_liq.f90, what the drop-ins CW_RC_HIP / DRY_CW_RC_HIP of shim/mistra_kpp_model.f90
+    call with the model's arrays in place) on the layers captured from the running reference model: bit for bit."""
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "shim")], check=True)
+    g = np.load(os.path.join(REPO, "tests", "golden", "cwrc.npz"))
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    for dry, pre in ((0, "wet"), (1, "dry")):
+        ff = g[pre + "_ff"]
+        nl, nka, nkt = ff.shape
+        with open(fin, "wb") as f:
+            np.array([nl, nkt, nka, dry, int(g["ka"]), int(g["ifeed"])], np.float64).tofile(f)
+            for a in (g["kw"].astype(np.float64), g["rq"], g["e"], g["crys4"], ff, g[pre + "_feu"], g[pre + "_cloud"].astype(np.float64)):
+                np.ascontiguousarray(a, np.float64).tofile(f)
+        subprocess.run([DRIVER, "Ca", str(fin), str(fout)], check=True, timeout=300)
+        raw = np.fromfile(fout, np.float64)
+        nb = 2 if dry else 4
+        rc, cw, cm, cv = (raw[i * nl * nb:(i + 1) * nl * nb].reshape(nl, nb) for i in range(4))
+        assert np.array_equal(rc, g[pre + "_rc"][:, :nb]) and np.array_equal(cw, g[pre + "_cw"][:, :nb])
+        if not dry:
+            assert np.array_equal(cm, g["wet_cm"]) and np.array_equal(cv, g["wet_conv2"])
+            assert np.array_equal(raw[4 * nl * nb:], (g["wet_feu"] < g["crys4"][:2].min()).astype(np.float64))

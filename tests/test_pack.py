@@ -121,6 +121,23 @@ def test_mean_molecular_speeds_of_captured_layers(mech):
         assert np.array_equal(liq_py.v_mean_layer(tab, float(g["vmean_tt"][i])), g["vmean"][i])
 
 
+def test_particle_bin_moments_of_captured_layers():
+    """cw_rc (kpp.f90:2152-2414) and dry_cw_rc (kpp.f90:4580-4690) restated (oracle/liq_py.py: cw_rc_layer) on layers captured from the running reference
+    model (tests/golden/cwrc.npz): liquid water, mean radius, water mass and the chemistry switch conv2 of the four bins — and rcd, cwd of the dry layers
+    above, whose 4./3. is a single-precision quotient — bit for bit; bins switched on and off are both in the capture."""
+    from oracle import liq_py
+    g = np.load(os.path.join(REPO, "tests", "golden", "cwrc.npz"))
+    assert len(g["wet_k"]) >= 8 and len(g["dry_k"]) >= 8
+    for i in range(len(g["wet_k"])):
+        rc, cw, cm, cv, below = liq_py.cw_rc_layer(g["wet_ff"][i], g["rq"], g["e"], g["kw"], int(g["ka"]), int(g["ifeed"]), float(g["wet_feu"][i]), g["wet_cloud"][i], g["crys4"])
+        for got, key in ((rc, "rc"), (cw, "cw"), (cm, "cm"), (cv, "conv2")):
+            assert np.array_equal(got, g["wet_" + key][i]), (i, key)
+    assert (g["wet_conv2"] > 0).any() and (g["wet_conv2"] == 0).any()
+    for i in range(len(g["dry_k"])):
+        rc, cw = liq_py.cw_rc_layer(g["dry_ff"][i], g["rq"], g["e"], g["kw"], int(g["ka"]), int(g["ifeed"]), dry=True)
+        assert np.array_equal(rc, g["dry_rc"][i][:2]) and np.array_equal(cw, g["dry_cw"][i][:2])
+
+
 def test_tables_in_the_repo_are_what_the_extractor_writes(tmp_path):
     if not os.path.isdir("/root/reference/src"):
         pytest.skip("no reference tree here")
