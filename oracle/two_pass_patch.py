@@ -2,11 +2,14 @@
 """TEST INFRASTRUCTURE — applies one of the two batched-driver patches of INTEGRATION.md §4 to scratch copies of four reference files
 (kpp.f90, gas.f, aer.f, tot.f) and writes the unified diff a maintainer would apply.
 
-    two_pass_patch.py [--mode two-pass|drive] <reference src dir> <scratch dir> [<diff out>]
+    two_pass_patch.py [--mode two-pass|drive|liq] <reference src dir> <scratch dir> [<diff out>]
 
 two-pass (shim/kpp_two_pass.patch): the layer loop runs twice around one batched INTEGRATE_x per mechanism; pack, rates, budgets and
 hand-over stay in Fortran.  drive (shim/kpp_drive.patch): the loop runs once, x_drive stages its layer behind its /kpp_rate_x/ prologue
 and ONE mistra_chem_drive call per mechanism does pack -> rates -> integrator -> budgets -> hand-over on the device (shim/mistra_kpp_drive.f90).
+
+liq (shim/kpp_liq.patch): liq_parm's calls of cw_rc, v_mean_x, henry_x, st_coeff_x, equil_co_x, fast_k_mt_x and dry_cw_rc (kpp.f90:609-650) go to the
+drop-ins of shim/mistra_kpp_model.f90, which have the reference's own argument lists (kpp.f90 only).
 
 Nothing under the reference tree is touched; the scratch copies live under oracle/_ref/ (git-ignored).  The edits are
 anchored on the exact reference lines they follow or replace (kpp.f90:4168-4470, gas.f:172-173, aer.f:216-217,
@@ -80,6 +83,21 @@ def patch_drive_single(t, sfx, anchor):
     return t[:at] + block + t[at:]
 
 
+def patch_kpp_liq(text):
+    a, b = text.index("subroutine liq_parm (xra,box,n_bl)"), text.index("end subroutine liq_parm")      # (initc calls some of the routines too: not touched)
+    t = text[a:b]
+    for old, new in (("  call cw_rc (nmaxf)\n", "  call CW_RC_HIP (nmaxf)      ! the particle bins' water and switches on the device (shim/mistra_kpp_model.f90)\n"),
+                     ("  call v_mean_a (t,nmaxf)", "  call V_MEAN_HIP_a (t,nmaxf)"), ("  call henry_a (t,nmaxf)\n", "  call HENRY_HIP_a (t,nmaxf)\n"),
+                     ("  call st_coeff_a\n", "  call ST_COEFF_HIP_a\n"), ("  call equil_co_a (t,nmaxf)\n", "  call EQUIL_CO_HIP_a (t,nmaxf)\n"),
+                     ("call fast_k_mt_a(freep,box,n_bl)\n", "call FAST_K_MT_HIP_a(freep,box,n_bl)\n"),
+                     ("     call v_mean_t (t,nmaxf)", "     call V_MEAN_HIP_t (t,nmaxf)"), ("     call henry_t (t,nmaxf)\n", "     call HENRY_HIP_t (t,nmaxf)\n"),
+                     ("     call st_coeff_t\n", "     call ST_COEFF_HIP_t\n"), ("     call equil_co_t (t,nmaxf)\n", "     call EQUIL_CO_HIP_t (t,nmaxf)\n"),
+                     ("call fast_k_mt_t(freep,box,n_bl)\n", "call FAST_K_MT_HIP_t(freep,box,n_bl)\n"),
+                     ("  call dry_cw_rc (nmax)\n", "  call DRY_CW_RC_HIP (nmax)\n")):
+        t = edit(t, old, new)
+    return text[:a] + t + text[b:]
+
+
 def main():
     mode = "two-pass"
     if sys.argv[1] == "--mode":
@@ -96,6 +114,8 @@ def main():
     elif mode == "two-pass":
         edits = (("kpp.f90", patch_kpp), ("gas.f", lambda t: patch_drive(t, "g", "      ")),
                  ("aer.f", lambda t: patch_drive(t, "a", "      ")), ("tot.f", lambda t: patch_drive(t, "t", "         ")))
+    elif mode == "liq":
+        edits = (("kpp.f90", patch_kpp_liq),)
     else:
         raise SystemExit("unknown mode " + mode)
     for name, fn in edits:
@@ -105,7 +125,7 @@ def main():
         diff += list(difflib.unified_diff(old.splitlines(True), new.splitlines(True), "a/src/" + name, "b/src/" + name, n=2))
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write("".join(diff))
-    print("patched 4 files into", scratch, "(%s, %d diff lines)" % (mode, len(diff)))
+    print("patched %d file(s) into" % len(edits), scratch, "(%s, %d diff lines)" % (mode, len(diff)))
 
 
 if __name__ == "__main__":

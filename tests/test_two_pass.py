@@ -77,9 +77,9 @@ def test_single_pass_batched_driver_reproduces_the_serial_model_bit_for_bit(case
             assert x["tin_out"] == y["tin_out"] and x["stepmin_out"] == y["stepmin_out"]
 
 
-@pytest.mark.parametrize("mode,name", [("two-pass", "kpp_two_pass.patch"), ("drive", "kpp_drive.patch")])
+@pytest.mark.parametrize("mode,name", [("two-pass", "kpp_two_pass.patch"), ("drive", "kpp_drive.patch"), ("liq", "kpp_liq.patch")])
 def test_patches_in_the_repo_are_what_the_generator_writes(tmp_path, mode, name):
-    """shim/kpp_two_pass.patch and shim/kpp_drive.patch are generated (oracle/two_pass_patch.py), not hand-edited."""
+    """shim/kpp_two_pass.patch, shim/kpp_drive.patch and shim/kpp_liq.patch are generated (oracle/two_pass_patch.py), not hand-edited."""
     if not os.path.isdir("/root/reference/src"):
         pytest.skip("no reference tree here")
     out = tmp_path / "p.patch"
