@@ -257,7 +257,7 @@ int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const dou
 
 /* The liq_parm kernels above on HOST buffers (same layouts, layer-major as the model holds them: every array of the reference has the
  * layer as its last dimension, so a run of layers kmin..kmax is handed over in place — ff(1,1,kmin), xkmt(1,1,kmin) ...): what the Fortran
- * shim calls (shim/mistra_kpp_liq.f90: FAST_K_MT_BATCH, HENRY_BATCH, V_MEAN_BATCH, ST_COEFF_BATCH, EQUIL_CO_BATCH, CW_RC_BATCH; drop-ins with the reference's own signatures in
+ * shim calls (shim/mistra_kpp_liq.f90: FAST_K_MT_BATCH, HENRY_BATCH, V_MEAN_BATCH, ST_COEFF_BATCH, EQUIL_CO_BATCH, CW_RC_BATCH, DRY_RATES_BATCH; drop-ins with the reference's own signatures in
  * shim/mistra_kpp_model.f90).  Synchronous; primary device. */
 int mistra_chem_fast_k_mt(int mech, int nlayer, const double* ff, const double* rq, const int32_t* kw, int nkw, int ka, int ifeed, int nkc_l,
                           const double* cw, const double* cm, const double* freep, const double* alpha, const double* vmean, double* xkmt,
@@ -277,6 +277,17 @@ int mistra_chem_st_coeff(int mech, int nlayer, int lp_joyce14bc, int lp_buxmann1
  *   below [nlayer]            1 where feu(k) < min(xcryssulf, xcrysss): the reference prints `k, feu(k), ' below both crystal. points'` for those
  *                             layers up to kinv (the Fortran drop-in does, shim/mistra_kpp_model.f90); may be NULL
  * cw_rc computes layers 2..nmaxf, dry_cw_rc nf+1..nmax: the caller hands over that run of layers. */
+/* dry_rates_g (tt,freep,nmax) (kpp.f90:4697-4853; gas != 0) | dry_rates_a (freep,nmaxf) (:4860-5073) | dry_rates_t (freep,nmaxf) (:5079-5198), called by
+ * liq_parm every time step (kpp.f90:651-653): the mass-transfer coefficients of HNO3, N2O5, NH3, H2SO4 — the routines' idr list, in that order — onto the
+ * dry aerosol of bins 1 and 2, and the equilibrium constant of HNO3.  The four species sit at mechanism-specific places of the model's NSPEC-wide arrays:
+ * the caller (shim/mistra_kpp_model.f90: DRY_RATES_HIP_g/_a/_t) gathers vmean and scatters the results, so these arrays are compact.  Host buffers:
+ *   tt, freep [nlayer]        temperature (/cb53/ t; dry_rates_g: its argument tt) and mean free path of the layers k = 2..nmax
+ *   rcd [nlayer][2]           rcd(1:2,k) of /blck11/
+ *   vmean4 [nlayer][4]        vmean(idr(l),k) of /kpp_2aer/ | /kpp_2tot/ (aer, tot; NULL for gas: dry_rates_g forms its own)
+ *   xkmtd [nlayer][2][4]      out: xkmtd(idr(l),kc,k);   xeq [nlayer]: out: xeq(ind_HNO3,k)
+ *   henry4 [nlayer][4]        gas only, in/out: henry(idr(l),k) of /kpp_dryg/ (HNO3 is set, then every positive entry becomes 1/(henry*FCT), as the reference does) */
+int mistra_chem_dry_rates(int gas, int nlayer, const double* tt, const double* freep, const double* rcd, const double* vmean4, double* xkmtd, double* xeq,
+                          double* henry4);
 int mistra_chem_cw_rc(int nlayer, int nkt, int nka, int dry, const double* ff, const double* rq, const double* e, const int32_t* kw, int ka, int ifeed,
                       const double* feu, const int32_t* cloud, const double* crys4, double* rc, double* cw, double* cm, double* conv2, int32_t* below);
 int mistra_chem_equil_co(int mech, int nlayer, int nkc, int j6, const double* tt, const double* conv2, const double* xgamma, double* xkef,

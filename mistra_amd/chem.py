@@ -371,6 +371,24 @@ def v_mean(mech, tt, out):
     _check(lib().mistra_chem_v_mean_device(mid, out.shape[0], _p(tt), _p(out), _stream(out)))
 
 
+def dry_rates(tt, freep, rcd, vmean4=None, henry4=None):
+    """dry_rates_a / dry_rates_t (vmean4 [nlayer, 4] given) or dry_rates_g (henry4 [nlayer, 4] given, returned updated) for a batch of layers
+    -> xkmtd [nlayer, 2, 4], xeq [nlayer] (, henry4); numpy arrays (host-buffer entry, include/mistra_chem.h)."""
+    L = lib()
+    if not hasattr(L, "_dry_rates_typed"):
+        L.mistra_chem_dry_rates.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L._dry_rates_typed = True
+    gas = vmean4 is None
+    f8 = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)
+    tt, freep, rcd, vmean4 = f8(tt), f8(freep), f8(rcd), f8(vmean4)
+    h = None if henry4 is None else np.array(henry4, np.float64, order="C", copy=True)
+    nl = tt.shape[0]
+    xk, xeq = np.full((nl, 2, 4), np.nan), np.full(nl, np.nan)
+    P = lambda a: None if a is None else a.ctypes.data_as(_dp)
+    _check(L.mistra_chem_dry_rates(int(gas), nl, P(tt), P(freep), P(rcd), P(vmean4), P(xk), P(xeq), P(h)))
+    return (xk, xeq, h) if gas else (xk, xeq)
+
+
 def cw_rc(ff, rq, e, kw, ka, ifeed, feu=None, cloud=None, crys4=None, dry=False):
     """cw_rc (dry=False: -> rc, cw, cm, conv2 [nlayer, 4], below [nlayer]) or dry_cw_rc (dry=True: -> rcd, cwd [nlayer, 2]) for a batch of layers;
     numpy arrays in and out (host-buffer entry, include/mistra_chem.h)."""

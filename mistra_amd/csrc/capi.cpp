@@ -1186,6 +1186,30 @@ int mistra_chem_henry(int mech, int nlayer, const double* tt, double* henry) {
   return 0;
 }
 
+int mistra_chem_dry_rates(int gas, int nlayer, const double* tt, const double* freep, const double* rcd, const double* vmean4, double* xkmtd, double* xeq,
+                          double* henry4) {
+  if (int rc0 = lazy_init()) return rc0;
+  if (nlayer == 0) return 0;
+  if (nlayer < 0) return fail("nlayer < 0");
+  if (!tt || !freep || !rcd || !xkmtd || !xeq || (gas ? !henry4 : !vmean4)) return fail("null pointer");
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  HIP_TRY(hipSetDevice(D.id));
+  const size_t nl = (size_t)nlayer, d8 = sizeof(double);
+  DevBlock B;
+  const size_t i_t = B.add(nl * d8), i_f = B.add(nl * d8), i_r = B.add(nl * 2 * d8), i_v = B.add(nl * 4 * d8), i_x = B.add(nl * 8 * d8), i_q = B.add(nl * d8),
+               i_h = B.add(nl * 4 * d8);
+  HIP_TRY(B.alloc());
+  HIP_TRY(B.up(i_t, tt)); HIP_TRY(B.up(i_f, freep)); HIP_TRY(B.up(i_r, rcd));
+  if (gas) HIP_TRY(B.up(i_h, henry4)); else HIP_TRY(B.up(i_v, vmean4));
+  const DryRatesArgs A{nlayer, gas ? 1 : 0, B.dptr(i_t), B.dptr(i_f), B.dptr(i_r), B.dptr(i_v), B.dptr(i_x), B.dptr(i_q), B.dptr(i_h)};
+  LAUNCH_TRY(launch_dry_rates(A, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.down(i_x, xkmtd)); HIP_TRY(B.down(i_q, xeq));
+  if (gas) HIP_TRY(B.down(i_h, henry4));
+  return 0;
+}
+
 int mistra_chem_cw_rc(int nlayer, int nkt, int nka, int dry, const double* ff, const double* rq, const double* e, const int32_t* kw, int ka, int ifeed,
                       const double* feu, const int32_t* cloud, const double* crys4, double* rc, double* cw, double* cm, double* conv2, int32_t* below) {
   if (int rc0 = lazy_init()) return rc0;

@@ -309,6 +309,48 @@ hipError_t launch_cw_rc(const CwRcArgs& A, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// dry_rates_g | dry_rates_a | dry_rates_t (kpp.f90:4697-4853 | 4860-5073 | 5079-5198): mass-transfer coefficients of HNO3, N2O5, NH3, H2SO4 onto the DRY
+// aerosol of bins 1 and 2, one thread per layer.  All three: xeq(HNO3) = funa(1.54d+1,8700.d0), funa(a0,b0) = a0*exp(b0*(1/t - 3.354d-3));
+// x1 = 1./(rcd*(rcd/freep + 4./(3.*zgamma))) where rcd > 0, else 0 (zgamma = 0.02, 0.02, 0.05, 0.1 in both bins); xkmtd = vmean*x1.  dry_rates_g forms the
+// mean molecular speeds itself, func(M) = sqrt(tt/M)*4.60138 with M = 6.3d-2, 1.08d-1, 1.7d-2, 9.8d-2, and the Henry constant of HNO3,
+// henry = func3(2.5d6/xeq,8694.d0), func3(a0,b0) = a0*exp(b0*((1/tt) - 3.3557d-3)), then henry = 1./(henry*FCT), FCT = 0.0820577*tt (a default-real
+// literal), for each of the four species whose entry is positive.  One rounding per operation; exp is the device library's.
+__global__ __launch_bounds__(64) void dry_rates_kernel(const DryRatesArgs A) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= A.nlayer) return;
+  const double zgamma[4] = {0.02, 0.02, 0.05, 0.1}, mass[4] = {6.3e-2, 1.08e-1, 1.7e-2, 9.8e-2};
+  const double t = A.tt[k], freep = A.freep[k];
+  const double xeq = 1.54e+1 * exp(8700.0 * (1.0 / t - 3.354e-3));
+  A.xeq[k] = xeq;
+  double vm[4];
+  if (A.gas) {
+    double h[4];
+    for (int l = 0; l < 4; l++) h[l] = A.henry4[(size_t)k * 4 + l];
+    h[0] = (2.5e6 / xeq) * exp(8694.0 * ((1.0 / t) - 3.3557e-3));
+    const double fct = (double)0.0820577f * t;
+    for (int l = 0; l < 4; l++) {
+      if (h[l] > 0.0) h[l] = 1.0 / (h[l] * fct);
+      A.henry4[(size_t)k * 4 + l] = h[l];
+      vm[l] = sqrt(t / mass[l]) * (double)4.60138f;
+    }
+  } else {
+    for (int l = 0; l < 4; l++) vm[l] = A.vmean4[(size_t)k * 4 + l];
+  }
+  for (int kc = 0; kc < 2; kc++) {
+    const double rcd = A.rcd[(size_t)k * 2 + kc];
+    for (int l = 0; l < 4; l++) {
+      double x1 = 0.0;
+      if (zgamma[l] > 0.0 && rcd > 0.0) x1 = 1.0 / (rcd * (rcd / freep + 4.0 / (3.0 * zgamma[l])));
+      A.xkmtd[((size_t)k * 2 + kc) * 4 + l] = vm[l] * x1;
+    }
+  }
+}
+hipError_t launch_dry_rates(const DryRatesArgs& A, hipStream_t stream) {
+  if (A.nlayer <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dry_rates_kernel, dim3((unsigned)((A.nlayer + 63) / 64)), dim3(64), 0, stream, A);
+  return hipGetLastError();
+}
+
 // v_mean_a | v_mean_t (kpp.f90:1472-1670 | 1268-1465): the mean molecular speed sqrt(8 R T / (pi M)) as the reference writes it,
 // func(a,k) = sqrt(tt(k)/a)*4.60138 (the factor a default-real literal), one thread per (layer, species); a species the routine does not
 // set stays 0 (`vmean(:,:) = 0._dp`).  Quotient, square root and product each round once, as compiled Fortran does: bit-identical.

@@ -94,6 +94,16 @@ struct CwRcArgs {
   int32_t* below;                     // [nlayer]: 1 where feu < min(xcryssulf, xcrysss) (the reference prints a line for those below the inversion)
 };
 hipError_t launch_cw_rc(const CwRcArgs& A, hipStream_t stream);
+// ---- uptake on the dry aerosol: dry_rates_g (kpp.f90:4697-4853), dry_rates_a (:4860-5073), dry_rates_t (:5079-5198).  Four species (HNO3, N2O5, NH3,
+//      H2SO4, the routines' idr list), two bins; the caller gathers and scatters by species index, so the kernel is the same for the three mechanisms.
+struct DryRatesArgs {
+  int nlayer, gas;                 // gas != 0: dry_rates_g — the routine's own mean molecular speeds and the Henry constant of HNO3
+  const double *tt, *freep, *rcd;  // [nlayer], [nlayer], [nlayer][2]
+  const double* vmean4;            // [nlayer][4]: vmean(idr(l),k) (aer, tot); unused for gas
+  double *xkmtd, *xeq;             // [nlayer][2][4] = xkmtd(idr(l),kc,k); [nlayer] = xeq(ind_HNO3,k)
+  double* henry4;                  // gas: [nlayer][4] = henry(idr(l),k), in/out
+};
+hipError_t launch_dry_rates(const DryRatesArgs& A, hipStream_t stream);
 // ---- mean molecular speeds (kpp.f90: v_mean_a 1472-1670, v_mean_t 1268-1465).  Table: mistra_amd/mech/<mech>.vmean (tools/extract_vmean.py).
 struct VmeanTable {
   int nspec = 0;

@@ -70,17 +70,19 @@ if [ "$WHAT" = model ] || [ "$WHAT" = all ]; then
   "$FC" $FFLAGS -I"$OUT/obj" -c "$HERE/capture_liq_wrap.f90" -o capture_liq_wrap.o
   # cw_rc and dry_cw_rc calls of liq_parm
   "$FC" $FFLAGS -I"$OUT/obj" -c "$HERE/capture_cwrc_wrap.f90" -o capture_cwrc_wrap.o
+  # dry_rates_g/a/t calls of liq_parm; the species indices of the routines' idr list come from the mechanisms' parameter headers
+  "$FC" $FFLAGS -I"$OUT/obj" -I"$REF" -c "$HERE/capture_dry_wrap.f90" -o capture_dry_wrap.o
   # the reference's own main program stays in str.o but under another name (it is not the entry point here)
   /opt/rocm/lib/llvm/bin/llvm-objcopy --redefine-sym main=mistra_reference_main --redefine-sym _QQmain=mistra_reference_qqmain \
       str.o str_lib.o
   "$FC" $FFLAGS -I"$REF" -c "$HERE/column_driver.f90" -o column_driver.o
   echo "  LD mistra_capture"
   "$FC" -o "$OUT/mistra_capture" column_driver.o $(objs $MODS $CHEM ${REST% str.f90}) str_lib.o capture_wrap.o \
-      capture_rates_wrap.o mistra_kpp_rates.o capture_drive_wrap.o capture_kmt_wrap.o capture_liq_wrap.o capture_cwrc_wrap.o \
+      capture_rates_wrap.o mistra_kpp_rates.o capture_drive_wrap.o capture_kmt_wrap.o capture_liq_wrap.o capture_cwrc_wrap.o capture_dry_wrap.o \
       -Wl,--wrap=integrate_g_ -Wl,--wrap=integrate_a_ -Wl,--wrap=integrate_t_ \
       -Wl,--wrap=update_rconst_g_ -Wl,--wrap=update_rconst_a_ -Wl,--wrap=update_rconst_t_ \
       -Wl,--wrap=gas_drive_ -Wl,--wrap=aer_drive_ -Wl,--wrap=tot_drive_ -Wl,--wrap=fast_k_mt_a_ -Wl,--wrap=fast_k_mt_t_ \
-      -Wl,--wrap=henry_a_ -Wl,--wrap=henry_t_ -Wl,--wrap=equil_co_a_ -Wl,--wrap=equil_co_t_ -Wl,--wrap=v_mean_a_ -Wl,--wrap=v_mean_t_ -Wl,--wrap=st_coeff_a_ -Wl,--wrap=st_coeff_t_ -Wl,--wrap=cw_rc_ -Wl,--wrap=dry_cw_rc_ \
+      -Wl,--wrap=henry_a_ -Wl,--wrap=henry_t_ -Wl,--wrap=equil_co_a_ -Wl,--wrap=equil_co_t_ -Wl,--wrap=v_mean_a_ -Wl,--wrap=v_mean_t_ -Wl,--wrap=st_coeff_a_ -Wl,--wrap=st_coeff_t_ -Wl,--wrap=cw_rc_ -Wl,--wrap=dry_cw_rc_ -Wl,--wrap=dry_rates_g_ -Wl,--wrap=dry_rates_a_ -Wl,--wrap=dry_rates_t_ \
       -Wl,--unresolved-symbols=ignore-all
 fi
 

@@ -110,3 +110,26 @@ def cw_rc_layer(ff, rq, e, kw, ka, ifeed, feu=None, cloud=None, crys4=None, dry=
                 cm[kc] = cms[kc] * 1.0e-3
                 conv2[kc] = 1.0e9 / cws[kc]
     return rc, cw, cm, conv2, int(below)
+
+
+def dry_rates_layer(tt, freep, rcd, vmean4=None, henry4=None):
+    """dry_rates_g (vmean4 None: kpp.f90:4697-4853) | dry_rates_a / dry_rates_t (kpp.f90:4860-5073 | 5079-5198) for ONE layer and the four species of the
+    routines' idr list (HNO3, N2O5, NH3, H2SO4): -> xkmtd [2][4], xeq(HNO3) (, henry [4] for gas, from the entries it held before)."""
+    zgamma, mass = (0.02, 0.02, 0.05, 0.1), (6.3e-2, 1.08e-1, 1.7e-2, 9.8e-2)
+    xeq = 1.54e+1 * math.exp(8700.0 * (1.0 / tt - 3.354e-3))                     # funa(1.54d+1,8700.d0,k)
+    h = None
+    if vmean4 is None:
+        h = [float(x) for x in henry4]
+        h[0] = (2.5e6 / xeq) * math.exp(8694.0 * ((1.0 / tt) - 3.3557e-3))          # func3(2.5d6/xeq,8694.d0,k)
+        fct = float(np.float32(0.0820577)) * tt                                      # FCT=0.0820577*tt(k): a default-real literal
+        h = [1.0 / (x * fct) if x > 0.0 else x for x in h]
+        vm = [math.sqrt(tt / m) * float(np.float32(4.60138)) for m in mass]          # func(a,k) = sqrt(tt(k)/a)*4.60138
+    else:
+        vm = [float(x) for x in vmean4]
+    xk = np.zeros((2, 4))
+    for kc in range(2):
+        r = float(rcd[kc])
+        for l in range(4):
+            x1 = 1.0 / (r * (r / freep + 4.0 / (3.0 * zgamma[l]))) if (zgamma[l] > 0.0 and r > 0.0) else 0.0
+            xk[kc, l] = vm[l] * x1
+    return (xk, xeq, np.array(h)) if h is not None else (xk, xeq)

@@ -8,7 +8,7 @@ two-pass (shim/kpp_two_pass.patch): the layer loop runs twice around one batched
 hand-over stay in Fortran.  drive (shim/kpp_drive.patch): the loop runs once, x_drive stages its layer behind its /kpp_rate_x/ prologue
 and ONE mistra_chem_drive call per mechanism does pack -> rates -> integrator -> budgets -> hand-over on the device (shim/mistra_kpp_drive.f90).
 
-liq (shim/kpp_liq.patch): liq_parm's calls of cw_rc, v_mean_x, henry_x, st_coeff_x, equil_co_x, fast_k_mt_x and dry_cw_rc (kpp.f90:609-650) go to the
+liq (shim/kpp_liq.patch): liq_parm's calls of cw_rc, v_mean_x, henry_x, st_coeff_x, equil_co_x, fast_k_mt_x, dry_cw_rc and dry_rates_x (kpp.f90:609-653) go to the
 drop-ins of shim/mistra_kpp_model.f90, which have the reference's own argument lists (kpp.f90 only).
 
 Nothing under the reference tree is touched; the scratch copies live under oracle/_ref/ (git-ignored).  The edits are
@@ -93,7 +93,8 @@ def patch_kpp_liq(text):
                      ("     call v_mean_t (t,nmaxf)", "     call V_MEAN_HIP_t (t,nmaxf)"), ("     call henry_t (t,nmaxf)\n", "     call HENRY_HIP_t (t,nmaxf)\n"),
                      ("     call st_coeff_t\n", "     call ST_COEFF_HIP_t\n"), ("     call equil_co_t (t,nmaxf)\n", "     call EQUIL_CO_HIP_t (t,nmaxf)\n"),
                      ("call fast_k_mt_t(freep,box,n_bl)\n", "call FAST_K_MT_HIP_t(freep,box,n_bl)\n"),
-                     ("  call dry_cw_rc (nmax)\n", "  call DRY_CW_RC_HIP (nmax)\n")):
+                     ("  call dry_cw_rc (nmax)\n", "  call DRY_CW_RC_HIP (nmax)\n"), ("  call dry_rates_g (t,freep,nmax)\n", "  call DRY_RATES_HIP_g (t,freep,nmax)\n"),
+                     ("  call dry_rates_a (freep,nmaxf)\n", "  call DRY_RATES_HIP_a (freep,nmaxf)\n"), ("  call dry_rates_t (freep,nmaxf)\n", "  call DRY_RATES_HIP_t (freep,nmaxf)\n")):
         t = edit(t, old, new)
     return text[:a] + t + text[b:]
 

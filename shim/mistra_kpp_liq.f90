@@ -1,9 +1,10 @@
-! Fortran side of liq_parm's table-driven kernels on the GPU (SURVEY.md §8 f3; include/mistra_chem.h: mistra_chem_fast_k_mt, _henry, _v_mean, _st_coeff, _equil_co, _cw_rc):
+! Fortran side of liq_parm's table-driven kernels on the GPU (SURVEY.md §8 f3; include/mistra_chem.h: mistra_chem_fast_k_mt, _henry, _v_mean, _st_coeff, _equil_co, _cw_rc, _dry_rates):
 !   FAST_K_MT_BATCH   fast_k_mt_a (kpp.f90:2683-2947) | fast_k_mt_t (kpp.f90:2421-2676): xkmt AND the sedimentation velocity vt, every 120 s
 !   HENRY_BATCH       henry_a (kpp.f90:1914-2145)     | henry_t (kpp.f90:1676-1907): the inverse dimensionless Henry constants, every step
 !   V_MEAN_BATCH      v_mean_a (kpp.f90:1472-1670)    | v_mean_t (kpp.f90:1268-1465): the mean molecular speeds, every step
 !   ST_COEFF_BATCH    st_coeff_a (kpp.f90:857-1038)   | st_coeff_t (kpp.f90:664-851): the accommodation coefficients alpha, every step
 !   CW_RC_BATCH       cw_rc (kpp.f90:2152-2414) | dry_cw_rc (kpp.f90:4580-4690): liquid water, mean radius, water mass and chemistry switch of the particle bins
+!   DRY_RATES_BATCH   dry_rates_g (kpp.f90:4697-4853) | dry_rates_a (:4860-5073) | dry_rates_t (:5079-5198): uptake of four species on the dry aerosol, every step
 !   EQUIL_CO_BATCH    equil_co_a (kpp.f90:3162-3363)  | equil_co_t (kpp.f90:2954-3155): forward / backward equilibrium rate constants, every step
 ! for a run of consecutive layers.  Every array of the reference has the layer as its LAST dimension, so the caller hands over the model
 ! arrays in place, starting at the first layer of the run: ff(1,1,kmin), xkmt(1,1,kmin), cw(1,kmin), freep(kmin) ... (drop-ins with the
@@ -53,6 +54,13 @@ module mistra_kpp_liq
        integer(c_int32_t) :: below(*)
        integer(c_int) :: ret
      end function mistra_chem_cw_rc
+     function mistra_chem_dry_rates(gas, nlayer, tt, freep, rcd, vmean4, xkmtd, xeq, henry4) bind(C, name="mistra_chem_dry_rates") result(rc)
+       import :: c_int, c_double
+       integer(c_int), value :: gas, nlayer
+       real(c_double), intent(in) :: tt(*), freep(*), rcd(*), vmean4(*)
+       real(c_double) :: xkmtd(*), xeq(*), henry4(*)
+       integer(c_int) :: rc
+     end function mistra_chem_dry_rates
      function mistra_chem_equil_co(mech, nlayer, nkc, j6, tt, conv2, xgamma, xkef, xkeb) bind(C, name="mistra_chem_equil_co") result(rc)
        import :: c_int, c_double
        integer(c_int), value :: mech, nlayer, nkc, j6
@@ -118,6 +126,18 @@ contains
                           int(ifeed, c_int), feu, cl, crys4, rc, cw, cm, conv2, bl) /= 0) call mistra_chem_fail('CW_RC_BATCH')
     if (.not. dry) below(1:nlayer) = bl
   end subroutine CW_RC_BATCH
+
+  ! tt, freep(nlayer), rcd(2,nlayer), vmean4(4,nlayer) (aer, tot) -> xkmtd(4,2,nlayer), xeq(nlayer); gas: henry4(4,nlayer) in/out.  Species order: the
+  ! routines' idr list HNO3, N2O5, NH3, H2SO4
+  subroutine DRY_RATES_BATCH(gas, nlayer, tt, freep, rcd, vmean4, xkmtd, xeq, henry4)
+    logical, intent(in) :: gas
+    integer, intent(in) :: nlayer
+    real(c_double), intent(in) :: tt(*), freep(*), rcd(*), vmean4(*)
+    real(c_double) :: xkmtd(*), xeq(*), henry4(*)
+    if (nlayer <= 0) return
+    if (mistra_chem_dry_rates(merge(1_c_int, 0_c_int, gas), int(nlayer, c_int), tt, freep, rcd, vmean4, xkmtd, xeq, henry4) /= 0) &
+         call mistra_chem_fail('DRY_RATES_BATCH')
+  end subroutine DRY_RATES_BATCH
 
   ! tt(nlayer), conv2(nkc,nlayer), xgamma(j6,nkc,nlayer) -> xkef, xkeb(NSPEC,nkc,nlayer) in/out
   subroutine EQUIL_CO_BATCH(mech, nlayer, nkc, j6, tt, conv2, xgamma, xkef, xkeb)

@@ -108,6 +108,86 @@ subroutine HENRY_HIP_a(tt, nmaxf)                  ! henry_a (tt,nmaxf), kpp.f90
   call HENRY_BATCH(2, nmaxf, tt, henry)
 end subroutine HENRY_HIP_a
 
+subroutine DRY_RATES_HIP_g(tt, freep, nmax)        ! dry_rates_g (tt,freep,nmax), kpp.f90:4697: layers 2..nmax
+  USE global_params, ONLY : n, nkc
+  USE mistra_kpp_liq, ONLY : DRY_RATES_BATCH
+  implicit none
+  include 'gas_Parameters.h'
+  double precision, intent(in) :: tt(n), freep(n)
+  integer, intent(in) :: nmax
+  double precision :: rcd, xkmtd, henry, xeq, xk(4, 2, n), xq(n), h4(4, n), dum(1)
+  integer :: idr(4), k, kc
+  common /blck11/ rcd(nkc,n)
+  common /kpp_dryg/ xkmtd(NSPEC,2,n), henry(NSPEC,n), xeq(NSPEC,n)
+  if (nmax < 2) return
+  idr = [ind_HNO3, ind_N2O5, ind_NH3, ind_H2SO4]
+  do k = 2, nmax
+     h4(:, k) = henry(idr, k)
+  end do
+  call DRY_RATES_BATCH(.true., nmax - 1, tt(2), freep(2), rcd(1:2, 2:nmax), dum, xk(1,1,2), xq(2), h4(1,2))
+  do k = 2, nmax
+     xeq(ind_HNO3, k) = xq(k)
+     henry(idr, k) = h4(:, k)
+     do kc = 1, 2
+        xkmtd(idr, kc, k) = xk(:, kc, k)
+     end do
+  end do
+end subroutine DRY_RATES_HIP_g
+
+subroutine DRY_RATES_HIP_a(freep, nmaxf)          ! dry_rates_a (freep,nmaxf), kpp.f90:4860: layers 2..nmaxf
+  USE global_params, ONLY : nf, n, nkc
+  USE mistra_kpp_liq, ONLY : DRY_RATES_BATCH
+  implicit none
+  include 'aer_Parameters.h'
+  double precision, intent(in) :: freep(n)
+  integer, intent(in) :: nmaxf
+  double precision :: rcd, xkmtd, xeq, alpha, vmean, theta, thetl, t, talt, p, rho, xk(4, 2, nf), xq(nf), v4(4, nf), dum(1)
+  integer :: idr(4), k, kc
+  common /blck11/ rcd(nkc,n)
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  common /kpp_2aer/ alpha(NSPEC,nf), vmean(NSPEC,nf)
+  common /kpp_drya/ xkmtd(NSPEC,2,nf), xeq(NSPEC,nf)
+  if (nmaxf < 2) return
+  idr = [ind_HNO3, ind_N2O5, ind_NH3, ind_H2SO4]
+  do k = 2, nmaxf
+     v4(:, k) = vmean(idr, k)
+  end do
+  call DRY_RATES_BATCH(.false., nmaxf - 1, t(2), freep(2), rcd(1:2, 2:nmaxf), v4(1,2), xk(1,1,2), xq(2), dum)
+  do k = 2, nmaxf
+     xeq(ind_HNO3, k) = xq(k)
+     do kc = 1, 2
+        xkmtd(idr, kc, k) = xk(:, kc, k)
+     end do
+  end do
+end subroutine DRY_RATES_HIP_a
+
+subroutine DRY_RATES_HIP_t(freep, nmaxf)          ! dry_rates_t (freep,nmaxf), kpp.f90:5079: layers 2..nmaxf
+  USE global_params, ONLY : nf, n, nkc
+  USE mistra_kpp_liq, ONLY : DRY_RATES_BATCH
+  implicit none
+  include 'tot_Parameters.h'
+  double precision, intent(in) :: freep(n)
+  integer, intent(in) :: nmaxf
+  double precision :: rcd, xkmtd, xeq, alpha, vmean, theta, thetl, t, talt, p, rho, xk(4, 2, nf), xq(nf), v4(4, nf), dum(1)
+  integer :: idr(4), k, kc
+  common /blck11/ rcd(nkc,n)
+  common /cb53/ theta(n), thetl(n), t(n), talt(n), p(n), rho(n)
+  common /kpp_2tot/ alpha(NSPEC,nf), vmean(NSPEC,nf)
+  common /kpp_dryt/ xkmtd(NSPEC,2,nf), xeq(NSPEC,nf)
+  if (nmaxf < 2) return
+  idr = [ind_HNO3, ind_N2O5, ind_NH3, ind_H2SO4]
+  do k = 2, nmaxf
+     v4(:, k) = vmean(idr, k)
+  end do
+  call DRY_RATES_BATCH(.false., nmaxf - 1, t(2), freep(2), rcd(1:2, 2:nmaxf), v4(1,2), xk(1,1,2), xq(2), dum)
+  do k = 2, nmaxf
+     xeq(ind_HNO3, k) = xq(k)
+     do kc = 1, 2
+        xkmtd(idr, kc, k) = xk(:, kc, k)
+     end do
+  end do
+end subroutine DRY_RATES_HIP_t
+
 subroutine CW_RC_HIP(nmaxf)                        ! cw_rc (nmaxf), kpp.f90:2152: layers 2..nmaxf
   USE config, ONLY : ifeed
   USE global_params, ONLY : n, nka, nkt, nkc

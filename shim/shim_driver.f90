@@ -17,9 +17,9 @@
 !                                                      sl1(121,4,n) sion1(55,4,n) bg(2,nrxn,nlev) bgs(2,122,n) | per layer: mech, k, air, h2o, env(nenv).
 !                                                      out.bin: the arrays after the step | per layer ierr, 8 statistics, texit, hexit | per repetition
 !                                                      the wall times (ms) of the staging loop and of the device call(s)
-!          shim_driver <Ka|Kt|Ha|Ht|Va|Vt|Sa|St|Qa|Qt|Ca> <in.bin> <out.bin>   liq_parm's kernels through shim/mistra_kpp_liq.f90 (SURVEY §8 f3): K = FAST_K_MT_BATCH
+!          shim_driver <Ka|Kt|Ha|Ht|Va|Vt|Sa|St|Qa|Qt|Ca|Rg|Ra|Rt> <in.bin> <out.bin>   liq_parm's kernels through shim/mistra_kpp_liq.f90 (SURVEY §8 f3): K = FAST_K_MT_BATCH
 !                                                      (in: nlayer, nka, nkt, nkc, nspec, ka, ifeed, nkc_l | kw | rq | ff cw cm freep alpha vmean xkmt t p vt;
-!                                                      out: xkmt, vt), H = HENRY_BATCH (in: nlayer, nspec | tt; out: henry), V = V_MEAN_BATCH (the same shapes; out: vmean), S = ST_COEFF_BATCH (in: nlayer, nspec, lpJoyce14bc, lpBuxmann15alph | env(5,nlayer); out: alpha), C = CW_RC_BATCH (in: nlayer, nkt, nka, dry, ka, ifeed | kw, rq, e, crys4, ff, feu, cloud; out: rc, cw, cm, conv2, below), Q = EQUIL_CO_BATCH (in: nlayer,
+!                                                      out: xkmt, vt), H = HENRY_BATCH (in: nlayer, nspec | tt; out: henry), V = V_MEAN_BATCH (the same shapes; out: vmean), S = ST_COEFF_BATCH (in: nlayer, nspec, lpJoyce14bc, lpBuxmann15alph | env(5,nlayer); out: alpha), R = DRY_RATES_BATCH (in: nlayer | tt, freep, rcd(2,nlayer), vmean4 / henry4 (4,nlayer); out: xkmtd, xeq, henry4), C = CW_RC_BATCH (in: nlayer, nkt, nka, dry, ka, ifeed | kw, rq, e, crys4, ff, feu, cloud; out: rc, cw, cm, conv2, below), Q = EQUIL_CO_BATCH (in: nlayer,
 !                                                      nkc, j6, nspec | tt conv2 xgamma xkef xkeb; out: xkef, xkeb)
 ! After the call the one-cell mode also writes ATOL(1), RTOL(1) (INTEGRATE_x resets them, gas.f:745-746).
 program shim_driver
@@ -37,7 +37,7 @@ program shim_driver
   case ('A'); call run_batch(1, 257, 5, 979, trim(fin), trim(fout))
   case ('T'); call run_batch(2, 417, 7, 1627, trim(fin), trim(fout))
   case ('D'); call run_drive(trim(fin), trim(fout))
-  case ('K', 'H', 'Q', 'V', 'S', 'C')
+  case ('K', 'H', 'Q', 'V', 'S', 'C', 'R')
      select case (a1(2:2))
      case ('a'); call run_liq(a1(1:1), 2, trim(fin), trim(fout))
      case ('t'); call run_liq(a1(1:1), 3, trim(fin), trim(fout))
@@ -243,6 +243,15 @@ contains
        write (12) alpha
     case ('C')
        call run_cw_rc()
+    case ('R')
+       read (11) h(1:1)
+       nl = int(h(1))
+       allocate (t(nl), freep(nl), rq(2 * nl), vmean(4 * nl), xkmt(8 * nl), henry(nl), alpha(4 * nl))
+       read (11) t, freep, rq, vmean
+       alpha = vmean      ! (gas: the Henry entries before the call, in/out)
+       xkmt = -7.d0; henry = -7.d0
+       call DRY_RATES_BATCH(mech == 1, nl, t, freep, rq, vmean, xkmt, henry, alpha)
+       write (12) xkmt, henry, alpha
     case ('Q')
        read (11) h(1:4)
        nl = int(h(1)); nkc = int(h(2)); j6 = int(h(3)); nspec = int(h(4))

@@ -138,3 +138,24 @@ def test_particle_bin_moments_on_the_device():
     assert np.array_equal(below, (g["wet_feu"] < g["crys4"][:2].min()).astype(np.int32))
     rcd, cwd = chem.cw_rc(g["dry_ff"], g["rq"], g["e"], g["kw"], int(g["ka"]), int(g["ifeed"]), dry=True)
     assert np.array_equal(rcd, g["dry_rc"][:, :2]) and np.array_equal(cwd, g["dry_cw"][:, :2])
+
+
+@pytest.mark.parametrize("mech", ["gas", "aer", "tot"])
+def test_dry_aerosol_uptake_on_the_device(mech):
+    """dry_rates_g / _a / _t (kpp.f90:4697-4853 | 4860-5073 | 5079-5198) from mistra_chem_dry_rates against layers captured from the running reference model
+    (tests/golden/dryrates.npz): xkmtd of aer and tot bit for bit (no library function: the speeds come in), xeq and the gas routine's Henry constants and
+    speeds to the last place of the device exp / sqrt (asserted: 1e-14)."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from mistra_amd import chem
+    chem.init(0)
+    g = np.load(os.path.join(REPO, "tests", "golden", "dryrates.npz"))
+    a = (g[mech + "_tt"], g[mech + "_freep"], g[mech + "_rcd"])
+    if mech == "gas":
+        xk, xeq, h = chem.dry_rates(*a, None, g["gas_henry4_before"])
+        assert _rel(h, g["gas_henry4"]) <= TOL and np.array_equal(h == 0, g["gas_henry4"] == 0)
+        assert _rel(xk, g["gas_xkmtd"]) <= TOL
+    else:
+        xk, xeq = chem.dry_rates(*a, g[mech + "_vmean4"])
+        assert np.array_equal(xk, g[mech + "_xkmtd"])
+    assert _rel(xeq, g[mech + "_xeq"]) <= TOL

@@ -280,3 +280,30 @@ def test_fortran_particle_bin_moments(tmp_path):
         if not dry:
             assert np.array_equal(cm, g["wet_cm"]) and np.array_equal(cv, g["wet_conv2"])
             assert np.array_equal(raw[4 * nl * nb:], (g["wet_feu"] < g["crys4"][:2].min()).astype(np.float64))
+
+
+@needs_flang
+@pytest.mark.parametrize("mech", ["gas", "aer", "tot"])
+def test_fortran_dry_aerosol_uptake(mech, tmp_path):
+    """dry_rates_x from Fortran (DRY_RATES_BATCH of shim/mistra_kpp_liq.f90, what the drop-ins DRY_RATES_HIP_g/_a/_t call after gathering the four species of
+    the routines' idr list) on the captured layers: what the Python entry returns, bit for bit."""
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "shim")], check=True)
+    from mistra_amd import chem
+    chem.init(0)
+    g = np.load(os.path.join(REPO, "tests", "golden", "dryrates.npz"))
+    nl = len(g[mech + "_k"])
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    four = g["gas_henry4_before"] if mech == "gas" else g[mech + "_vmean4"]
+    with open(fin, "wb") as f:
+        np.array([nl], np.float64).tofile(f)
+        for a in (g[mech + "_tt"], g[mech + "_freep"], g[mech + "_rcd"], four):
+            np.ascontiguousarray(a, np.float64).tofile(f)
+    subprocess.run([DRIVER, "R" + mech[0], str(fin), str(fout)], check=True, timeout=300)
+    raw = np.fromfile(fout, np.float64)
+    xk, xeq, h = raw[:8 * nl].reshape(nl, 2, 4), raw[8 * nl:9 * nl], raw[9 * nl:].reshape(nl, 4)
+    if mech == "gas":
+        wk, wq, wh = chem.dry_rates(g["gas_tt"], g["gas_freep"], g["gas_rcd"], None, g["gas_henry4_before"])
+        assert np.array_equal(h, wh)
+    else:
+        wk, wq = chem.dry_rates(g[mech + "_tt"], g[mech + "_freep"], g[mech + "_rcd"], g[mech + "_vmean4"])
+    assert np.array_equal(xk, wk) and np.array_equal(xeq, wq)

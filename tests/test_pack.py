@@ -138,6 +138,23 @@ def test_particle_bin_moments_of_captured_layers():
         assert np.array_equal(rc, g["dry_rc"][i][:2]) and np.array_equal(cw, g["dry_cw"][i][:2])
 
 
+@pytest.mark.parametrize("mech", ["gas", "aer", "tot"])
+def test_dry_aerosol_uptake_of_captured_layers(mech):
+    """dry_rates_g / dry_rates_a / dry_rates_t (kpp.f90:4697-4853 | 4860-5073 | 5079-5198) restated (oracle/liq_py.py: dry_rates_layer) on layers captured
+    from the running reference model (tests/golden/dryrates.npz): xkmtd of the four species in both bins, xeq(HNO3) and — gas — the Henry entries, bit for bit."""
+    from oracle import liq_py
+    g = np.load(os.path.join(REPO, "tests", "golden", "dryrates.npz"))
+    assert len(g[mech + "_k"]) >= 8 and (g[mech + "_rcd"] > 0).any()
+    for i in range(len(g[mech + "_k"])):
+        a = (float(g[mech + "_tt"][i]), float(g[mech + "_freep"][i]), g[mech + "_rcd"][i])
+        if mech == "gas":
+            xk, xeq, h = liq_py.dry_rates_layer(*a, None, g["gas_henry4_before"][i])
+            assert np.array_equal(h, g["gas_henry4"][i])
+        else:
+            xk, xeq = liq_py.dry_rates_layer(*a, g[mech + "_vmean4"][i])
+        assert np.array_equal(xk, g[mech + "_xkmtd"][i]) and xeq == g[mech + "_xeq"][i]
+
+
 def test_tables_in_the_repo_are_what_the_extractor_writes(tmp_path):
     if not os.path.isdir("/root/reference/src"):
         pytest.skip("no reference tree here")
