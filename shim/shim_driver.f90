@@ -39,6 +39,9 @@ program shim_driver
   case ('D'); call run_drive(trim(fin), trim(fout))
   case ('K', 'H', 'Q', 'V', 'S', 'C', 'R')
      select case (a1(2:2))
+     case ('g')
+        if (a1(1:1) /= 'R') stop 'mechanism must be a or t'
+        call run_liq(a1(1:1), 1, trim(fin), trim(fout))
      case ('a'); call run_liq(a1(1:1), 2, trim(fin), trim(fout))
      case ('t'); call run_liq(a1(1:1), 3, trim(fin), trim(fout))
      case default; stop 'mechanism must be a or t'
