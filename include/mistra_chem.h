@@ -277,6 +277,13 @@ int mistra_chem_st_coeff(int mech, int nlayer, int lp_joyce14bc, int lp_buxmann1
  *   below [nlayer]            1 where feu(k) < min(xcryssulf, xcrysss): the reference prints `k, feu(k), ' below both crystal. points'` for those
  *                             layers up to kinv (the Fortran drop-in does, shim/mistra_kpp_model.f90); may be NULL
  * cw_rc computes layers 2..nmaxf, dry_cw_rc nf+1..nmax: the caller hands over that run of layers. */
+/* The host-buffer entries below gather their inputs into a pinned arena, send it up in one stream, and hand the outputs back the same way.  A caller whose
+ * arrays never move — the model's COMMON blocks: ff of /cb52/ is 5.9 MB, /kpp_ltot/ 4.4 MB — registers them ONCE with mistra_chem_pin_host; from then on a
+ * block that lies inside a registered range is copied straight from / to the caller's memory at the link's rate (no staging copy).  The range must stay
+ * mapped until mistra_chem_unpin_host or mistra_chem_finalize; ranges must not overlap.  Not for memory the caller may free (the reference has no such
+ * call: its arrays are static; shim/mistra_kpp_model.f90: LIQ_PIN_ONCE). */
+int mistra_chem_pin_host(void* p, size_t bytes);
+int mistra_chem_unpin_host(void* p);
 /* dry_rates_g (tt,freep,nmax) (kpp.f90:4697-4853; gas != 0) | dry_rates_a (freep,nmaxf) (:4860-5073) | dry_rates_t (freep,nmaxf) (:5079-5198), called by
  * liq_parm every time step (kpp.f90:651-653): the mass-transfer coefficients of HNO3, N2O5, NH3, H2SO4 — the routines' idr list, in that order — onto the
  * dry aerosol of bins 1 and 2, and the equilibrium constant of HNO3.  The four species sit at mechanism-specific places of the model's NSPEC-wide arrays:

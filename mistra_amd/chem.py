@@ -389,6 +389,21 @@ def dry_rates(tt, freep, rcd, vmean4=None, henry4=None):
     return (xk, xeq, h) if gas else (xk, xeq)
 
 
+def pin_host(a):
+    """Registers the memory of a C-contiguous numpy array for direct transfers by the host-buffer entries (include/mistra_chem.h: mistra_chem_pin_host).
+    The array must stay alive, and must not be resized, until unpin_host(a)."""
+    assert a.flags["C_CONTIGUOUS"]
+    L = lib()
+    L.mistra_chem_pin_host.argtypes = [C.c_void_p, C.c_size_t]
+    _check(L.mistra_chem_pin_host(a.ctypes.data, a.nbytes))
+
+
+def unpin_host(a):
+    L = lib()
+    L.mistra_chem_unpin_host.argtypes = [C.c_void_p]
+    _check(L.mistra_chem_unpin_host(a.ctypes.data))
+
+
 def cw_rc(ff, rq, e, kw, ka, ifeed, feu=None, cloud=None, crys4=None, dry=False):
     """cw_rc (dry=False: -> rc, cw, cm, conv2 [nlayer, 4], below [nlayer]) or dry_cw_rc (dry=True: -> rcd, cwd [nlayer, 2]) for a batch of layers;
     numpy arrays in and out (host-buffer entry, include/mistra_chem.h)."""

@@ -368,6 +368,42 @@ bool g_inited = false;
 int g_max_steps = 100000;      // Max_no_steps (gas.f:1042); only mistra_chem_debug_set_max_steps changes it
 std::vector<DeviceState> g_devs;
 
+// host-buffer entries of the liq_parm kernels: arenas on the primary device (see DevBlock below)
+struct LiqStage {
+  char *dev = nullptr, *host = nullptr;
+  size_t cap = 0;
+  hipStream_t st = nullptr;
+  std::vector<std::pair<const char*, size_t>> pinned;      // caller ranges registered by mistra_chem_pin_host
+  hipError_t ensure(size_t bytes) {
+    if (!st)
+      if (hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) return e;
+    if (bytes <= cap) return hipSuccess;
+    if (dev) (void)hipFree(dev);
+    if (host) (void)hipHostFree(host);
+    dev = host = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 4;
+    if (hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), want)) return e;
+    if (hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&host), want, hipHostMallocDefault)) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  bool is_pinned(const void* p, size_t n) const {
+    const char* c = static_cast<const char*>(p);
+    for (const auto& r : pinned)
+      if (c >= r.first && c + n <= r.first + r.second) return true;
+    return false;
+  }
+  void release() {
+    for (const auto& r : pinned) (void)hipHostUnregister(const_cast<char*>(r.first));
+    pinned.clear();
+    if (dev) (void)hipFree(dev);
+    if (host) (void)hipHostFree(host);
+    if (st) (void)hipStreamDestroy(st);
+    dev = host = nullptr; cap = 0; st = nullptr;
+  }
+};
+LiqStage g_liq;
+
 DeviceState* device_slot(int hip_device) {
   for (auto& d : g_devs)
     if (d.id == hip_device) return &d;
@@ -566,6 +602,8 @@ int init_locked(int n, const int* ids) {
     HIP_TRY(hipSetDevice(g_devs[0].id));
     return 0;
   }
+  if (!g_devs.empty() && g_devs[0].id >= 0) (void)hipSetDevice(g_devs[0].id);
+  g_liq.release();
   for (auto& d : g_devs) d.release();
   g_devs.clear();
   g_devs.resize(want.size());
@@ -684,6 +722,8 @@ int mistra_chem_device_count(void) { return g_inited ? (int)g_devs.size() : 0; }
 
 void mistra_chem_finalize(void) {
   std::lock_guard<std::mutex> lock(g_mu);
+  if (!g_devs.empty() && g_devs[0].id >= 0) (void)hipSetDevice(g_devs[0].id);
+  g_liq.release();
   for (auto& d : g_devs) d.release();
   g_devs.clear();
   g_inited = false;
@@ -1116,21 +1156,89 @@ int mistra_chem_equil_co_device(int mech, int nlayer, int nkc, int j6, const dou
   return 0;
 }
 
-// ---- host-buffer forms of the three liq_parm kernels: what a Fortran caller reaches (shim/mistra_kpp_liq.f90).  One device block per call,
-//      copies and kernel on the primary device's default stream, synchronous.
+// ---- host-buffer forms of the liq_parm kernels: what a Fortran caller reaches (shim/mistra_kpp_liq.f90).  One grow-only device arena and a pinned host
+//      arena of the same layout on the primary device, a private stream: a call gathers its inputs into the pinned arena (or, for caller memory that
+//      mistra_chem_pin_host registered, leaves them where they are), sends them up, runs the kernel on the same stream and fetches its outputs; one
+//      stream synchronisation per call, no allocation once the arenas have grown to the column's size.
 namespace {
-struct DevBlock {      // one hipMalloc for a handful of arrays (256-byte aligned sub-blocks), freed on scope exit
-  char* base = nullptr;
-  size_t used = 0, cap = 0;
+struct DevBlock {      // the arrays of one call as 256-byte aligned sub-blocks of the arenas
   std::vector<std::pair<size_t, size_t>> parts;      // (offset, bytes)
-  size_t add(size_t bytes) { const size_t at = cap; parts.emplace_back(at, bytes); cap += (bytes + 255) & ~(size_t)255; return parts.size() - 1; }
-  hipError_t alloc() { return hipMalloc(reinterpret_cast<void**>(&base), cap ? cap : 256); }
-  double* dptr(size_t i) const { return reinterpret_cast<double*>(base + parts[i].first); }
-  hipError_t up(size_t i, const void* host) const { return hipMemcpy(base + parts[i].first, host, parts[i].second, hipMemcpyHostToDevice); }
-  hipError_t down(size_t i, void* host) const { return hipMemcpy(host, base + parts[i].first, parts[i].second, hipMemcpyDeviceToHost); }
-  ~DevBlock() { if (base) (void)hipFree(base); }
+  std::vector<const void*> src;                      // per part: where its input comes from (nullptr: not an input)
+  std::vector<void*> dst;                            // per part: where its output goes (nullptr: not an output)
+  size_t cap = 0;
+  size_t add(size_t bytes) {
+    const size_t at = cap;
+    parts.emplace_back(at, bytes); src.push_back(nullptr); dst.push_back(nullptr);
+    cap += (bytes + 255) & ~(size_t)255;
+    return parts.size() - 1;
+  }
+  hipError_t alloc() { return g_liq.ensure(cap ? cap : 256); }
+  double* dptr(size_t i) const { return reinterpret_cast<double*>(g_liq.dev + parts[i].first); }
+  hipError_t up(size_t i, const void* from) { src[i] = from; return hipSuccess; }
+  // every transfer costs ~15 us of latency in the stream whatever its size: neighbouring staged parts travel as ONE copy (the padding between them with
+  // them), parts inside a registered caller range go straight from / to the caller's memory
+  hipError_t transfer(bool upward) {
+    size_t i = 0;
+    while (i < parts.size()) {
+      const void* p = upward ? src[i] : dst[i];
+      if (!p) { i++; continue; }
+      if (g_liq.is_pinned(p, parts[i].second)) {
+        hipError_t e = upward ? hipMemcpyAsync(g_liq.dev + parts[i].first, p, parts[i].second, hipMemcpyHostToDevice, g_liq.st)
+                              : hipMemcpyAsync(const_cast<void*>(p), g_liq.dev + parts[i].first, parts[i].second, hipMemcpyDeviceToHost, g_liq.st);
+        if (e != hipSuccess) return e;
+        i++;
+        continue;
+      }
+      size_t j = i;      // the run of staged parts i..j-1
+      while (j < parts.size() && (upward ? src[j] : dst[j]) && !g_liq.is_pinned(upward ? src[j] : dst[j], parts[j].second)) {
+        if (upward) std::memcpy(g_liq.host + parts[j].first, src[j], parts[j].second);
+        j++;
+      }
+      const size_t lo = parts[i].first, hi = parts[j - 1].first + parts[j - 1].second;
+      hipError_t e = upward ? hipMemcpyAsync(g_liq.dev + lo, g_liq.host + lo, hi - lo, hipMemcpyHostToDevice, g_liq.st)
+                            : hipMemcpyAsync(g_liq.host + lo, g_liq.dev + lo, hi - lo, hipMemcpyDeviceToHost, g_liq.st);
+      if (e != hipSuccess) return e;
+      i = j;
+    }
+    return hipSuccess;
+  }
+  hipError_t send() { return transfer(true); }      // after the last up(), before the kernel
+  hipStream_t stream() const { return g_liq.st; }
+  hipError_t down(size_t i, void* to) { dst[i] = to; return hipSuccess; }
+  hipError_t finish() {       // after the last down(): fetch, wait, hand the staged outputs to the caller
+    if (hipError_t e = transfer(false)) return e;
+    if (hipError_t e = hipStreamSynchronize(g_liq.st)) return e;
+    for (size_t i = 0; i < parts.size(); i++)
+      if (dst[i] && !g_liq.is_pinned(dst[i], parts[i].second)) std::memcpy(dst[i], g_liq.host + parts[i].first, parts[i].second);
+    return hipSuccess;
+  }
 };
 }  // namespace
+
+int mistra_chem_pin_host(void* p, size_t bytes) {
+  if (int rc = lazy_init()) return rc;
+  if (!p || !bytes) return fail("mistra_chem_pin_host: null range");
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (g_liq.is_pinned(p, bytes)) return 0;
+  const char* c = static_cast<const char*>(p);
+  for (const auto& r : g_liq.pinned)
+    if (c < r.first + r.second && r.first < c + bytes) return fail("mistra_chem_pin_host: the range overlaps one registered before");
+  HIP_TRY(hipSetDevice(g_devs[0].id));
+  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  g_liq.pinned.emplace_back(c, bytes);
+  return 0;
+}
+
+int mistra_chem_unpin_host(void* p) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  for (size_t i = 0; i < g_liq.pinned.size(); i++)
+    if (g_liq.pinned[i].first == static_cast<const char*>(p)) {
+      HIP_TRY(hipHostUnregister(p));
+      g_liq.pinned.erase(g_liq.pinned.begin() + (long)i);
+      return 0;
+    }
+  return fail("mistra_chem_unpin_host: not a registered range");
+}
 
 int mistra_chem_fast_k_mt(int mech, int nlayer, const double* ff, const double* rq, const int32_t* kw, int nkw, int ka, int ifeed, int nkc_l,
                           const double* cw, const double* cm, const double* freep, const double* alpha, const double* vmean, double* xkmt,
@@ -1155,13 +1263,14 @@ int mistra_chem_fast_k_mt(int mech, int nlayer, const double* ff, const double* 
   HIP_TRY(B.up(i_ff, ff)); HIP_TRY(B.up(i_rq, rq)); HIP_TRY(B.up(i_cw, cw)); HIP_TRY(B.up(i_cm, cm)); HIP_TRY(B.up(i_fp, freep)); HIP_TRY(B.up(i_al, alpha));
   HIP_TRY(B.up(i_vm, vmean)); HIP_TRY(B.up(i_xk, xkmt));
   if (vt) { HIP_TRY(B.up(i_t, t)); HIP_TRY(B.up(i_p, p)); HIP_TRY(B.up(i_vt, vt)); }
+  HIP_TRY(B.send());
   if (int rc = mistra_chem_fast_k_mt_device(mech, nlayer, B.dptr(i_ff), B.dptr(i_rq), kw, nkw, ka, ifeed, nkc_l, B.dptr(i_cw), B.dptr(i_cm),
                                             B.dptr(i_fp), B.dptr(i_al), B.dptr(i_vm), B.dptr(i_xk), vt ? B.dptr(i_t) : nullptr,
-                                            vt ? B.dptr(i_p) : nullptr, vt ? B.dptr(i_vt) : nullptr, nullptr))
+                                            vt ? B.dptr(i_p) : nullptr, vt ? B.dptr(i_vt) : nullptr, B.stream()))
     return rc;
-  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(B.down(i_xk, xkmt));
   if (vt) HIP_TRY(B.down(i_vt, vt));
+  HIP_TRY(B.finish());
   return 0;
 }
 
@@ -1180,9 +1289,10 @@ int mistra_chem_henry(int mech, int nlayer, const double* tt, double* henry) {
   const size_t i_t = B.add(nl * sizeof(double)), i_h = B.add(nl * nspec * sizeof(double));
   HIP_TRY(B.alloc());
   HIP_TRY(B.up(i_t, tt));
-  if (int rc = mistra_chem_henry_device(mech, nlayer, B.dptr(i_t), B.dptr(i_h), nullptr)) return rc;
-  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.send());
+  if (int rc = mistra_chem_henry_device(mech, nlayer, B.dptr(i_t), B.dptr(i_h), B.stream())) return rc;
   HIP_TRY(B.down(i_h, henry));
+  HIP_TRY(B.finish());
   return 0;
 }
 
@@ -1203,10 +1313,11 @@ int mistra_chem_dry_rates(int gas, int nlayer, const double* tt, const double* f
   HIP_TRY(B.up(i_t, tt)); HIP_TRY(B.up(i_f, freep)); HIP_TRY(B.up(i_r, rcd));
   if (gas) HIP_TRY(B.up(i_h, henry4)); else HIP_TRY(B.up(i_v, vmean4));
   const DryRatesArgs A{nlayer, gas ? 1 : 0, B.dptr(i_t), B.dptr(i_f), B.dptr(i_r), B.dptr(i_v), B.dptr(i_x), B.dptr(i_q), B.dptr(i_h)};
-  LAUNCH_TRY(launch_dry_rates(A, nullptr));
-  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.send());
+  LAUNCH_TRY(launch_dry_rates(A, B.stream()));
   HIP_TRY(B.down(i_x, xkmtd)); HIP_TRY(B.down(i_q, xeq));
   if (gas) HIP_TRY(B.down(i_h, henry4));
+  HIP_TRY(B.finish());
   return 0;
 }
 
@@ -1214,7 +1325,7 @@ int mistra_chem_cw_rc(int nlayer, int nkt, int nka, int dry, const double* ff, c
                       const double* feu, const int32_t* cloud, const double* crys4, double* rc, double* cw, double* cm, double* conv2, int32_t* below) {
   if (int rc0 = lazy_init()) return rc0;
   if (nlayer == 0) return 0;
-  if (nlayer < 0 || nkt < 1 || nka < 1 || nkt > 4096 || nka > 4096 || ka < 0 || ka > nka) return fail("cw_rc: bad dimensions");
+  if (nlayer < 0 || nkt < 1 || nka < 1 || nkt > 2048 || nka > 4096 || ka < 0 || ka > nka) return fail("cw_rc: bad dimensions (nkt <= 2048, nka <= 4096)");
   if (!ff || !rq || !kw || !rc || !cw || (!dry && (!e || !feu || !cloud || !crys4 || !cm || !conv2))) return fail("null pointer");
   for (int i = 0; i < nka; i++)
     if (kw[i] < 0 || kw[i] > nkt) return fail("kw out of range");      // the kernel's loop limits: checked here, on the host
@@ -1235,10 +1346,11 @@ int mistra_chem_cw_rc(int nlayer, int nkt, int nka, int dry, const double* ff, c
   A.kw = reinterpret_cast<const int32_t*>(B.dptr(i_kw)); A.ff = B.dptr(i_ff); A.rq = B.dptr(i_rq); A.e = B.dptr(i_e); A.feu = B.dptr(i_feu);
   A.cloud = reinterpret_cast<const int32_t*>(B.dptr(i_cl)); A.rc = B.dptr(i_rc); A.cw = B.dptr(i_cw); A.cm = B.dptr(i_cm); A.conv2 = B.dptr(i_cv);
   A.below = reinterpret_cast<int32_t*>(B.dptr(i_bl));
-  LAUNCH_TRY(launch_cw_rc(A, nullptr));
-  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.send());
+  LAUNCH_TRY(launch_cw_rc(A, B.stream()));
   HIP_TRY(B.down(i_rc, rc)); HIP_TRY(B.down(i_cw, cw));
   if (!dry) { HIP_TRY(B.down(i_cm, cm)); HIP_TRY(B.down(i_cv, conv2)); if (below) HIP_TRY(B.down(i_bl, below)); }
+  HIP_TRY(B.finish());
   return 0;
 }
 
@@ -1257,9 +1369,10 @@ int mistra_chem_st_coeff(int mech, int nlayer, int lp_joyce14bc, int lp_buxmann1
   const size_t i_e = B.add(nl * nenv * sizeof(double)), i_a = B.add(nl * nspec * sizeof(double));
   HIP_TRY(B.alloc());
   HIP_TRY(B.up(i_e, env));
-  if (int rc = mistra_chem_st_coeff_device(mech, nlayer, lp_joyce14bc, lp_buxmann15alph, B.dptr(i_e), B.dptr(i_a), nullptr)) return rc;
-  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.send());
+  if (int rc = mistra_chem_st_coeff_device(mech, nlayer, lp_joyce14bc, lp_buxmann15alph, B.dptr(i_e), B.dptr(i_a), B.stream())) return rc;
   HIP_TRY(B.down(i_a, alpha));
+  HIP_TRY(B.finish());
   return 0;
 }
 
@@ -1278,9 +1391,10 @@ int mistra_chem_v_mean(int mech, int nlayer, const double* tt, double* vmean) {
   const size_t i_t = B.add(nl * sizeof(double)), i_v = B.add(nl * nspec * sizeof(double));
   HIP_TRY(B.alloc());
   HIP_TRY(B.up(i_t, tt));
-  if (int rc = mistra_chem_v_mean_device(mech, nlayer, B.dptr(i_t), B.dptr(i_v), nullptr)) return rc;
-  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(B.send());
+  if (int rc = mistra_chem_v_mean_device(mech, nlayer, B.dptr(i_t), B.dptr(i_v), B.stream())) return rc;
   HIP_TRY(B.down(i_v, vmean));
+  HIP_TRY(B.finish());
   return 0;
 }
 
@@ -1299,10 +1413,11 @@ int mistra_chem_equil_co(int mech, int nlayer, int nkc, int j6, const double* tt
   const size_t i_t = B.add(nl * d8), i_c = B.add(nl * nkc * d8), i_g = B.add(nl * nkc * j6 * d8), i_f = B.add(nl * nkc * nspec * d8), i_b = B.add(nl * nkc * nspec * d8);
   HIP_TRY(B.alloc());
   HIP_TRY(B.up(i_t, tt)); HIP_TRY(B.up(i_c, conv2)); HIP_TRY(B.up(i_g, xgamma)); HIP_TRY(B.up(i_f, xkef)); HIP_TRY(B.up(i_b, xkeb));
-  if (int rc = mistra_chem_equil_co_device(mech, nlayer, nkc, j6, B.dptr(i_t), B.dptr(i_c), B.dptr(i_g), B.dptr(i_f), B.dptr(i_b), nullptr))
+  HIP_TRY(B.send());
+  if (int rc = mistra_chem_equil_co_device(mech, nlayer, nkc, j6, B.dptr(i_t), B.dptr(i_c), B.dptr(i_g), B.dptr(i_f), B.dptr(i_b), B.stream()))
     return rc;
-  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(B.down(i_f, xkef)); HIP_TRY(B.down(i_b, xkeb));
+  HIP_TRY(B.finish());
   return 0;
 }
 

@@ -151,49 +151,83 @@ __device__ double vterm_dev(double a, double t, double p) {
 // (str.f90:2704, 2751):
 //     xx1 = sum_ia sum_jt  r*r*r * vterm(r, t, p) * ff(jt,ia) * 1e6                       (the routine's l = 1 pass)
 //     vt(kc) = 4 pi / (3 cw(kc)) * xx1                                                    where cw(kc) > 0
-// One thread per (layer, bin, species) walks its sum in the reference's order (ia outer, jt inner; one rounding per operation), so the
-// coefficients are bit-identical; the lanes of a wave are the species of one (layer, bin): they read the same ff / rq element at a time
-// (broadcast).  Lane 0 carries the vt sum beside its species' (vt == nullptr: the caller does not want it).
-__global__ __launch_bounds__(64) void fast_k_mt_kernel(const KmtDev K, int nlayer, const double* __restrict__ ff, const double* __restrict__ rq,
-                                                       const double* __restrict__ cw, const double* __restrict__ cm, const double* __restrict__ freep,
-                                                       const double* __restrict__ alpha, const double* __restrict__ vmean, double* __restrict__ xkmt,
-                                                       const double* __restrict__ tt, const double* __restrict__ pp, double* __restrict__ vt) {
-  const int layer = blockIdx.x, kc = blockIdx.y + 1, l = threadIdx.x;      // kc 1-based as in the Fortran
-  if (layer >= nlayer || kc > K.nkc_l || l >= K.nx) return;
+// One workgroup of sixteen waves per (layer, bin).  A sum's ORDER is its value (ia outer, jt inner; one rounding per operation) but its terms are not
+// ordered: waves 1..15 form the terms of a chunk of 60 grid cells — lane = species, every lane of a wave at the same cell, so ff / rq are broadcast reads;
+// a cell outside the bin's jt range contributes +0.0, which leaves a non-negative sum as it is — into one half of an LDS buffer while wave 0 adds the
+// previous chunk's terms, cell by cell in the reference's order, out of the other half (lane = species; its reads run ahead of the add chain).  The vt sum
+// rides in lane 63: its terms (Beard's polynomial, the expensive one) are formed by lanes 60..63 of each wave, one cell each.  Bit-identical to the thread
+// per species that walked the whole bin alone (the round-3 kernel: 0.64 ms per column against ~0.06 ms).
+constexpr int kKmtWaves = 16, kKmtU = 4, kKmtCells = (kKmtWaves - 1) * kKmtU;      // 60 cells per chunk, 2 x 30 KB of LDS
+__global__ __launch_bounds__(kKmtWaves * 64) void fast_k_mt_kernel(const KmtDev K, int nlayer, const double* __restrict__ ff, const double* __restrict__ rq,
+                                                                    const double* __restrict__ cw, const double* __restrict__ cm,
+                                                                    const double* __restrict__ freep, const double* __restrict__ alpha,
+                                                                    const double* __restrict__ vmean, double* __restrict__ xkmt,
+                                                                    const double* __restrict__ tt, const double* __restrict__ pp, double* __restrict__ vt) {
+  __shared__ double buf[2][kKmtCells][64];
+  const int layer = blockIdx.x, kc = blockIdx.y + 1, w = threadIdx.x / 64, l = threadIdx.x % 64;      // kc 1-based as in the Fortran
+  if (layer >= nlayer || kc > K.nkc_l) return;                                                          // (uniform in the workgroup, like every exit below)
   const double cmk = cm[(size_t)layer * K.nkc + (kc - 1)], cwk = cw[(size_t)layer * K.nkc + (kc - 1)];
-  const bool llchem = cmk > 0.0, do_vt = vt != nullptr && l == 0;      // (the dry case only integrates vt: lmax = 1, kpp.f90:2560-2566)
+  const bool llchem = cmk > 0.0, do_vt = vt != nullptr;      // (the dry case only integrates vt: lmax = 1, kpp.f90:2560-2566)
   if (!llchem && !do_vt) return;
-  const int sp = K.lex[l] - 1;
-  const double al = alpha[(size_t)layer * K.nspec + sp], vm = vmean[(size_t)layer * K.nspec + sp], fp = freep[layer];
+  const bool species = llchem && l < K.nx;
+  const int sp = species ? K.lex[l] - 1 : 0;
+  const double al = species ? alpha[(size_t)layer * K.nspec + sp] : 0.0, vm = species ? vmean[(size_t)layer * K.nspec + sp] : 0.0, fp = freep[layer];
   const double tk = do_vt ? tt[layer] : 0.0, pk = do_vt ? pp[layer] : 0.0;
-  double x1 = 0.0, xk1 = 0.0, xx1 = 0.0;
+  double x1 = 0.0;
   if (al > 0.0) x1 = 4.0 / (3.0 * al);            // 4./(3.*alpha): default-REAL literals, exact
   int ia0, ia1;                                   // summation limits (1): the aerosol-size axis, 1-based inclusive
   if (kc == 1 || kc == 3) { ia0 = K.ifeed == 2 ? 2 : 1; ia1 = K.ka; }
   else { ia0 = K.ka + 1; ia1 = K.nka; }
+  const bool low_jt = kc == 1 || kc == 2;         // limits (2), the water axis: jt <= kw(ia) | jt > kw(ia)
+  const int ncell = ia1 >= ia0 ? (ia1 - ia0 + 1) * K.nkt : 0, nchunk = (ncell + kKmtCells - 1) / kKmtCells;
   const double* F = ff + (size_t)layer * K.nka * K.nkt;      // ff(jt,ia,k): jt fastest
-  for (int ia = ia0; ia <= ia1; ia++) {
-    int jt0, jt1;                                 // limits (2): the water axis
-    if (kc == 1 || kc == 2) { jt0 = 1; jt1 = K.kw[ia - 1]; }
-    else { jt0 = K.kw[ia - 1] + 1; jt1 = K.nkt; }
-    for (int jt = jt0; jt <= jt1; jt++) {
-      const double rqq = rq[(size_t)(ia - 1) * K.nkt + (jt - 1)] * 1.0e-6;      // rqm = rq * 1.d-6
-      const double fv = F[(size_t)(ia - 1) * K.nkt + (jt - 1)];
-      if (llchem) {
-        const double x2 = vm / (rqq / fp + x1);
-        xk1 = xk1 + (((x2 * rqq) * rqq) * fv) * 1.0e6;
+  double acc = 0.0;                               // wave 0: xk1 of species l; lane 63: xx1
+  for (int i = 0; i <= nchunk; i++) {
+    if (w > 0 && i < nchunk) {
+      double (*B)[64] = buf[i & 1];
+      const int n0 = i * kKmtCells + (w - 1) * kKmtU;
+#pragma unroll
+      for (int u = 0; u < kKmtU; u++) {
+        const int n = n0 + u, ia = ia0 + n / K.nkt, jt = 1 + n % K.nkt;
+        double term = 0.0;
+        if (n < ncell) {
+          const int kwa = K.kw[ia - 1];
+          if (low_jt ? jt <= kwa : jt > kwa) {
+            const double rqq = rq[(size_t)(ia - 1) * K.nkt + (jt - 1)] * 1.0e-6;      // rqm = rq * 1.d-6
+            const double fv = F[(size_t)(ia - 1) * K.nkt + (jt - 1)];
+            if (species) {
+              const double x2 = vm / (rqq / fp + x1);
+              term = (((x2 * rqq) * rqq) * fv) * 1.0e6;
+            }
+          }
+        }
+        B[(w - 1) * kKmtU + u][l] = term;
       }
-      if (do_vt) {
-        const double xvs = vterm_dev(rqq, tk, pk);
-        xx1 = xx1 + ((((rqq * rqq) * rqq) * xvs) * fv) * 1.0e6;
+      if (do_vt && l >= 64 - kKmtU) {             // (behind the stores above: lane 63's zero is overwritten)
+        const int u = l - (64 - kKmtU), n = n0 + u, ia = ia0 + n / K.nkt, jt = 1 + n % K.nkt;
+        double term = 0.0;
+        if (n < ncell) {
+          const int kwa = K.kw[ia - 1];
+          if (low_jt ? jt <= kwa : jt > kwa) {
+            const double rqq = rq[(size_t)(ia - 1) * K.nkt + (jt - 1)] * 1.0e-6;
+            const double fv = F[(size_t)(ia - 1) * K.nkt + (jt - 1)];
+            const double xvs = vterm_dev(rqq, tk, pk);
+            term = ((((rqq * rqq) * rqq) * xvs) * fv) * 1.0e6;
+          }
+        }
+        B[(w - 1) * kKmtU + u][63] = term;
       }
+    } else if (w == 0 && i > 0) {
+      const double (*B)[64] = buf[(i - 1) & 1];
+#pragma unroll 4
+      for (int c = 0; c < kKmtCells; c++) acc = acc + B[c][l];
     }
+    __syncthreads();
   }
-  if (cwk > 0.0) {
-    constexpr double z4pi3 = 4.0 * 3.1415926535897932 / 3.0;      // z4pi3 = 4._dp * pi / 3._dp (constants.f90:54)
-    if (llchem) xkmt[((size_t)layer * K.nkc + (kc - 1)) * K.nspec + sp] = z4pi3 / cwk * xk1;
-    if (do_vt) vt[(size_t)layer * K.nkc + (kc - 1)] = z4pi3 / cwk * xx1;
-  }
+  if (w != 0 || !(cwk > 0.0)) return;
+  constexpr double z4pi3 = 4.0 * 3.1415926535897932 / 3.0;      // z4pi3 = 4._dp * pi / 3._dp (constants.f90:54)
+  if (species) xkmt[((size_t)layer * K.nkc + (kc - 1)) * K.nspec + sp] = z4pi3 / cwk * acc;
+  if (do_vt && l == 63) vt[(size_t)layer * K.nkc + (kc - 1)] = z4pi3 / cwk * acc;
 }
 
 }  // namespace
@@ -256,35 +290,62 @@ __global__ __launch_bounds__(256) void equil_co_kernel(const LiqDev L, int nlaye
   xkeb[at] = liq_product(L, L.boff[e], L.foff[e + 1], T, cv2, xg);
 }
 
-// cw_rc (kpp.f90:2152-2414) | dry_cw_rc (kpp.f90:4580-4690): one thread per (layer, bin) walks the bin's part of the particle grid in the reference's
-// order — dry-aerosol classes ia ascending, droplet classes jt ascending inside — with the reference's three running sums: every sum is a serial chain
-// of ~1 200 additions whose order is its value, and a column of layers times four bins is parallel enough for what is a few microseconds of work.
+// cw_rc (kpp.f90:2152-2414) | dry_cw_rc (kpp.f90:4580-4690): one workgroup per layer.  The reference walks the particle grid — dry-aerosol classes ia
+// ascending, droplet classes jt ascending inside — with three running sums per bin; every sum is a serial chain of ~1 200 additions whose order is its value.
+// The TERMS do not depend on that order: all 256 threads form them for a chunk of grid rows (coalesced reads of ff and rq, the products into LDS), then
+// wave kc walks bin kc's cells of the chunk in the reference's order, lanes 0..2 adding one of the three sums each out of LDS (the reads run ahead of the
+// additions: nothing but the add chain is serial).  Per layer ~10 us instead of the ~1 ms of a thread that fetched and multiplied as it went.
 //   bin 1: ia <= ka, jt <= kw(ia)    bin 3: ia <= ka, jt > kw(ia)    bin 2: ia > ka, jt <= kw(ia)    bin 4: ia > ka, jt > kw(ia)
 //   x0 = ff*xpi*rq**3 (rq**3 as the compiler expands it: rq*rq*rq); cw += x0; rc += x0*rq; cm += ff*e(jt)
 // xpi = 4._dp/3._dp*pi in cw_rc and 4./3.*pi — a single-precision 4/3 — in dry_cw_rc.  One rounding per operation (-ffp-contract=off).
-__global__ __launch_bounds__(64) void cw_rc_kernel(const CwRcArgs A) {
+constexpr int kCwRcChunk = 2048;      // grid cells per chunk: 3 x 16 KB of LDS
+__global__ __launch_bounds__(256) void cw_rc_kernel(const CwRcArgs A) {
   constexpr double pi = 3.1415926535897932;                              // constants.f90:54
   constexpr double cwm = 1.0e-1, cwmd = 1.0e2;                           // kpp.f90:2195-2196
+  __shared__ double term[3][kCwRcChunk];
+  __shared__ double sums[4][3];
   const int nbin = A.dry ? 2 : 4;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, k = tid / 4, kc = tid % 4;
-  if (k >= A.nlayer || kc >= nbin) return;
+  const int k = blockIdx.x, t = threadIdx.x, kc = t / 64, which = t % 64;
   const double xpi = A.dry ? (double)(4.0f / 3.0f) * pi : 4.0 / 3.0 * pi;
   const bool small_ia = (kc == 0 || kc == 2);
-  const int ia0 = small_ia ? A.ial : A.ka + 1, ia1 = small_ia ? A.ka : A.nka;      // 1-based, inclusive
+  const int ia0 = small_ia ? A.ial : A.ka + 1, ia1 = small_ia ? A.ka : A.nka;      // this wave's bin: 1-based, inclusive
   const double* ffk = A.ff + (size_t)k * A.nka * A.nkt;
-  double cws = 0.0, rcs = 0.0, cms = 0.0;
-  for (int ia = ia0; ia <= ia1; ia++) {
-    const int kwa = A.kw[ia - 1];
-    const int jt0 = kc < 2 ? 1 : kwa + 1, jt1 = kc < 2 ? kwa : A.nkt;
-    for (int jt = jt0; jt <= jt1; jt++) {
-      const double f = ffk[(size_t)(ia - 1) * A.nkt + (jt - 1)], r = A.rq[(size_t)(ia - 1) * A.nkt + (jt - 1)];
+  const int rows = kCwRcChunk / A.nkt;                                   // grid rows (ia) per chunk; the host checks nkt <= kCwRcChunk
+  double acc = 0.0;
+  for (int r0 = 1; r0 <= A.nka; r0 += rows) {                            // rows r0 .. r1 of the grid
+    const int r1 = r0 + rows - 1 < A.nka ? r0 + rows - 1 : A.nka, ncell = (r1 - r0 + 1) * A.nkt;
+    __syncthreads();
+    for (int c = t; c < ncell; c += 256) {
+      const size_t g = (size_t)(r0 - 1) * A.nkt + c;
+      const double f = ffk[g], r = A.rq[g];
       const double x0 = (f * xpi) * ((r * r) * r);
-      cws = cws + x0;
-      rcs = rcs + x0 * r;
-      if (!A.dry) cms = cms + f * A.e[jt - 1];
+      term[0][c] = x0;
+      term[1][c] = x0 * r;
+      if (!A.dry) term[2][c] = f * A.e[c % A.nkt];
+    }
+    __syncthreads();
+    if (kc < nbin && which < (A.dry ? 2 : 3)) {
+      const double* tm = term[which];
+      const int lo = ia0 > r0 ? ia0 : r0, hi = ia1 < r1 ? ia1 : r1;
+      for (int ia = lo; ia <= hi; ia++) {
+        const int kwa = A.kw[ia - 1];
+        const int jt0 = kc < 2 ? 1 : kwa + 1, jt1 = kc < 2 ? kwa : A.nkt;
+        const double* row = tm + (ia - r0) * A.nkt - 1;
+        int jt = jt0;
+        for (; jt + 7 <= jt1; jt += 8) {            // eight reads in flight, then the eight additions in order
+          const double v0 = row[jt], v1 = row[jt + 1], v2 = row[jt + 2], v3 = row[jt + 3], v4 = row[jt + 4], v5 = row[jt + 5], v6 = row[jt + 6], v7 = row[jt + 7];
+          acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3; acc = acc + v4; acc = acc + v5; acc = acc + v6; acc = acc + v7;
+        }
+        for (; jt <= jt1; jt++) acc = acc + row[jt];
+      }
     }
   }
-  const size_t at = (size_t)k * nbin + kc;
+  if (kc < nbin && which < 3) sums[kc][which] = acc;
+  __syncthreads();
+  if (t >= nbin) return;      // thread b finishes bin b
+  const int b = t;
+  const double cws = sums[b][0], rcs = sums[b][1], cms = A.dry ? 0.0 : sums[b][2];
+  const size_t at = (size_t)k * nbin + b;
   A.rc[at] = cws > 0.0 ? (rcs / cws) * 1.0e-6 : 0.0;
   A.cw[at] = cws * 1.0e-12;
   if (A.dry) return;
@@ -293,11 +354,11 @@ __global__ __launch_bounds__(64) void cw_rc_kernel(const CwRcArgs A) {
   bool on;
   if (feu < xmin) {
     on = false;
-    if (kc == 0) A.below[k] = 1;
+    if (b == 0) A.below[k] = 1;
   } else {
-    if (kc == 0) A.below[k] = 0;
-    if (kc == 0) on = cws >= cwm && ((A.cloud[(size_t)k * 4 + 0] != 0 && feu >= A.xcryssulf) || feu >= A.xdelisulf);
-    else if (kc == 1) on = cws >= cwm && ((A.cloud[(size_t)k * 4 + 1] != 0 && feu >= A.xcrysss) || feu >= A.xdeliss);
+    if (b == 0) A.below[k] = 0;
+    if (b == 0) on = cws >= cwm && ((A.cloud[(size_t)k * 4 + 0] != 0 && feu >= A.xcryssulf) || feu >= A.xdelisulf);
+    else if (b == 1) on = cws >= cwm && ((A.cloud[(size_t)k * 4 + 1] != 0 && feu >= A.xcrysss) || feu >= A.xdeliss);
     else on = cws >= cwmd;
   }
   A.cm[at] = on ? cms * 1.0e-3 : 0.0;
@@ -305,7 +366,8 @@ __global__ __launch_bounds__(64) void cw_rc_kernel(const CwRcArgs A) {
 }
 hipError_t launch_cw_rc(const CwRcArgs& A, hipStream_t stream) {
   if (A.nlayer <= 0) return hipSuccess;
-  hipLaunchKernelGGL(cw_rc_kernel, dim3((unsigned)((A.nlayer * 4 + 63) / 64)), dim3(64), 0, stream, A);
+  if (A.nkt > kCwRcChunk) return hipErrorInvalidValue;      // one grid row per chunk at least (capi.cpp refuses such a grid with a message)
+  hipLaunchKernelGGL(cw_rc_kernel, dim3((unsigned)A.nlayer), dim3(256), 0, stream, A);
   return hipGetLastError();
 }
 
@@ -386,8 +448,8 @@ hipError_t launch_equil_co(const LiqDev& L, int nlayer, int nkc, int j6, const d
 hipError_t launch_fast_k_mt(const KmtDev& K, int nlayer, const double* ff, const double* rq, const double* cw, const double* cm, const double* freep,
                             const double* alpha, const double* vmean, double* xkmt, const double* tt, const double* pp, double* vt, hipStream_t stream) {
   if (nlayer <= 0) return hipSuccess;
-  if (K.nx > 64 || K.nka > kKmtMaxNka) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fast_k_mt_kernel, dim3((unsigned)nlayer, (unsigned)K.nkc_l), dim3(64), 0, stream, K, nlayer, ff, rq, cw, cm, freep, alpha, vmean, xkmt, tt, pp, vt);
+  if (K.nx > 64 - kKmtU || K.nka > kKmtMaxNka) return hipErrorInvalidValue;      // (lanes 60..63 form the vt terms)
+  hipLaunchKernelGGL(fast_k_mt_kernel, dim3((unsigned)nlayer, (unsigned)K.nkc_l), dim3(kKmtWaves * 64), 0, stream, K, nlayer, ff, rq, cw, cm, freep, alpha, vmean, xkmt, tt, pp, vt);
   return hipGetLastError();
 }
 

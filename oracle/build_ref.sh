@@ -84,6 +84,12 @@ if [ "$WHAT" = model ] || [ "$WHAT" = all ]; then
       -Wl,--wrap=gas_drive_ -Wl,--wrap=aer_drive_ -Wl,--wrap=tot_drive_ -Wl,--wrap=fast_k_mt_a_ -Wl,--wrap=fast_k_mt_t_ \
       -Wl,--wrap=henry_a_ -Wl,--wrap=henry_t_ -Wl,--wrap=equil_co_a_ -Wl,--wrap=equil_co_t_ -Wl,--wrap=v_mean_a_ -Wl,--wrap=v_mean_t_ -Wl,--wrap=st_coeff_a_ -Wl,--wrap=st_coeff_t_ -Wl,--wrap=cw_rc_ -Wl,--wrap=dry_cw_rc_ -Wl,--wrap=dry_rates_g_ -Wl,--wrap=dry_rates_a_ -Wl,--wrap=dry_rates_t_ \
       -Wl,--unresolved-symbols=ignore-all
+  # the same model with nothing captured: every routine liq_parm calls (and liq_parm, pitzer, kpp_driver) behind a clock (time_liq_wrap.c)
+  gcc -O2 -c "$HERE/time_liq_wrap.c" -o time_liq_wrap.o
+  echo "  LD mistra_time"
+  TW=""; for r in liq_parm gasdrydep cw_rc v_mean_a henry_a st_coeff_a equil_co_a fast_k_mt_a v_mean_t henry_t st_coeff_t equil_co_t fast_k_mt_t \
+      dry_cw_rc dry_rates_g dry_rates_a dry_rates_t activ pitzer kpp_driver; do TW="$TW -Wl,--wrap=${r}_"; done
+  "$FC" -o "$OUT/mistra_time" column_driver.o $(objs $MODS $CHEM ${REST% str.f90}) str_lib.o time_liq_wrap.o $TW -Wl,--unresolved-symbols=ignore-all
 fi
 
 { echo "compiler: $("$FC" --version | head -1)"; echo "flags: $FFLAGS"; echo "reference: $REF";

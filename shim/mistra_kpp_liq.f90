@@ -68,8 +68,21 @@ module mistra_kpp_liq
        real(c_double) :: xkef(*), xkeb(*)
        integer(c_int) :: rc
      end function mistra_chem_equil_co
+     function mistra_chem_pin_host(p, bytes) bind(C, name="mistra_chem_pin_host") result(rc)
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: p
+       integer(c_size_t), value :: bytes
+       integer(c_int) :: rc
+     end function mistra_chem_pin_host
   end interface
 contains
+  ! registers n doubles starting at a (a model array that never moves) for direct transfers; a refusal is not an error: the call then stages as before
+  subroutine PIN_HOST(a, n)
+    real(c_double), target, intent(in) :: a(*)
+    integer, intent(in) :: n
+    if (mistra_chem_pin_host(c_loc(a), int(n, c_size_t) * 8_c_size_t) /= 0) print *, 'mistra_kpp_liq: model array not registered, transfers are staged'
+  end subroutine PIN_HOST
+
   ! ff(nkt,nka,nlayer), rq(nkt,nka), kw(nka), cw / cm(nkc,nlayer), freep(nlayer), alpha / vmean(NSPEC,nlayer), xkmt(NSPEC,nkc,nlayer) in/out,
   ! t / p(nlayer), vt(nkc,nlayer) in/out
   subroutine FAST_K_MT_BATCH(mech, nlayer, ff, rq, nka, kw, ka, ifeed, nkc_l, cw, cm, freep, alpha, vmean, xkmt, t, p, vt)

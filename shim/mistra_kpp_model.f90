@@ -188,6 +188,24 @@ subroutine DRY_RATES_HIP_t(freep, nmaxf)          ! dry_rates_t (freep,nmaxf), k
   end do
 end subroutine DRY_RATES_HIP_t
 
+subroutine LIQ_PIN_ONCE      ! the model arrays liq_parm's kernels move in bulk, registered for direct transfers on the first call (include/mistra_chem.h)
+  USE global_params, ONLY : n, nf, nka, nkt, nkc
+  USE mistra_kpp_liq, ONLY : PIN_HOST
+  implicit none
+  logical, save :: done = .false.
+  integer, parameter :: NSPEC_a = 262, NSPEC_t = 424
+  integer :: nar
+  double precision :: ff, fsum, henry_a, xkmt_a, xkef_a, xkeb_a, henry_t, xkmt_t, xkef_t, xkeb_t
+  common /cb52/ ff(nkt,nka,n), fsum(n), nar(n)
+  common /kpp_laer/ henry_a(NSPEC_a,nf), xkmt_a(NSPEC_a,nkc,nf), xkef_a(NSPEC_a,nkc,nf), xkeb_a(NSPEC_a,nkc,nf)
+  common /kpp_ltot/ henry_t(NSPEC_t,nf), xkmt_t(NSPEC_t,nkc,nf), xkef_t(NSPEC_t,nkc,nf), xkeb_t(NSPEC_t,nkc,nf)
+  if (done) return
+  done = .true.
+  call PIN_HOST(ff, nkt * nka * n)
+  call PIN_HOST(henry_a, NSPEC_a * nf * (1 + 3 * nkc))      ! the four arrays of the block are contiguous
+  call PIN_HOST(henry_t, NSPEC_t * nf * (1 + 3 * nkc))
+end subroutine LIQ_PIN_ONCE
+
 subroutine CW_RC_HIP(nmaxf)                        ! cw_rc (nmaxf), kpp.f90:2152: layers 2..nmaxf
   USE config, ONLY : ifeed
   USE global_params, ONLY : n, nka, nkt, nkc
@@ -208,6 +226,7 @@ subroutine CW_RC_HIP(nmaxf)                        ! cw_rc (nmaxf), kpp.f90:2152
   common /kpp_crys/ xcryssulf, xcrysss, xdelisulf, xdeliss
   common /kinv_i/ kinv
   if (nmaxf < 2) return
+  call LIQ_PIN_ONCE      ! (cw_rc is liq_parm's first kernel call, kpp.f90:609)
   cl = merge(1, 0, cloud)
   call CW_RC_BATCH(nmaxf - 1, nkt, nka, .false., ff(1,1,2), rq, e, kw, ka, ifeed, feu(2), cl(1,2), [xcryssulf, xcrysss, xdelisulf, xdeliss], &
                    rc(1,2), cw(1,2), cm(1,2), conv2(1,2), below(2))

@@ -159,3 +159,35 @@ def test_dry_aerosol_uptake_on_the_device(mech):
         xk, xeq = chem.dry_rates(*a, g[mech + "_vmean4"])
         assert np.array_equal(xk, g[mech + "_xkmtd"])
     assert _rel(xeq, g[mech + "_xeq"]) <= TOL
+
+
+def test_registered_caller_memory_gives_the_same_results():
+    """mistra_chem_pin_host (what the Fortran drop-ins do once for the model's COMMON arrays): blocks inside a registered range travel without the staging
+    copy — same bits out; overlapping and unknown ranges are refused."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from mistra_amd import chem
+    chem.init(0)
+    g = np.load(os.path.join(REPO, "tests", "golden", "cwrc.npz"))
+    base = np.zeros((97,) + g["wet_ff"].shape[1:])
+    ff = base[:96]
+    ff[:] = np.concatenate([g["wet_ff"]] * 8)
+    feu, cloud = np.concatenate([g["wet_feu"]] * 8), np.concatenate([g["wet_cloud"]] * 8)
+    a = (g["rq"], g["e"], g["kw"], int(g["ka"]), int(g["ifeed"]), feu, cloud, g["crys4"])
+    plain = chem.cw_rc(ff, *a)
+    chem.pin_host(ff)
+    chem.pin_host(ff[1:])                               # inside a registered range: nothing to do
+    with pytest.raises(chem.MistraChemError):
+        chem.pin_host(base)                             # overlaps the registered range without lying inside it
+    try:
+        pinned = chem.cw_rc(ff, *a)
+        half = chem.cw_rc(ff[:40], *(a[:5] + (feu[:40], cloud[:40], g["crys4"])))      # a sub-run of the registered layers
+    finally:
+        chem.unpin_host(ff)
+    for x, y in zip(plain, pinned):
+        assert np.array_equal(x, y)
+    for x, y in zip(plain, half):
+        assert np.array_equal(x[:40], y)
+    assert np.array_equal(plain[0][:12], g["wet_rc"])
+    with pytest.raises(chem.MistraChemError):
+        chem.unpin_host(ff)                             # not registered any more
