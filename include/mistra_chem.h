@@ -197,6 +197,17 @@ int mistra_chem_drive_device(int mech, int ncell, double* d_s1, double* d_s3, do
 int mistra_chem_drive(int mech, int nlayer, const int32_t* layer, int n, double* s1, double* s3, double* sl1, double* sion1, const double* scal,
                       const double* env, double tin, double dt, int32_t* ierr, int32_t* stats, double* t_h, double* bg, int nrxn,
                       const int32_t* bg_level, double* bgs, double* c_packed);
+/* The same in two halves, so that the three mechanisms of one column step run SIDE BY SIDE on the device: kpp_driver gives every layer to one of
+ * gas / aer / tot (kpp.f90:4454-4467), the three batches touch disjoint rows of the model arrays, and a column's 148 cells leave most of the GPU's 256 CUs
+ * idle behind any one mechanism — a step then lasts as long as its slowest cell, not as the three mechanisms' slowest cells in a row (BTZ96: 14.4 -> 8.4 ms,
+ * INTEGRATION.md §4d).  mistra_chem_drive_begin takes mistra_chem_drive's arguments, gathers the layers, and returns once the copies and kernels are
+ * enqueued on the mechanism's private stream; mistra_chem_drive_end(mech) waits for them and scatters the results into the arrays given to begin.  Between
+ * the two the caller must not touch those arrays' rows (nor ierr, stats, t_h, c_packed); one step per mechanism may be open at a time.
+ * shim/mistra_kpp_drive.f90: KPP_DRIVE_RUN issues all mechanisms, then fetches them in mechanism order. */
+int mistra_chem_drive_begin(int mech, int nlayer, const int32_t* layer, int n, double* s1, double* s3, double* sl1, double* sion1, const double* scal,
+                      const double* env, double tin, double dt, int32_t* ierr, int32_t* stats, double* t_h, double* bg, int nrxn,
+                      const int32_t* bg_level, double* bgs, double* c_packed);
+int mistra_chem_drive_end(int mech);
 
 /* ---- liq_parm, first slice: the gas <-> particle mass-transfer coefficients of fast_k_mt_a (mech = aer;
  * kpp.f90:2683-2947) and fast_k_mt_t (mech = tot; kpp.f90:2421-2676), called by liq_parm every 120 s (kpp.f90:617,637), for nlayer

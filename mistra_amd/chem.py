@@ -89,6 +89,9 @@ def lib():
             L.mistra_chem_drive.argtypes = [C.c_int, C.c_int, _ip, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _ip, _ip, _dp, _dp, C.c_int,
                                             _ip, _dp, _dp]
             L.mistra_chem_debug_set_max_steps.argtypes = [C.c_int]
+        if hasattr(L, "mistra_chem_drive_begin"):
+            L.mistra_chem_drive_begin.argtypes = L.mistra_chem_drive.argtypes
+            L.mistra_chem_drive_end.argtypes = [C.c_int]
         L.mistra_chem_last_error.restype = C.c_char_p
         L.mistra_chem_describe.restype = C.c_char_p
         L.mistra_chem_describe.argtypes = [C.c_int]
@@ -328,10 +331,11 @@ def drive(mech, s1, s3, sl1, sion1, scal, env, var, fix, tin, dt, ierr, stats, t
                                           float(dt), _p(ierr), _p(stats), _p(texit_hexit), _p(bg), _p(bgs), _stream(var)))
 
 
-def drive_host(mech, layer, s1, s3, sl1, sion1, scal, env, tin, dt, bg=None, bg_level=None, bgs=None, want_c=False):
+def drive_host(mech, layer, s1, s3, sl1, sion1, scal, env, tin, dt, bg=None, bg_level=None, bgs=None, want_c=False, begin_only=False):
     """mistra_chem_drive: one x_drive per layer for the layers `layer` (k, 1-based) of the model arrays in HOST memory — numpy float64,
     C-contiguous, s1 [n, j1], s3 [n, j5], sl1 [n, nkc*j2], sion1 [n, nkc*j6], bg [nlev, nrxn, 2], bgs [n, 122, 2], updated in place; scal
-    [nlayer, 6], env [nlayer, nenv] per layer of the batch.  -> (ierr, stats, t_h[, c_packed])"""
+    [nlayer, 6], env [nlayer, nenv] per layer of the batch.  -> (ierr, stats, t_h[, c_packed]).  begin_only: mistra_chem_drive_begin — the call returns
+    with the work enqueued, the outputs are valid after drive_host_end(mech)."""
     mid, name = _mech_id(mech)
     lay = np.ascontiguousarray(layer, np.int32)
     nl = lay.size
@@ -344,10 +348,17 @@ def drive_host(mech, layer, s1, s3, sl1, sion1, scal, env, tin, dt, bg=None, bg_
     cp = np.zeros((nl, nvar + nfix)) if want_c else None
     lev = np.ascontiguousarray(bg_level, np.int32) if bg_level is not None else None
     P = lambda a: None if a is None else a.ctypes.data_as(_dp)
-    _check(lib().mistra_chem_drive(mid, nl, lay.ctypes.data_as(_ip), s1.shape[0], P(s1), P(s3), P(sl1), P(sion1), P(sc), P(ev), float(tin), float(dt),
-                                   ierr.ctypes.data_as(_ip), stats.ctypes.data_as(_ip), P(th), P(bg), 0 if bg is None else bg.shape[1],
-                                   None if lev is None else lev.ctypes.data_as(_ip), P(bgs), P(cp)))
-    return (ierr, stats, th, cp) if want_c else (ierr, stats, th)
+    fn = lib().mistra_chem_drive_begin if begin_only else lib().mistra_chem_drive
+    _check(fn(mid, nl, lay.ctypes.data_as(_ip), s1.shape[0], P(s1), P(s3), P(sl1), P(sion1), P(sc), P(ev), float(tin), float(dt),
+              ierr.ctypes.data_as(_ip), stats.ctypes.data_as(_ip), P(th), P(bg), 0 if bg is None else bg.shape[1],
+              None if lev is None else lev.ctypes.data_as(_ip), P(bgs), P(cp)))
+    out = (ierr, stats, th, cp) if want_c else (ierr, stats, th)
+    return out + ((lay, sc, ev, lev),) if begin_only else out      # (begin_only: the inputs ride along so that they outlive the call)
+
+
+def drive_host_end(mech):
+    """mistra_chem_drive_end: waits for the step drive_host(..., begin_only=True) issued for this mechanism and scatters its results."""
+    _check(lib().mistra_chem_drive_end(_mech_id(mech)[0]))
 
 
 def fast_k_mt(mech, ff, rq, kw, ka, ifeed, nkc_l, cw, cm, freep, alpha, vmean, xkmt, t=None, p=None, vt=None):

@@ -290,6 +290,14 @@ struct MechState {
   double* drv_host = nullptr;
   size_t drv_cap = 0;               // doubles
   hipStream_t drv_stream = nullptr;
+  struct PendingDrive {             // a column step issued by mistra_chem_drive_begin and not yet fetched by mistra_chem_drive_end
+    bool active = false;
+    std::vector<int32_t> layer, level;
+    double *s1 = nullptr, *s3 = nullptr, *sl1 = nullptr, *sion1 = nullptr, *bg = nullptr, *bgs = nullptr, *t_h = nullptr, *c_packed = nullptr;
+    int32_t *ierr = nullptr, *stats = nullptr;
+    int nrxn = 0;
+    size_t o_s1 = 0, o_s3 = 0, o_sl1 = 0, o_si = 0, o_bg = 0, o_bgs = 0, o_th = 0, o_hl = 0, o_int = 0, o_cp = 0;
+  } pend;
   // fast_k_mt_a / fast_k_mt_t (aer, tot): the exchanged species and the size-axis limits of the last call
   bool kmt_ready = false;
   KmtTable kmt_tab;
@@ -936,9 +944,9 @@ int mistra_chem_drive_device(int mech, int ncell, double* d_s1, double* d_s3, do
 // x_drive for a batch of layers from the model's own arrays in HOST memory (include/mistra_chem.h).  The layers' slabs are gathered into one
 // pinned block, go up in one copy, the device chain of mistra_chem_drive_device runs on a private stream, everything the model gets back
 // comes down in one copy and is scattered into the model arrays.  Primary device only: a column step is 148 layers.
-int mistra_chem_drive(int mech, int nlayer, const int32_t* layer, int n, double* s1, double* s3, double* sl1, double* sion1, const double* scal,
-                      const double* env, double tin, double dt, int32_t* ierr, int32_t* stats, double* t_h, double* bg, int nrxn,
-                      const int32_t* bg_level, double* bgs, double* c_packed) {
+int mistra_chem_drive_begin(int mech, int nlayer, const int32_t* layer, int n, double* s1, double* s3, double* sl1, double* sion1, const double* scal,
+                            const double* env, double tin, double dt, int32_t* ierr, int32_t* stats, double* t_h, double* bg, int nrxn,
+                            const int32_t* bg_level, double* bgs, double* c_packed) {
   if (int rc = lazy_init()) return rc;
   if (int rc = check_call(mech, nlayer)) return rc;
   if (nlayer == 0) return 0;
@@ -950,6 +958,7 @@ int mistra_chem_drive(int mech, int nlayer, const int32_t* layer, int n, double*
   if (!S.pack_ready) return fail(std::string("no hand-over table for the ") + kMechName[mech] + " mechanism");
   if (!S.maps_ready) return fail("mistra_chem_set_species_maps has not been called for this mechanism");
   if (!S.rates_ready) return fail("no device rate table for this mechanism");
+  if (S.pend.active) return fail("mistra_chem_drive_begin: the mechanism's previous step has not been fetched (mistra_chem_drive_end)");
   for (int i = 0; i < nlayer; i++) {
     if (layer[i] < 1 || layer[i] > n) return fail("layer index out of range");
     if (bg && (bg_level[i] < 0)) return fail("bg_level out of range");
@@ -1028,7 +1037,34 @@ int mistra_chem_drive(int mech, int nlayer, const int32_t* layer, int n, double*
   // what comes back: the in/out part and the out-only part (two copies: the in-only part between them stays up)
   HIP_TRY(hipMemcpyAsync(H, Dv, io_end * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(H + in_end, Dv + in_end, (out_end - in_end) * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  MechState::PendingDrive& Q = S.pend;
+  Q.layer.assign(layer, layer + nl);
+  if (bg) Q.level.assign(bg_level, bg_level + nl); else Q.level.clear();
+  Q.s1 = s1; Q.s3 = s3; Q.sl1 = sl1; Q.sion1 = sion1; Q.bg = bg; Q.bgs = bgs; Q.t_h = t_h; Q.c_packed = c_packed; Q.ierr = ierr; Q.stats = stats; Q.nrxn = nrxn;
+  Q.o_s1 = o_s1; Q.o_s3 = o_s3; Q.o_sl1 = o_sl1; Q.o_si = o_si; Q.o_bg = o_bg; Q.o_bgs = o_bgs; Q.o_th = o_th; Q.o_hl = o_hl; Q.o_int = o_int; Q.o_cp = o_cp;
+  Q.active = true;
+  return 0;
+}
+
+int mistra_chem_drive_end(int mech) {
+  if (int rc = check_call(mech, 1)) return rc;
+  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceState& D = g_devs[0];
+  MechState& S = D.mech[mech];
+  MechState::PendingDrive& Q = S.pend;
+  if (!Q.active) return fail("mistra_chem_drive_end: nothing issued for this mechanism");
+  Q.active = false;
+  HIP_TRY(hipSetDevice(D.id));
+  HIP_TRY(hipStreamSynchronize(S.drv_stream));
+  const PackTable& T = S.pack_tab;
+  const size_t nl = Q.layer.size(), j1 = (size_t)S.map_j1, j5 = (size_t)S.map_j5, nsl = (size_t)T.j2 * T.nkc, nsi = (size_t)T.j6 * T.nkc;
+  const size_t nv = (size_t)kDims[mech][0], nf = (size_t)kDims[mech][1], nr = (size_t)kDims[mech][2], nb = 2 * (size_t)kBudSlots;
+  const double* H = S.drv_host;
+  double *s1 = Q.s1, *s3 = Q.s3, *sl1 = Q.sl1, *sion1 = Q.sion1, *bg = Q.bg, *bgs = Q.bgs, *t_h = Q.t_h, *c_packed = Q.c_packed;
+  int32_t *ierr = Q.ierr, *stats = Q.stats;
+  const int nrxn = Q.nrxn;
+  const int32_t *layer = Q.layer.data(), *bg_level = Q.level.data();
+  const size_t o_s1 = Q.o_s1, o_s3 = Q.o_s3, o_sl1 = Q.o_sl1, o_si = Q.o_si, o_bg = Q.o_bg, o_bgs = Q.o_bgs, o_th = Q.o_th, o_hl = Q.o_hl, o_int = Q.o_int, o_cp = Q.o_cp;
   // ---- scatter
   const int32_t* h_int = reinterpret_cast<const int32_t*>(H + o_int);
   for (size_t i = 0; i < nl; i++) {
@@ -1045,6 +1081,14 @@ int mistra_chem_drive(int mech, int nlayer, const int32_t* layer, int n, double*
   }
   if (c_packed) std::memcpy(c_packed, H + o_cp, nl * (nv + nf) * sizeof(double));
   return 0;
+}
+
+int mistra_chem_drive(int mech, int nlayer, const int32_t* layer, int n, double* s1, double* s3, double* sl1, double* sion1, const double* scal,
+                      const double* env, double tin, double dt, int32_t* ierr, int32_t* stats, double* t_h, double* bg, int nrxn,
+                      const int32_t* bg_level, double* bgs, double* c_packed) {
+  if (int rc = mistra_chem_drive_begin(mech, nlayer, layer, n, s1, s3, sl1, sion1, scal, env, tin, dt, ierr, stats, t_h, bg, nrxn, bg_level, bgs, c_packed)) return rc;
+  if (nlayer == 0) return 0;
+  return mistra_chem_drive_end(mech);
 }
 
 int mistra_chem_fast_k_mt_device(int mech, int nlayer, const double* d_ff, const double* d_rq, const int32_t* kw, int nkw, int ka, int ifeed,

@@ -157,6 +157,51 @@ def test_host_driver_call_against_a_captured_column_step(chem, case):
           "bit-identical to the device-resident chain" % (case, worst_bits, np.bincount(g["mech"], minlength=3).tolist(), worst))
 
 
+@pytest.mark.parametrize("case", ["base1", "BTZ96"])
+def test_mechanisms_of_a_step_side_by_side(chem, case):
+    """mistra_chem_drive_begin for every mechanism of the step, then mistra_chem_drive_end in mechanism order (what KPP_DRIVE_RUN does): the batches touch
+    disjoint rows of the model arrays and run on streams of their own — every bit as one mechanism after the other, and the step lasts as long as its
+    slowest mechanism."""
+    import time
+    g = _load(case)
+
+    for m, mech in enumerate(MECHS):      # (once, as the model does: the call uploads tables and waits for the device)
+        if (g["mech"] == m).any():
+            chem.set_species_maps(mech, g[mech + "_gas_m2k"], g[mech + "_gas_k2m"], g[mech + "_rad_m2k"], g[mech + "_rad_k2m"])
+
+    def step(side_by_side):
+        a = _model_arrays(g)
+        open_, out, keep = [], {}, []
+        for m, mech in enumerate(MECHS):
+            idx = np.nonzero(g["mech"] == m)[0]
+            if idx.size == 0:
+                continue
+            r = chem.drive_host(mech, g["k"][idx], a["s1"], a["s3"], a["sl1"], a["sion1"], g["scal"][idx], g["env"][idx, :NENV[mech]].copy(), 0.0, 10.0, bg=a["bg"],
+                                bg_level=g["level"][idx], bgs=a["bgs"], begin_only=side_by_side)
+            out[mech] = r[:3]
+            keep.append(r)
+            if side_by_side:
+                open_.append(mech)
+        for mech in open_:
+            chem.drive_host_end(mech)
+        return a, out
+
+    a1, o1 = step(False)
+    a2, o2 = step(True)
+    for key in a1:
+        assert np.array_equal(a1[key], a2[key]), "%s differs between the mechanisms one after the other and side by side" % key
+    for mech in o1:
+        for x, y in zip(o1[mech], o2[mech]):
+            assert np.array_equal(x, y)
+    with pytest.raises(chem.MistraChemError):
+        chem.drive_host_end("gas")      # nothing open
+    t = {}
+    for mode in (False, True, False, True):
+        t0 = time.perf_counter(); step(mode); t.setdefault(mode, []).append((time.perf_counter() - t0) * 1e3)
+    print("%s: column step, mechanisms one after the other %.2f ms, side by side %.2f ms (wall, Python staging included)" % (case, min(t[False]), min(t[True])))
+    assert min(t[True]) < 1.05 * min(t[False])
+
+
 needs_flang = pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/flang"), reason="no Fortran compiler here")
 
 
