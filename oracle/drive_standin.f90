@@ -1,4 +1,4 @@
-! TEST INFRASTRUCTURE — stands in for libmistra_chem.so's mistra_chem_drive in the CPU validation build of the single-pass batched
+! TEST INFRASTRUCTURE — stands in for libmistra_chem.so's mistra_chem_drive_begin / _end in the CPU validation build of the single-pass batched
 ! kpp_driver (oracle/build_drive.sh; shim/kpp_drive.patch, shim/mistra_kpp_drive.f90, shim/mistra_kpp_model.f90 — all unmodified).
 ! There is no GPU in the build container, so the call is served by the REFERENCE's own drivers: for every staged layer the x_drive
 ! argument list is rebuilt from nothing but what crossed the C boundary — the layer number, scal (air, h2o, cvv1..4) and the rate
@@ -21,8 +21,10 @@ function mistra_chem_set_species_maps(mech, j1, gas_m2k, gas_k2m, j5, rad_m2k, r
   rc = 0
 end function mistra_chem_set_species_maps
 
-function mistra_chem_drive(mech, nlayer, layer, n, s1, s3, sl1, sion1, scal, env, tin, dt, ierr, stats, t_h, bg, nrxn, bg_level, bgs, c_packed) &
-     bind(C, name="mistra_chem_drive") result(rc)
+! (KPP_DRIVE_RUN issues every mechanism with _begin and fetches with _end; here _begin serves the layers at once — each mechanism's layers are its own —
+!  and _end has nothing left to do)
+function mistra_chem_drive_begin(mech, nlayer, layer, n, s1, s3, sl1, sion1, scal, env, tin, dt, ierr, stats, t_h, bg, nrxn, bg_level, bgs, c_packed) &
+     bind(C, name="mistra_chem_drive_begin") result(rc)
   use iso_c_binding
   use drive_standin_idx
   use mistra_kpp_batch, only: kpp_pass
@@ -79,4 +81,12 @@ contains
     pick = 0.d0
     if (slot > 0) pick = env(base + slot)
   end function pick
-end function mistra_chem_drive
+end function mistra_chem_drive_begin
+
+function mistra_chem_drive_end(mech) bind(C, name="mistra_chem_drive_end") result(rc)
+  use iso_c_binding
+  implicit none
+  integer(c_int), value :: mech
+  integer(c_int) :: rc
+  rc = 0
+end function mistra_chem_drive_end
