@@ -151,19 +151,23 @@ __device__ double vterm_dev(double a, double t, double p) {
 // (str.f90:2704, 2751):
 //     xx1 = sum_ia sum_jt  r*r*r * vterm(r, t, p) * ff(jt,ia) * 1e6                       (the routine's l = 1 pass)
 //     vt(kc) = 4 pi / (3 cw(kc)) * xx1                                                    where cw(kc) > 0
-// One workgroup of sixteen waves per (layer, bin).  A sum's ORDER is its value (ia outer, jt inner; one rounding per operation) but its terms are not
-// ordered: waves 1..15 form the terms of a chunk of 60 grid cells — lane = species, every lane of a wave at the same cell, so ff / rq are broadcast reads;
-// a cell outside the bin's jt range contributes +0.0, which leaves a non-negative sum as it is — into one half of an LDS buffer while wave 0 adds the
-// previous chunk's terms, cell by cell in the reference's order, out of the other half (lane = species; its reads run ahead of the add chain).  The vt sum
-// rides in lane 63: its terms (Beard's polynomial, the expensive one) are formed by lanes 60..63 of each wave, one cell each.  Bit-identical to the thread
-// per species that walked the whole bin alone (the round-3 kernel: 0.64 ms per column against ~0.06 ms).
-constexpr int kKmtWaves = 16, kKmtU = 4, kKmtCells = (kKmtWaves - 1) * kKmtU;      // 60 cells per chunk, 2 x 30 KB of LDS
+// One workgroup of sixteen waves per (layer, bin), a pipeline of three stages with one barrier per chunk of 56 grid cells.  A sum's ORDER is its value (ia
+// outer, jt inner; one rounding per operation) but its terms are not ordered:
+//   wave 15, lane = CELL: what does not depend on the species — the cell's radius, its ff, the quotient r/freep and the vt term (Beard's polynomial,
+//            the expensive one: once per cell here instead of once per cell and wave) — for chunk i+1, into LDS;
+//   waves 1..14, lane = SPECIES, four cells each: the terms of chunk i (one IEEE division per cell and species) out of the cell data, into LDS; a cell
+//            outside the bin's jt range contributes +0.0, which leaves a non-negative sum as it is; lane 63 passes the vt term on;
+//   wave 0, lane = species: adds the terms of chunk i-1, cell by cell in the reference's order (its reads run ahead of the add chain).
+// Bit-identical to the thread per species that walked the whole bin alone (the round-3 kernel: 0.64 ms per column).
+constexpr int kKmtWaves = 16, kKmtU = 4, kKmtCells = (kKmtWaves - 2) * kKmtU;      // 56 cells per chunk (<= 64: one lane of wave 15 each)
 __global__ __launch_bounds__(kKmtWaves * 64) void fast_k_mt_kernel(const KmtDev K, int nlayer, const double* __restrict__ ff, const double* __restrict__ rq,
                                                                     const double* __restrict__ cw, const double* __restrict__ cm,
                                                                     const double* __restrict__ freep, const double* __restrict__ alpha,
                                                                     const double* __restrict__ vmean, double* __restrict__ xkmt,
                                                                     const double* __restrict__ tt, const double* __restrict__ pp, double* __restrict__ vt) {
-  __shared__ double buf[2][kKmtCells][64];
+  __shared__ double term[2][kKmtCells][64];      // 2 x 28 KB
+  __shared__ double cell[2][4][64];              // per cell of a chunk: r [m], ff, r/freep, the vt term (0: outside the bin)
+  __shared__ int inbin[2][64];
   const int layer = blockIdx.x, kc = blockIdx.y + 1, w = threadIdx.x / 64, l = threadIdx.x % 64;      // kc 1-based as in the Fortran
   if (layer >= nlayer || kc > K.nkc_l) return;                                                          // (uniform in the workgroup, like every exit below)
   const double cmk = cm[(size_t)layer * K.nkc + (kc - 1)], cwk = cw[(size_t)layer * K.nkc + (kc - 1)];
@@ -182,44 +186,49 @@ __global__ __launch_bounds__(kKmtWaves * 64) void fast_k_mt_kernel(const KmtDev 
   const int ncell = ia1 >= ia0 ? (ia1 - ia0 + 1) * K.nkt : 0, nchunk = (ncell + kKmtCells - 1) / kKmtCells;
   const double* F = ff + (size_t)layer * K.nka * K.nkt;      // ff(jt,ia,k): jt fastest
   double acc = 0.0;                               // wave 0: xk1 of species l; lane 63: xx1
-  for (int i = 0; i <= nchunk; i++) {
-    if (w > 0 && i < nchunk) {
-      double (*B)[64] = buf[i & 1];
-      const int n0 = i * kKmtCells + (w - 1) * kKmtU;
-#pragma unroll
-      for (int u = 0; u < kKmtU; u++) {
-        const int n = n0 + u, ia = ia0 + n / K.nkt, jt = 1 + n % K.nkt;
-        double term = 0.0;
+  for (int i = 0; i < nchunk + 2; i++) {
+    if (w == kKmtWaves - 1) {
+      if (i < nchunk && l < kKmtCells) {          // chunk i: this lane's cell
+        const int n = i * kKmtCells + l, ia = ia0 + n / K.nkt, jt = 1 + n % K.nkt;
+        bool in = false;
+        double rqq = 0.0, fv = 0.0, q = 0.0, tv = 0.0;
         if (n < ncell) {
           const int kwa = K.kw[ia - 1];
-          if (low_jt ? jt <= kwa : jt > kwa) {
-            const double rqq = rq[(size_t)(ia - 1) * K.nkt + (jt - 1)] * 1.0e-6;      // rqm = rq * 1.d-6
-            const double fv = F[(size_t)(ia - 1) * K.nkt + (jt - 1)];
-            if (species) {
-              const double x2 = vm / (rqq / fp + x1);
-              term = (((x2 * rqq) * rqq) * fv) * 1.0e6;
+          in = low_jt ? jt <= kwa : jt > kwa;
+          if (in) {
+            rqq = rq[(size_t)(ia - 1) * K.nkt + (jt - 1)] * 1.0e-6;      // rqm = rq * 1.d-6
+            fv = F[(size_t)(ia - 1) * K.nkt + (jt - 1)];
+            q = rqq / fp;
+            if (do_vt) {
+              const double xvs = vterm_dev(rqq, tk, pk);
+              tv = ((((rqq * rqq) * rqq) * xvs) * fv) * 1.0e6;
             }
           }
         }
-        B[(w - 1) * kKmtU + u][l] = term;
+        cell[i & 1][0][l] = rqq; cell[i & 1][1][l] = fv; cell[i & 1][2][l] = q; cell[i & 1][3][l] = tv;
+        inbin[i & 1][l] = in ? 1 : 0;
       }
-      if (do_vt && l >= 64 - kKmtU) {             // (behind the stores above: lane 63's zero is overwritten)
-        const int u = l - (64 - kKmtU), n = n0 + u, ia = ia0 + n / K.nkt, jt = 1 + n % K.nkt;
-        double term = 0.0;
-        if (n < ncell) {
-          const int kwa = K.kw[ia - 1];
-          if (low_jt ? jt <= kwa : jt > kwa) {
-            const double rqq = rq[(size_t)(ia - 1) * K.nkt + (jt - 1)] * 1.0e-6;
-            const double fv = F[(size_t)(ia - 1) * K.nkt + (jt - 1)];
-            const double xvs = vterm_dev(rqq, tk, pk);
-            term = ((((rqq * rqq) * rqq) * xvs) * fv) * 1.0e6;
+    } else if (w > 0) {
+      if (i >= 1 && i <= nchunk) {                // chunk i-1: this wave's four cells
+        const int b = (i - 1) & 1;
+#pragma unroll
+        for (int u = 0; u < kKmtU; u++) {
+          const int c = (w - 1) * kKmtU + u;
+          double t = 0.0;
+          if (inbin[b][c]) {                      // (uniform in the wave)
+            const double rqq = cell[b][0][c], fv = cell[b][1][c], q = cell[b][2][c];
+            if (species) {
+              const double x2 = vm / (q + x1);
+              t = (((x2 * rqq) * rqq) * fv) * 1.0e6;
+            }
+            if (l == 63) t = cell[b][3][c];
           }
+          term[b][c][l] = t;
         }
-        B[(w - 1) * kKmtU + u][63] = term;
       }
-    } else if (w == 0 && i > 0) {
-      const double (*B)[64] = buf[(i - 1) & 1];
-#pragma unroll 4
+    } else if (i >= 2) {                          // chunk i-2
+      const double (*B)[64] = term[i & 1];
+#pragma unroll 8
       for (int c = 0; c < kKmtCells; c++) acc = acc + B[c][l];
     }
     __syncthreads();
@@ -448,7 +457,7 @@ hipError_t launch_equil_co(const LiqDev& L, int nlayer, int nkc, int j6, const d
 hipError_t launch_fast_k_mt(const KmtDev& K, int nlayer, const double* ff, const double* rq, const double* cw, const double* cm, const double* freep,
                             const double* alpha, const double* vmean, double* xkmt, const double* tt, const double* pp, double* vt, hipStream_t stream) {
   if (nlayer <= 0) return hipSuccess;
-  if (K.nx > 64 - kKmtU || K.nka > kKmtMaxNka) return hipErrorInvalidValue;      // (lanes 60..63 form the vt terms)
+  if (K.nx > 63 || K.nka > kKmtMaxNka) return hipErrorInvalidValue;      // (lane 63 carries the vt sum)
   hipLaunchKernelGGL(fast_k_mt_kernel, dim3((unsigned)nlayer, (unsigned)K.nkc_l), dim3(kKmtWaves * 64), 0, stream, K, nlayer, ff, rq, cw, cm, freep, alpha, vmean, xkmt, tt, pp, vt);
   return hipGetLastError();
 }
