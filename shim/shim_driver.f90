@@ -283,6 +283,11 @@ contains
     rc = -7.d0; cw = -7.d0; cm = -7.d0; conv2 = -7.d0; below = -7
     call CW_RC_BATCH(nl, nkt, nka, dry, ff, rq, e, kw, ka, ifeed, feu, cloud, crys4, rc, cw, cm, conv2, below)
     write (12) rc, cw, cm, conv2, dble(below)
+    ! once more with the spectrum registered for direct transfers, as LIQ_PIN_ONCE does for the model's /cb52/ (same bits; the test compares)
+    call PIN_HOST(ff, nkt * nka * nl)
+    rc = -7.d0; cw = -7.d0; cm = -7.d0; conv2 = -7.d0; below = -7
+    call CW_RC_BATCH(nl, nkt, nka, dry, ff, rq, e, kw, ka, ifeed, feu, cloud, crys4, rc, cw, cm, conv2, below)
+    write (12) rc, cw, cm, conv2, dble(below)
   end subroutine run_cw_rc
   subroutine run_drive(fin, fout)
     use mistra_kpp_drive

@@ -273,13 +273,15 @@ def test_fortran_particle_bin_moments(tmp_path):
             for a in (g["kw"].astype(np.float64), g["rq"], g["e"], g["crys4"], ff, g[pre + "_feu"], g[pre + "_cloud"].astype(np.float64)):
                 np.ascontiguousarray(a, np.float64).tofile(f)
         subprocess.run([DRIVER, "Ca", str(fin), str(fout)], check=True, timeout=300)
-        raw = np.fromfile(fout, np.float64)
+        both = np.fromfile(fout, np.float64)
         nb = 2 if dry else 4
-        rc, cw, cm, cv = (raw[i * nl * nb:(i + 1) * nl * nb].reshape(nl, nb) for i in range(4))
-        assert np.array_equal(rc, g[pre + "_rc"][:, :nb]) and np.array_equal(cw, g[pre + "_cw"][:, :nb])
-        if not dry:
-            assert np.array_equal(cm, g["wet_cm"]) and np.array_equal(cv, g["wet_conv2"])
-            assert np.array_equal(raw[4 * nl * nb:], (g["wet_feu"] < g["crys4"][:2].min()).astype(np.float64))
+        assert both.size == 2 * (4 * nl * nb + nl)      # the driver makes the call twice: plain, then with the spectrum registered (PIN_HOST)
+        for raw in (both[:both.size // 2], both[both.size // 2:]):
+            rc, cw, cm, cv = (raw[i * nl * nb:(i + 1) * nl * nb].reshape(nl, nb) for i in range(4))
+            assert np.array_equal(rc, g[pre + "_rc"][:, :nb]) and np.array_equal(cw, g[pre + "_cw"][:, :nb])
+            if not dry:
+                assert np.array_equal(cm, g["wet_cm"]) and np.array_equal(cv, g["wet_conv2"])
+                assert np.array_equal(raw[4 * nl * nb:], (g["wet_feu"] < g["crys4"][:2].min()).astype(np.float64))
 
 
 @needs_flang
