@@ -31,6 +31,10 @@ program mistra_column_capture
   character(len=32) :: envbuf
   real(dp) :: xra, u0_floor, box_switch
   logical :: daylight, llnucboth
+  ! end-to-end runs (oracle/build_gpu_model.sh, tests/test_gpu_model.py): wall time of the chemistry stem, the model's chemical state at the end
+  integer(8) :: clk0, clk1, clk_rate, clk_chem, clk_start
+  character(len=512) :: dumpfile
+  integer :: dumpstat
 
   ! the handful of reference COMMON members this loop has to advance itself
   real(dp) :: u0, albedo, thk
@@ -89,6 +93,8 @@ program mistra_column_capture
   call get_environment_variable('MISTRA_COLUMN_MINUTES', envbuf, status=envstat)      ! shorter runs for the test-suite
   max_minutes = 60 * lstmax
   if (envstat == 0) read (envbuf, *) max_minutes
+  clk_chem = 0
+  call system_clock(clk_start, clk_rate)
   do minutes = 1, min(max_minutes, 60 * lstmax)
      it = minutes
      if (lct > nf) stop 'cloud top above nf'
@@ -108,7 +114,9 @@ program mistra_column_capture
            call box_update(box_switch, sub, nlevbox, nz_box, nbl, BL_box)
            call sedc_box(dt_fast, z_box, nbl)
            call box_partdep(dt_fast, z_box, nbl)
+           call system_clock(clk0)
            call stem_kpp(dt_fast, xra, z_box, nbl, box, chamber, nuc)
+           call system_clock(clk1); clk_chem = clk_chem + (clk1 - clk0)
            cycle
         end if
         call difm(dt_fast)
@@ -123,7 +131,9 @@ program mistra_column_capture
         call surf0(dt_fast)
         call sedc(dt_fast)
         call sedl(dt_fast)
+        call system_clock(clk0)
         call stem_kpp(dt_fast, xra, z_box, nbl, box, chamber, nuc)
+        call system_clock(clk1); clk_chem = clk_chem + (clk1 - clk0)
         if (nuc) then                     ! src/str.f90:397-402
            if (llnucboth) then
               call appnucl2(dt_fast, llnucboth)
@@ -159,4 +169,24 @@ program mistra_column_capture
      end if
      if (mod(minutes, 10) == 0) write (0, '(a,i5,a,i3,a,i3)') ' [column] minute ', minutes, '  lcl ', lcl, '  lct ', lct
   end do
+  call system_clock(clk1)
+  write (0, '(a,i6,a,f10.3,a,f10.3,a)') ' [column] ', min(max_minutes, 60 * lstmax) * 6, ' steps of 10 s: chemistry stem (liq_parm + kpp_driver + the rest of stem_kpp) ', &
+       dble(clk_chem) / dble(clk_rate), ' s of ', dble(clk1 - clk_start) / dble(clk_rate), ' s in the time loop'
+  call get_environment_variable('MISTRA_COLUMN_DUMP', dumpfile, status=dumpstat)
+  if (dumpstat == 0 .and. len_trim(dumpfile) > 0) call dump_chemical_state(trim(dumpfile))
+contains
+  ! the chemical state the column ends in: s1, s3 of module gas_common, sl1 / sion1 of /blck17/, the temperature profile; stream of doubles behind
+  ! four int32 {j1, j5, j2*nkc, j6*nkc} and n
+  subroutine dump_chemical_state(path)
+    use gas_common, only: j1, j5, s1, s3
+    use global_params, only: j2, j6, nkc
+    character(len=*), intent(in) :: path
+    real(dp) :: sl1, sion1
+    common /blck17/ sl1(j2, nkc, n), sion1(j6, nkc, n)
+    integer :: u
+    open (newunit=u, file=path, access='stream', form='unformatted', status='replace')
+    write (u) int(j1, 4), int(j5, 4), int(j2 * nkc, 4), int(j6 * nkc, 4), int(n, 4)
+    write (u) s1(1:j1, 1:n), s3(1:j5, 1:n), sl1, sion1, t
+    close (u)
+  end subroutine dump_chemical_state
 end program mistra_column_capture
