@@ -45,6 +45,14 @@ objs=""; for m in $MODS $BUD $REST; do objs="$objs $O/$m.o"; done
     mistra_kpp_drive.o mistra_kpp_liq.o mistra_kpp_model.o \
     -Wl,--wrap=integrate_g_ -Wl,--wrap=integrate_a_ -Wl,--wrap=integrate_t_ \
     -L"$HERE/../mistra_amd/lib" -lmistra_chem -Wl,-rpath,'$ORIGIN/../../mistra_amd/lib' -Wl,-rpath,/opt/rocm/lib -Wl,--unresolved-symbols=ignore-all
+# the same with a clock around liq_parm, kpp_driver and what they call (time_liq_wrap.c): where a step's time goes inside the running model
+gcc -O2 -c "$HERE/time_liq_wrap.c" -o time_liq_wrap.o
+TW=""; for r in stem_kpp liq_parm gasdrydep activ pitzer kpp_driver kpp_drive_run cw_rc_hip v_mean_hip_a henry_hip_a st_coeff_hip_a equil_co_hip_a fast_k_mt_hip_a \
+    v_mean_hip_t henry_hip_t st_coeff_hip_t equil_co_hip_t fast_k_mt_hip_t dry_cw_rc_hip dry_rates_hip_g dry_rates_hip_a dry_rates_hip_t; do TW="$TW -Wl,--wrap=${r}_"; done
+"$FC" -o "$OUT/mistra_gpu_time" "$O/column_driver.o" $objs gas.o aer.o tot.o kpp.o "$O/str_lib.o" mistra_kpp_batch.o shim_wrap.o mistra_kpp_rates.o \
+    mistra_kpp_drive.o mistra_kpp_liq.o mistra_kpp_model.o time_liq_wrap.o $TW \
+    -Wl,--wrap=integrate_g_ -Wl,--wrap=integrate_a_ -Wl,--wrap=integrate_t_ \
+    -L"$HERE/../mistra_amd/lib" -lmistra_chem -Wl,-rpath,'$ORIGIN/../../mistra_amd/lib' -Wl,-rpath,/opt/rocm/lib -Wl,--unresolved-symbols=ignore-all
 rm -rf "$TP/src"      # the patched scratch copies are build inputs only: nothing of the reference's text stays under the repo
 # ---- run-time DATA of the model (no source): initial profiles and radiation / photolysis tables, species lists and index tables, namelists
 IN="$OUT/model_inputs"
