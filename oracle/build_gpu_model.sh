@@ -59,5 +59,5 @@ IN="$OUT/model_inputs"
 rm -rf "$IN"; mkdir -p "$IN/input" "$IN/mech" "$IN/namelists"
 cp -r "$REFROOT"/input/*.dat "$REFROOT"/input/photolys "$IN/input/"
 cp "$REFROOT"/src/mech/*.csv "$REFROOT"/src/mech/*.dat "$IN/mech/"
-for c in Joyce2014_basecase base1 BTZ96; do cp "$REFROOT/namelists/namelist.$c" "$IN/namelists/"; done
+for c in Joyce2014_basecase base1 BTZ96 Buys13_0D Bott2020; do cp "$REFROOT/namelists/namelist.$c" "$IN/namelists/"; done
 echo "oracle/_ref/mistra_gpu ready (inputs: $(du -sh "$IN" | cut -f1))"

@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.join(HERE, "..", "..")
 REF = os.path.join(REPO, "oracle", "_ref")
-CASES = (("Joyce2014_basecase", 5), ("BTZ96", 10))
+CASES = (("Joyce2014_basecase", 5), ("BTZ96", 10), ("Buys13_0D", 10), ("Bott2020", 5))
 
 
 def load_dump(path):

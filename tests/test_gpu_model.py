@@ -5,7 +5,9 @@ unmodified Fortran shim and the product library; it reads the model's run-time D
 leaves its chemical end state in a file.  Expected: the end state of the UNPATCHED model on the CPU (tests/golden/endstate_<case>.npz,
 make_endstate_golden.py).  Tolerances: the gas-only Joyce2014 column 1e-12 (measured 2e-15: every layer sits at the integrator's 7-step floor, where the
 kernel is bit-identical to the reference in all but the last place); the stratus column BTZ96 — 34 tot, 46 aer, 68 gas layers, 60 steps that feed back through
-cloud water and sedimentation — 1e-4 of an entry above 1e-3 of its species' column maximum (measured 1.3e-6; the integrator's own RTOL is 1e-3)."""
+cloud water and sedimentation — 1e-4 of an entry above 1e-3 of its species' column maximum (measured 1.3e-6; the integrator's own RTOL is 1e-3).  Also the
+box case namelist.Buys13_0D (BASELINE configs[0]: one aer cell per step; 1e-5, measured 1e-7 after 180 steps) and namelist.Bott2020 with chem = T (1e-4,
+measured 9e-6)."""
 import os
 import subprocess
 
@@ -31,7 +33,7 @@ def _load_dump(path):
 
 
 @pytest.mark.skipif(not have_model, reason="oracle/_ref/mistra_gpu is built where the reference tree is (oracle/build_gpu_model.sh)")
-@pytest.mark.parametrize("case,tol", [("Joyce2014_basecase", 1e-12), ("BTZ96", 1e-4)])
+@pytest.mark.parametrize("case,tol", [("Joyce2014_basecase", 1e-12), ("BTZ96", 1e-4), ("Buys13_0D", 1e-5), ("Bott2020", 1e-4)])
 def test_reference_model_with_its_chemistry_on_the_gpu(case, tol, tmp_path):
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU"
