@@ -86,3 +86,23 @@ def test_patches_in_the_repo_are_what_the_generator_writes(tmp_path, mode, name)
     subprocess.run(["python3", os.path.join(REPO, "oracle", "two_pass_patch.py"), "--mode", mode, "/root/reference/src", str(tmp_path / "src"), str(out)],
                    check=True, stdout=subprocess.DEVNULL)
     assert out.read_text() == open(os.path.join(REPO, "shim", name)).read()
+
+
+def test_the_gpu_model_build_stages_data_only():
+    """oracle/build_gpu_model.sh stages what the end-to-end GPU run (tests/test_gpu_model.py) reads at run time under oracle/_ref/model_inputs, because the
+    reference tree does not exist on the GPU box: initial profiles, radiation / photolysis tables, species lists, namelists — DATA.  No source file of the
+    reference may be among them, and the scratch copies of the four patched files must be gone."""
+    root = os.path.join(REPO, "oracle", "_ref", "model_inputs")
+    if not os.path.isdir(root):
+        pytest.skip("oracle/build_gpu_model.sh has not run here (no reference tree)")
+    seen = []
+    for d, _, files in os.walk(root):
+        for f in files:
+            seen.append(os.path.relpath(os.path.join(d, f), root))
+            ext = os.path.splitext(f)[1].lower()
+            assert ext in (".dat", ".csv", "") or f.startswith("namelist."), "not a data file: " + seen[-1]
+            assert ext not in (".f", ".f90", ".h", ".sc", ".eqn", ".def", ".spc", ".k", ".bud")
+            head = open(os.path.join(d, f), "rb").read(4096).lower()
+            assert b"subroutine" not in head and b"end module" not in head, "source text in " + seen[-1]
+    assert any(s.startswith("namelists/namelist.") for s in seen) and any(s.startswith("mech/") and s.endswith(".csv") for s in seen)
+    assert not os.path.exists(os.path.join(REPO, "oracle", "_ref", "gpu_model", "src")), "patched scratch copies of reference files left behind"
