@@ -353,6 +353,7 @@ struct MechState {
     if (one_stream) (void)hipStreamDestroy(one_stream);
     one_dev = one_host = nullptr;
     one_stream = nullptr;
+    pend = PendingDrive{};      // (a step issued and never fetched dies with its buffers)
     ready = false;
   }
 };
